@@ -1,0 +1,176 @@
+/*
+ * nequip_amd.h -- C ABI of libnequip_amd.so, the MI355X (gfx950) implementation of the NequIP
+ * message-passing hot path.
+ *
+ * The reference (mir-group/nequip v0.19.0) is pure Python and has no FFI; its seam for accelerated
+ * kernels is the torch.nn.Module contract of `TensorProductScatter` plus the `enable_*` model
+ * modifiers (nequip/nn/_tp_scatter_base.py:9-109, adapters nequip/nn/_tp_scatter_oeq.py:4-57 and
+ * nequip/nn/_tp_scatter_cueq.py:66-122).  This header is the native boundary that sits *under* that
+ * contract: every entry point below names the reference interface it replaces.  The Python host side
+ * (nequip_amd/nn/...) binds these symbols with ctypes and mirrors the reference module API on top.
+ *
+ * Conventions
+ *  - Every data pointer is a *borrowed device pointer* (HIP global memory) owned by the caller; the
+ *    library never allocates or frees result buffers.  Scratch comes from caller-provided workspaces
+ *    sized by the matching *_workspace_bytes query.
+ *  - Kernels are enqueued asynchronously on the passed `stream` (a hipStream_t); no entry point
+ *    synchronises the device and there is no global mutable state besides immutable plans.
+ *  - Return value: NQA_OK (0) or a negative error code; nqa_last_error() returns a thread-local
+ *    human-readable message.  The host side converts non-zero codes to RuntimeError, matching the
+ *    reference's exception-only error convention.
+ *  - Feature layout is e3nn "mul_ir" ([mul, 2l+1], m fastest) unless the plan was created with
+ *    NQA_LAYOUT_IR_MUL for that operand.  Edge attributes have mul == 1 per irrep.
+ *  - dtype selects the arithmetic/storage type of feature tensors: NQA_F32 or NQA_F64 (the reference's
+ *    `model_dtype`, nequip/nn/_tp_scatter_base.py:33).  Edge vectors are always float64
+ *    (nequip/utils/global_dtype.py:5).
+ */
+#ifndef NEQUIP_AMD_H
+#define NEQUIP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NQA_ABI_VERSION 1
+
+enum nqa_status {
+  NQA_OK = 0,
+  NQA_ERR_INVALID = -1,     /* bad argument / inconsistent irreps or instruction            */
+  NQA_ERR_UNSUPPORTED = -2, /* l > NQA_LMAX, unsupported dtype, ...                          */
+  NQA_ERR_LAUNCH = -3,      /* HIP launch / runtime failure                                  */
+  NQA_ERR_WORKSPACE = -4    /* workspace missing or too small                                */
+};
+
+enum nqa_dtype { NQA_F32 = 0, NQA_F64 = 1 };
+enum nqa_layout { NQA_LAYOUT_MUL_IR = 0, NQA_LAYOUT_IR_MUL = 1 };
+
+enum nqa_plan_field {
+  NQA_PLAN_DIM_IN1 = 0,      /* feature_irreps_in.dim                                        */
+  NQA_PLAN_DIM_IN2 = 1,      /* irreps_edge_attr.dim                                         */
+  NQA_PLAN_DIM_OUT = 2,      /* irreps_mid.dim                                               */
+  NQA_PLAN_WEIGHT_NUMEL = 3, /* e3nn TensorProduct.weight_numel                              */
+  NQA_PLAN_NUM_INSTR = 4,
+  NQA_PLAN_OUT_NEEDS_ZERO = 5, /* 1 if output slots are shared/uncovered (caller must zero `out`) */
+  NQA_PLAN_YPART_WIDTH = 6   /* columns of the per-edge dY partial buffer (bwd_edge workspace) */
+};
+
+typedef struct nqa_plan nqa_plan;
+typedef void* nqa_stream; /* hipStream_t */
+
+int nqa_abi_version(void);
+const char* nqa_last_error(void);
+/* largest supported l for features / edge attributes / outputs, and for spherical harmonics */
+int nqa_lmax(void);
+int nqa_sh_lmax(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Plan: replaces the constructor of nequip.nn.TensorProductScatter
+ *   __init__(feature_irreps_in, irreps_edge_attr, irreps_mid, instructions)
+ *   (nequip/nn/_tp_scatter_base.py:10-33), i.e. e3nn TensorProduct(..., 'uvu' instructions,
+ *   shared_weights=False, internal_weights=False, irrep_normalization="component",
+ *   path_normalization="element").  Built once from exactly those four arguments; immutable and
+ *   thread-safe afterwards.  Each irreps operand is given as parallel arrays (mul, l, p) with
+ *   p = +1 (even) / -1 (odd).  Instructions are (i_in1, i_in2, i_out) index triples, mode "uvu";
+ *   path_weight may be NULL (all 1.0).  The weight tensor is consumed in instruction-list order,
+ *   mul_in1 values per instruction.
+ * ------------------------------------------------------------------------------------------- */
+int nqa_plan_create(int32_t n_in1, const int32_t* in1_mul, const int32_t* in1_l, const int32_t* in1_p,
+                    int32_t n_in2, const int32_t* in2_mul, const int32_t* in2_l, const int32_t* in2_p,
+                    int32_t n_out, const int32_t* out_mul, const int32_t* out_l, const int32_t* out_p,
+                    int32_t n_instr, const int32_t* instr_i1, const int32_t* instr_i2,
+                    const int32_t* instr_io, const double* instr_path_weight,
+                    int32_t layout_in1, int32_t layout_out, nqa_plan** plan);
+void nqa_plan_destroy(nqa_plan* plan);
+int64_t nqa_plan_query(const nqa_plan* plan, int32_t field);
+/* The kernels read the plan's path tables from device memory.  The library does not allocate device
+ * memory: the caller obtains the (position independent) table image, copies it into a device buffer it
+ * owns (the host side keeps it as a non-persistent module buffer so it follows `.to(device)`) and
+ * passes that buffer as `plan_image` to the nqa_tp_* calls. */
+int64_t nqa_plan_image_bytes(const nqa_plan* plan);
+int nqa_plan_image_write(const nqa_plan* plan, void* host_dst, int64_t host_dst_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge topology (CSR): replaces the implicit index handling of
+ *   x[edge_src] (row gather, nequip/nn/_tp_scatter_base.py:36) and
+ *   scatter(edge_features, edge_dst, dim=0, dim_size=N) (nequip/nn/utils.py:24-53),
+ * for arbitrary (unsorted, repeated) int64 indices as in
+ *   tests/unit/nn/test_tp_scatter_kernel.py:144-149.  Groups the E edges by `key` with a stable
+ * radix sort:  rowptr[n]..rowptr[n+1] indexes the edges whose key == n (ascending original edge
+ * id), edge_id[] holds their original ids and other_sorted[] the matching `other` index.
+ * Call once with (key=edge_dst, other=edge_src) for forward / edge gradients and once with
+ * (key=edge_src, other=edge_dst) for the feature gradient (the transposed graph, cf.
+ * nequip/data/transforms/neighborlist.py:150-155 `edge_transpose_perm`).
+ * Returns NQA_ERR_INVALID (reported asynchronously as out-of-range being clamped is NOT done):
+ * indices must satisfy 0 <= idx < num_nodes; this is checked on the device and reported through
+ * `status_flag` (int32 device word, set non-zero on violation) when it is non-NULL.
+ * ------------------------------------------------------------------------------------------- */
+int64_t nqa_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int nqa_csr_build(const int64_t* key, const int64_t* other, int64_t num_nodes, int64_t num_edges,
+                  int32_t* rowptr, int32_t* edge_id, int32_t* other_sorted, int32_t* status_flag,
+                  void* workspace, int64_t workspace_bytes, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused gather -> Clebsch-Gordan tensor product ('uvu', per-edge weights) -> scatter-add.
+ * Replaces TensorProductScatter.forward(x, edge_attr, edge_weight, edge_dst, edge_src)
+ *   (nequip/nn/_tp_scatter_base.py:35-38):
+ *   out[n, slot_p, u, k] = sum_{e: dst(e)=n} c_p * w[e, p, u] * sum_ij C^p_ijk x[src(e), u, i] y[e, j]
+ * x [N, dim_in1], y [E, dim_in2], w [E, weight_numel], out [N, dim_out]; (rowptr, edge_id,
+ * src_sorted) from nqa_csr_build(key=dst, other=src).  Rows of `out` without incoming edges are
+ * written as zeros.  If NQA_PLAN_OUT_NEEDS_ZERO the caller must pre-zero `out`.
+ * ------------------------------------------------------------------------------------------- */
+int nqa_tp_scatter_fwd(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y, const void* w,
+                       const int32_t* rowptr_dst, const int32_t* edge_id_dst, const int32_t* src_sorted,
+                       void* out, int64_t num_nodes, int64_t num_edges, nqa_stream stream);
+
+/* Backward of the op above w.r.t. the per-edge operands (replaces the autograd of the e3nn einsum
+ * chain exercised by tests/unit/nn/test_tp_scatter_kernel.py:160-177):
+ *   gw[e,p,u] = c_p sum_ijk C^p_ijk x[src(e),u,i] y[e,j] g[dst(e),slot_p,u,k]
+ *   gy[e,j]   = sum_p sum_u c_p w[e,p,u] sum_ik C^p_ijk x[src(e),u,i] g[dst(e),slot_p,u,k]
+ * gw and/or gy may be NULL (gradient not needed).  `workspace` (>= nqa_tp_bwd_edge_workspace_bytes)
+ * holds deterministic per-path partial sums of gy; required iff gy != NULL. */
+int64_t nqa_tp_bwd_edge_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges);
+int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y, const void* w,
+                            const void* grad_out, const int32_t* rowptr_dst, const int32_t* edge_id_dst,
+                            const int32_t* src_sorted, void* grad_w, void* grad_y, void* workspace,
+                            int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, nqa_stream stream);
+
+/* Backward w.r.t. the node features (a scatter over *src*: the transposed graph):
+ *   gx[m, u, i] = sum_{e: src(e)=m} sum_p c_p w[e,p,u] sum_jk C^p_ijk y[e,j] g[dst(e),slot_p,u,k]
+ * (rowptr, edge_id, dst_sorted) from nqa_csr_build(key=src, other=dst). */
+int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w, const void* grad_out,
+                         const int32_t* rowptr_src, const int32_t* edge_id_src, const int32_t* dst_sorted,
+                         void* grad_x, int64_t num_nodes, int64_t num_edges, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge embedding: real spherical harmonics + Bessel radial basis with polynomial cutoff.
+ * Replaces, for precomputed float64 edge vectors (nequip/nn/utils.py:68-118),
+ *   SphericalHarmonicEdgeAttrs.forward  (nequip/nn/embedding/_edge.py:193-198; e3nn
+ *       SphericalHarmonics(irreps 0..lmax, normalize=True, normalization="component")),
+ *   EdgeLengthNormalizer.forward        (nequip/nn/embedding/_edge.py:65-80),
+ *   BesselEdgeLengthEncoding.forward    (nequip/nn/embedding/_edge.py:136-150),
+ *   PolynomialCutoff.forward            (nequip/nn/embedding/cutoffs.py:17-27),
+ *   ApplyFactor (2*pi/r_max^2)          (nequip/model/nequip_models.py:318-322).
+ * All arithmetic is float64; results are rounded to `dtype` exactly where the reference casts
+ * (.to(model_dtype)), then bessel*cutoff*factor is formed in `dtype`.
+ *   sh  [E, (lmax+1)^2]   emb [E, num_bessels]   cutoff [E]   (any output may be NULL)
+ * rmax_recip_edge (optional, [E] float64) overrides the scalar 1/r_max per edge (per-edge-type
+ * cutoffs).  bessel_weights: [num_bessels] float64 DEVICE pointer (the reference's buffer /
+ * trainable parameter, _edge.py:112-121).
+ * ------------------------------------------------------------------------------------------- */
+int nqa_edge_embed_fwd(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges,
+                       double rmax_recip, const double* rmax_recip_edge, int32_t num_bessels,
+                       const double* bessel_weights, double cutoff_p, double factor, void* sh, void* emb,
+                       void* cutoff, nqa_stream stream);
+/* Vector-Jacobian product of the above: g_edge_vec[E,3] (float64) from g_sh / g_emb (either may be
+ * NULL).  This is the edge -> position leg of the force backward (nequip/nn/grad_output.py:217-221). */
+int nqa_edge_embed_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges,
+                       double rmax_recip, const double* rmax_recip_edge, int32_t num_bessels,
+                       const double* bessel_weights, double cutoff_p, double factor, const void* g_sh,
+                       const void* g_emb, double* g_edge_vec, nqa_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEQUIP_AMD_H */

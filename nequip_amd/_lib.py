@@ -1,0 +1,127 @@
+"""ctypes binding of ``libnequip_amd.so`` -- the C ABI declared in ``include/nequip_amd.h``.
+
+There is deliberately no fallback: if the HIP library has not been built (``python -m
+nequip_amd.csrc.build`` / ``__graft_entry__.build()``) every kernel-backed op raises.  Nothing in this
+package computes the hot path on the CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnequip_amd.so")
+
+NQA_OK = 0
+NQA_F32 = 0
+NQA_F64 = 1
+NQA_LAYOUT_MUL_IR = 0
+NQA_LAYOUT_IR_MUL = 1
+
+NQA_PLAN_DIM_IN1 = 0
+NQA_PLAN_DIM_IN2 = 1
+NQA_PLAN_DIM_OUT = 2
+NQA_PLAN_WEIGHT_NUMEL = 3
+NQA_PLAN_NUM_INSTR = 4
+NQA_PLAN_OUT_NEEDS_ZERO = 5
+NQA_PLAN_YPART_WIDTH = 6
+
+_P32 = POINTER(c_int32)
+
+# name -> (restype, argtypes); must list every symbol include/nequip_amd.h declares
+SIGNATURES = {
+    "nqa_abi_version": (c_int32, []),
+    "nqa_last_error": (c_char_p, []),
+    "nqa_lmax": (c_int32, []),
+    "nqa_sh_lmax": (c_int32, []),
+    "nqa_plan_create": (
+        c_int32,
+        [c_int32, _P32, _P32, _P32, c_int32, _P32, _P32, _P32, c_int32, _P32, _P32, _P32]
+        + [c_int32, _P32, _P32, _P32, POINTER(c_double), c_int32, c_int32, POINTER(c_void_p)],
+    ),
+    "nqa_plan_destroy": (None, [c_void_p]),
+    "nqa_plan_query": (c_int64, [c_void_p, c_int32]),
+    "nqa_plan_image_bytes": (c_int64, [c_void_p]),
+    "nqa_plan_image_write": (c_int32, [c_void_p, c_void_p, c_int64]),
+    "nqa_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "nqa_csr_build": (
+        c_int32,
+        [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "nqa_tp_scatter_fwd": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_int64, c_int64, c_void_p],
+    ),
+    "nqa_tp_bwd_edge_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int64]),
+    "nqa_tp_scatter_bwd_edge": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p],
+    ),
+    "nqa_tp_scatter_bwd_x": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_int64, c_int64, c_void_p],
+    ),
+    "nqa_edge_embed_fwd": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]
+        + [c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "nqa_edge_embed_bwd": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]
+        + [c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NequipAmdLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NequipAmdLibraryError(
+                f"{LIB_PATH} not found: the HIP kernels have not been built. Run "
+                "`python -m nequip_amd.csrc.build` (or `__graft_entry__.build()`); there is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:  # pragma: no cover
+                raise NequipAmdLibraryError(f"{LIB_PATH} does not export `{name}`") from exc
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.nqa_abi_version() != 1:
+            raise NequipAmdLibraryError("libnequip_amd.so ABI version mismatch; rebuild the library")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != NQA_OK:
+        msg = load().nqa_last_error()
+        raise RuntimeError(f"libnequip_amd {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def int32_array(values):
+    arr = (c_int32 * max(len(values), 1))()
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+    return arr

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Build ``libnequip_amd.so`` (the C-ABI of ``include/nequip_amd.h``) for gfx950 with hipcc.
+
+Cross-compiles without a GPU.  The shared object is written next to this file (in-tree, git-ignored)
+so it travels to the GPU box with the repository snapshot.
+
+    python -m nequip_amd.csrc.build [--force] [--jobs N]
+"""
+
+from __future__ import annotations
+
+import argparse
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+LIB_NAME = "libnequip_amd.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+OBJ_DIR = os.path.join(HERE, "build")
+GEN_DIR = os.path.join(HERE, "generated")
+
+SOURCES = ["plan.cpp", "csr.hip", "tp_generic.hip", "edge_embed.hip", "radial_mlp.hip", "tp_fused.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libnequip_amd.so (set HIPCC or install ROCm)")
+
+
+def _flags() -> list:
+    return [
+        f"--offload-arch={ARCH}",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        "-x",
+        "hip",
+        "-Wall",
+        "-Wno-unused-function",
+        "-Wno-unused-variable",
+        "-Wno-unused-but-set-variable",
+        f"-I{os.path.join(REPO, 'include')}",
+        f"-I{HERE}",
+    ]
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(p.encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(_flags()).encode())
+    return h.hexdigest()
+
+
+def _headers() -> list:
+    hs = [os.path.join(REPO, "include", "nequip_amd.h")]
+    for d in (HERE, GEN_DIR):
+        if os.path.isdir(d):
+            hs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
+    return hs
+
+
+def generate_tables(force: bool = False) -> None:
+    gen_script = os.path.join(HERE, "gen_tables.py")
+    wigner = os.path.join(REPO, "nequip_amd", "o3", "wigner.py")
+    outs = [os.path.join(GEN_DIR, "cg_generated.h"), os.path.join(GEN_DIR, "sh_generated.h")]
+    stamp = os.path.join(GEN_DIR, ".stamp")
+    want = _digest([gen_script, wigner])
+    if not force and all(os.path.exists(o) for o in outs) and os.path.exists(stamp):
+        if open(stamp).read().strip() == want:
+            return
+    subprocess.run([sys.executable, gen_script], check=True, cwd=REPO)
+    with open(stamp, "w") as f:
+        f.write(want)
+
+
+def _compile_one(src: str, force: bool) -> str:
+    src_path = os.path.join(HERE, src)
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    stamp = obj + ".stamp"
+    want = _digest([src_path] + _headers())
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return obj
+    cmd = [_hipcc()] + _flags() + ["-c", src_path, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    if res.stderr.strip():
+        sys.stderr.write(res.stderr)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    generate_tables(force)
+    sources = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    jobs = jobs or min(len(sources), os.cpu_count() or 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile_one(s, force), sources))
+    link_stamp = LIB_PATH + ".stamp"
+    want = _digest(objs)
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(link_stamp) or open(link_stamp).read().strip() != want:
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        with open(link_stamp, "w") as f:
+            f.write(want)
+    if verbose:
+        print(f"[nequip_amd] built {LIB_PATH} ({os.path.getsize(LIB_PATH) / 1e6:.1f} MB) from {len(objs)} objects")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=0)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.jobs)

@@ -1,0 +1,115 @@
+"""Edge topology (CSR by destination and by source) shared by all layers of one model evaluation.
+
+The reference passes raw ``edge_index`` rows to every ``TensorProductScatter.forward``
+(``nequip/nn/interaction_block.py:193-199``) and lets ATen gather/scatter with them
+(``nequip/nn/_tp_scatter_base.py:36-37``, ``nequip/nn/utils.py:42-51``).  The fused kernels instead
+walk per-node edge lists, so the (unsorted, possibly repeated) int64 indices are grouped once on the
+device by ``nqa_csr_build`` and reused by the three convolution layers and their backward passes.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import weakref
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
+
+
+def current_stream_ptr(device: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class EdgeTopology:
+    """CSR views of one edge list.  ``by_dst`` drives forward / edge gradients, ``by_src`` the feature gradient."""
+
+    check_indices: bool = False  # set True to validate 0 <= index < num_nodes (costs a device sync)
+
+    def __init__(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int):
+        if not edge_dst.is_cuda:
+            raise RuntimeError(
+                "nequip_amd kernels run on the GPU only (got CPU index tensors); there is no CPU fallback"
+            )
+        assert edge_dst.dtype == torch.int64 and edge_src.dtype == torch.int64, "edge indices must be int64"
+        assert edge_dst.dim() == 1 and edge_dst.shape == edge_src.shape
+        self.device = edge_dst.device
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(edge_dst.numel())
+        self._dst = edge_dst.contiguous()
+        self._src = edge_src.contiguous()
+        self._by_dst: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        self._by_src: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+
+    def _build(self, key: torch.Tensor, other: torch.Tensor):
+        lib = _lib.load()
+        N, E = self.num_nodes, self.num_edges
+        dev = self.device
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        oth = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        ws_bytes = lib.nqa_csr_workspace_bytes(N, E)
+        if ws_bytes < 0:
+            raise RuntimeError("edge list exceeds the int32 index range supported by the kernels")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev) if self.check_indices else None
+        with torch.cuda.device(dev):
+            rc = lib.nqa_csr_build(
+                _ptr(key), _ptr(other), N, E, _ptr(rowptr), _ptr(eid), _ptr(oth), _ptr(status), _ptr(ws),
+                ws_bytes, current_stream_ptr(dev),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_csr_build")
+        if status is not None and int(status.item()) != 0:
+            raise RuntimeError("edge index out of range [0, num_nodes)")
+        return rowptr, eid, oth
+
+    @property
+    def by_dst(self):
+        if self._by_dst is None:
+            self._by_dst = self._build(self._dst, self._src)
+        return self._by_dst
+
+    @property
+    def by_src(self):
+        if self._by_src is None:
+            self._by_src = self._build(self._src, self._dst)
+        return self._by_src
+
+
+class _TopologyCache:
+    """Reuse the CSR across the layers of one forward: keyed on the identity/version of the index storage."""
+
+    def __init__(self):
+        self._key = None
+        self._ref = None
+        self._topo: Optional[EdgeTopology] = None
+
+    @staticmethod
+    def _base(t: torch.Tensor) -> torch.Tensor:
+        return t._base if t._base is not None else t
+
+    def get(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int) -> EdgeTopology:
+        bd, bs = self._base(edge_dst), self._base(edge_src)
+        key = (
+            id(bd), id(bs), bd._version, bs._version, edge_dst.data_ptr(), edge_src.data_ptr(),
+            edge_dst.numel(), edge_dst.stride(0), edge_src.stride(0), int(num_nodes), str(edge_dst.device),
+        )  # fmt: skip
+        alive = self._ref is not None and self._ref[0]() is bd and self._ref[1]() is bs
+        if self._topo is not None and alive and key == self._key:
+            return self._topo
+        topo = EdgeTopology(edge_dst, edge_src, num_nodes)
+        self._key = key
+        self._ref = (weakref.ref(bd), weakref.ref(bs))
+        self._topo = topo
+        return topo
+
+    def clear(self):
+        self._key = self._ref = self._topo = None
+
+
+topology_cache = _TopologyCache()

@@ -1,0 +1,235 @@
+"""``TensorProductScatter`` on MI355X: fused gather -> Clebsch-Gordan 'uvu' product -> scatter-add.
+
+Mirrors ``nequip.nn._tp_scatter_base.TensorProductScatter`` (``nequip/nn/_tp_scatter_base.py:9-38``):
+same constructor arguments ``(feature_irreps_in, irreps_edge_attr, irreps_mid, instructions)``, same
+``forward(x, edge_attr, edge_weight, edge_dst, edge_src)`` signature and semantics, the ``tp`` /
+``model_dtype`` attributes and the ``_nequip_custom_ops_libs`` marker of the reference's accelerated
+adapters (``nequip/nn/_tp_scatter_oeq.py:4-57``).  The arithmetic runs in the hand-written HIP kernels
+of ``libnequip_amd.so`` (``include/nequip_amd.h``); there is no eager / CPU implementation in this
+package -- a CPU tensor or a missing library raises.
+
+Differentiability (``tests/unit/nn/test_tp_scatter_kernel.py:160-177`` for first order,
+``nequip/nn/grad_output.py:217-221`` ``create_graph=self.training`` for second order): the op is
+trilinear in ``(x, edge_attr, edge_weight)``, so its derivative kernels ``bwd_x`` / ``bwd_edge`` are
+the same contraction with one operand replaced by a cotangent and the family
+{fwd, bwd_x, bwd_edge} is closed under differentiation; double backward is expressed with the same
+three kernels.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib
+from ..o3.irreps import Irreps
+from ..o3.tensor_product import NativePlan, TensorProduct
+from ._topology import EdgeTopology, _ptr, current_stream_ptr, topology_cache
+
+
+def _nqa_dtype(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return _lib.NQA_F32
+    if dtype == torch.float64:
+        return _lib.NQA_F64
+    raise RuntimeError(f"nequip_amd kernels support float32/float64 model dtypes, got {dtype}")
+
+
+class _Kernels:
+    """Thin launcher around the three native entry points for one plan."""
+
+    def __init__(self, plan: NativePlan, image: torch.Tensor):
+        self.plan = plan
+        self.image = image  # device uint8 tensor
+        self.dim_in1 = plan.query(_lib.NQA_PLAN_DIM_IN1)
+        self.dim_in2 = plan.query(_lib.NQA_PLAN_DIM_IN2)
+        self.dim_out = plan.query(_lib.NQA_PLAN_DIM_OUT)
+        self.weight_numel = plan.query(_lib.NQA_PLAN_WEIGHT_NUMEL)
+        self.out_needs_zero = bool(plan.query(_lib.NQA_PLAN_OUT_NEEDS_ZERO))
+
+    def _check(self, x, y, w, topo: EdgeTopology):
+        N, E = topo.num_nodes, topo.num_edges
+        if x is not None:
+            assert x.shape == (N, self.dim_in1), f"x has shape {tuple(x.shape)}, expected {(N, self.dim_in1)}"
+        if y is not None:
+            assert y.shape == (E, self.dim_in2), f"edge_attr has shape {tuple(y.shape)}, expected {(E, self.dim_in2)}"
+        if w is not None:
+            assert w.shape == (E, self.weight_numel), (
+                f"edge_weight has shape {tuple(w.shape)}, expected {(E, self.weight_numel)}"
+            )
+
+    def fwd(self, x, y, w, topo: EdgeTopology) -> torch.Tensor:
+        self._check(x, y, w, topo)
+        lib = _lib.load()
+        alloc = torch.zeros if self.out_needs_zero else torch.empty
+        out = alloc((topo.num_nodes, self.dim_out), dtype=x.dtype, device=x.device)
+        rowptr, eid, nbr = topo.by_dst
+        with torch.cuda.device(x.device):
+            rc = lib.nqa_tp_scatter_fwd(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w),
+                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(out), topo.num_nodes, topo.num_edges,
+                current_stream_ptr(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_fwd")
+        return out
+
+    def bwd_edge(self, x, y, w, g, topo: EdgeTopology, need_gw: bool, need_gy: bool):
+        self._check(x, y, w, topo)
+        lib = _lib.load()
+        E = topo.num_edges
+        gw = torch.empty((E, self.weight_numel), dtype=x.dtype, device=x.device) if need_gw else None
+        gy = torch.empty((E, self.dim_in2), dtype=x.dtype, device=x.device) if need_gy else None
+        if not (need_gw or need_gy):
+            return None, None
+        ws, ws_bytes = None, 0
+        if need_gy:
+            ws_bytes = lib.nqa_tp_bwd_edge_workspace_bytes(self.plan.handle, _nqa_dtype(x.dtype), E)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        rowptr, eid, nbr = topo.by_dst
+        with torch.cuda.device(x.device):
+            rc = lib.nqa_tp_scatter_bwd_edge(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gw), _ptr(gy), _ptr(ws), ws_bytes,
+                topo.num_nodes, E, current_stream_ptr(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_bwd_edge")
+        return gw, gy
+
+    def bwd_x(self, y, w, g, topo: EdgeTopology) -> torch.Tensor:
+        self._check(None, y, w, topo)
+        lib = _lib.load()
+        gx = torch.empty((topo.num_nodes, self.dim_in1), dtype=g.dtype, device=g.device)
+        rowptr, eid, nbr = topo.by_src
+        with torch.cuda.device(g.device):
+            rc = lib.nqa_tp_scatter_bwd_x(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(g),
+                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gx), topo.num_nodes, topo.num_edges,
+                current_stream_ptr(g.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_bwd_x")
+        return gx
+
+
+class _TPScatterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, w, k: _Kernels, topo: EdgeTopology):
+        x, y, w = x.contiguous(), y.contiguous(), w.contiguous()
+        out = k.fwd(x, y, w, topo)
+        ctx.save_for_backward(x, y, w)
+        ctx.k, ctx.topo = k, topo
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w = ctx.saved_tensors
+        need = tuple(ctx.needs_input_grad[:3])
+        gx, gy, gw = _TPScatterBwdFn.apply(g, x, y, w, ctx.k, ctx.topo, need)
+        return gx, gy, gw, None, None
+
+
+class _TPScatterBwdFn(torch.autograd.Function):
+    """(g, x, y, w) -> (gx, gy, gw); itself differentiable once more (force-matching training)."""
+
+    @staticmethod
+    def forward(ctx, g, x, y, w, k: _Kernels, topo: EdgeTopology, need: Tuple[bool, bool, bool]):
+        g = g.contiguous()
+        gx = k.bwd_x(y, w, g, topo) if need[0] else None
+        gw, gy = k.bwd_edge(x, y, w, g, topo, need_gw=need[2], need_gy=need[1])
+        ctx.save_for_backward(g, x, y, w)
+        ctx.k, ctx.topo = k, topo
+        ctx.mark_non_differentiable(*[t for t, n in zip((gx, gy, gw), need) if not n and t is not None])
+        return gx, gy, gw
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, c_x, c_y, c_w):
+        g, x, y, w = ctx.saved_tensors
+        k, topo = ctx.k, ctx.topo
+        need_g, need_x, need_y, need_w = ctx.needs_input_grad[:4]
+        c_x = c_x.contiguous() if c_x is not None else None
+        c_y = c_y.contiguous() if c_y is not None else None
+        c_w = c_w.contiguous() if c_w is not None else None
+
+        def add(a, b):
+            return b if a is None else (a if b is None else a + b)
+
+        gg = gxx = gyy = gww = None
+        if need_g:
+            if c_x is not None:
+                gg = add(gg, k.fwd(c_x, y, w, topo))
+            if c_y is not None:
+                gg = add(gg, k.fwd(x, c_y, w, topo))
+            if c_w is not None:
+                gg = add(gg, k.fwd(x, y, c_w, topo))
+        if need_x:
+            if c_y is not None:
+                gxx = add(gxx, k.bwd_x(c_y, w, g, topo))
+            if c_w is not None:
+                gxx = add(gxx, k.bwd_x(y, c_w, g, topo))
+        if c_x is not None and (need_y or need_w):
+            # one pass yields both Bw(c_x, y, g) and By(c_x, g, w)
+            a_w, a_y = k.bwd_edge(c_x, y, w, g, topo, need_gw=need_w, need_gy=need_y)
+            gww, gyy = add(gww, a_w), add(gyy, a_y)
+        if c_y is not None and need_w:
+            a_w, _ = k.bwd_edge(x, c_y, w, g, topo, need_gw=True, need_gy=False)
+            gww = add(gww, a_w)
+        if c_w is not None and need_y:
+            _, a_y = k.bwd_edge(x, y, c_w, g, topo, need_gw=False, need_gy=True)
+            gyy = add(gyy, a_y)
+        return gg, gxx, gyy, gww, None, None, None
+
+
+class TensorProductScatter(torch.nn.Module):
+    """Drop-in for ``nequip.nn._tp_scatter_base.TensorProductScatter`` backed by gfx950 HIP kernels."""
+
+    _nequip_custom_ops_libs = ("nequip_amd",)
+
+    def __init__(self, feature_irreps_in, irreps_edge_attr, irreps_mid, instructions) -> None:
+        super().__init__()
+        # keep the caller's objects (e3nn Irreps when used under nequip) for introspection, and our own
+        # e3nn-free copies for the plan
+        self.feature_irreps_in = feature_irreps_in
+        self.irreps_edge_attr = irreps_edge_attr
+        self.irreps_mid = irreps_mid
+        self.instructions = instructions
+
+        irreps_in1 = Irreps(str(feature_irreps_in))
+        irreps_in2 = Irreps(str(irreps_edge_attr))
+        irreps_out = Irreps(str(irreps_mid))
+        # parameter-free descriptor under the same attribute name as the reference (`self.tp`)
+        self.tp = TensorProduct(
+            irreps_in1, irreps_in2, irreps_out, instructions, shared_weights=False, internal_weights=False
+        )
+        self.model_dtype = torch.get_default_dtype()
+
+        self._plan = NativePlan(irreps_in1, irreps_in2, irreps_out, self.tp.instructions)
+        # device image of the path tables: a non-persistent buffer so it follows .to(device) and never
+        # enters the state dict (the reference module owns no persistent state of its own)
+        self.register_buffer("_plan_image", self._plan.image, persistent=False)
+        self._kernels: Optional[_Kernels] = None
+
+    def _get_kernels(self) -> _Kernels:
+        k = self._kernels
+        if k is None or k.image.data_ptr() != self._plan_image.data_ptr():
+            k = _Kernels(self._plan, self._plan_image)
+            self._kernels = k
+        return k
+
+    def forward(self, x, edge_attr, edge_weight, edge_dst, edge_src, topology: Optional[EdgeTopology] = None):
+        if not x.is_cuda:
+            raise RuntimeError(
+                "nequip_amd.nn.TensorProductScatter runs on the GPU only (HIP kernels); no CPU fallback exists"
+            )
+        if self._plan_image.device != x.device:
+            raise RuntimeError("module and inputs are on different devices; call .to(device) on the model")
+        # explicit cast to account for AMP (as nequip/nn/_tp_scatter_oeq.py:49-57)
+        x = x.to(self.model_dtype)
+        edge_attr = edge_attr.to(self.model_dtype)
+        edge_weight = edge_weight.to(self.model_dtype)
+        if topology is None:
+            topology = topology_cache.get(edge_dst, edge_src, x.size(0))
+        return _TPScatterFn.apply(x, edge_attr, edge_weight, self._get_kernels(), topology)
+
+    def extra_repr(self) -> str:
+        return f"{self.tp.extra_repr()} | dtype={self.model_dtype}"

@@ -1,0 +1,164 @@
+"""Edge embedding modules backed by the fused HIP kernel ``nqa_edge_embed_fwd/bwd``.
+
+Mirrors ``nequip/nn/embedding/_edge.py``: ``EdgeLengthNormalizer`` (:19-80), ``BesselEdgeLengthEncoding``
+(:84-150) and ``SphericalHarmonicEdgeAttrs`` (:154-198) with the same constructor arguments, fields and
+float64-in / model-dtype-out behaviour.  The real spherical harmonics (e3nn ``SphericalHarmonics(...,
+normalize=True, normalization="component")``), the Bessel basis ``sinc(n x) n``, the polynomial cutoff and
+the ``2 pi / r_max^2`` factor (``nequip/model/nequip_models.py:318-322``) are evaluated on the GPU in one
+pass over the edges; their vector-Jacobian product feeds the force backward.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from ... import _lib
+from ...data import AtomicDataDict
+from ...o3.irreps import Irreps
+from .._graph_mixin import GraphModuleMixin
+from .._topology import _ptr, current_stream_ptr
+from ..utils import with_edge_vectors_
+
+_GLOBAL_DTYPE = torch.float64  # nequip/utils/global_dtype.py:5
+
+
+def _dt(dtype):
+    return _lib.NQA_F32 if dtype == torch.float32 else _lib.NQA_F64
+
+
+class _EdgeEmbedFn(torch.autograd.Function):
+    """edge_vec [E,3] f64 -> (sh [E,S] | None, emb [E,nb] | None) in model dtype."""
+
+    @staticmethod
+    def forward(ctx, edge_vec, bessel_weights, cfg):
+        if not edge_vec.is_cuda:
+            raise RuntimeError("nequip_amd edge embedding runs on the GPU only (HIP kernel); no CPU fallback exists")
+        assert edge_vec.dtype == torch.float64, "edge vectors must be float64 (nequip _GLOBAL_DTYPE)"
+        lib = _lib.load()
+        vec = edge_vec.contiguous()
+        E = vec.shape[0]
+        out_dtype = cfg["dtype"]
+        lmax = cfg["lmax"]
+        sh = torch.empty((E, (lmax + 1) ** 2), dtype=out_dtype, device=vec.device) if cfg["want_sh"] else None
+        emb = torch.empty((E, cfg["nb"]), dtype=out_dtype, device=vec.device) if cfg["want_emb"] else None
+        with torch.cuda.device(vec.device):
+            rc = lib.nqa_edge_embed_fwd(
+                _dt(out_dtype), max(lmax, 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(), cfg["nb"],
+                _ptr(bessel_weights), cfg["p"], cfg["factor"], _ptr(sh), _ptr(emb), ctypes.c_void_p(),
+                current_stream_ptr(vec.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_edge_embed_fwd")
+        ctx.save_for_backward(vec, bessel_weights)
+        ctx.cfg = cfg
+        outs = tuple(t for t in (sh, emb) if t is not None)
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        vec, bw = ctx.saved_tensors
+        cfg = ctx.cfg
+        lib = _lib.load()
+        grads = list(grads)
+        g_sh = grads.pop(0) if cfg["want_sh"] else None
+        g_emb = grads.pop(0) if cfg["want_emb"] else None
+        g_sh = g_sh.contiguous() if g_sh is not None else None
+        g_emb = g_emb.contiguous() if g_emb is not None else None
+        E = vec.shape[0]
+        g_vec = torch.empty((E, 3), dtype=torch.float64, device=vec.device)
+        with torch.cuda.device(vec.device):
+            rc = lib.nqa_edge_embed_bwd(
+                _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
+                cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(g_vec),
+                current_stream_ptr(vec.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_edge_embed_bwd")
+        return g_vec, None, None
+
+
+class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):
+    """Holds ``1/r_max``; the product ``r * (1/r_max)`` itself is formed inside the fused radial kernel
+    (``nequip/nn/embedding/_edge.py:65-80``).  Per-edge-type cutoffs are not wired yet."""
+
+    def __init__(self, r_max: float, type_names: List[str], per_edge_type_cutoff: Optional[Dict] = None,
+                 norm_length_field: str = AtomicDataDict.NORM_LENGTH_KEY, irreps_in=None):
+        super().__init__()
+        if per_edge_type_cutoff is not None:
+            raise NotImplementedError("per_edge_type_cutoff is outside the benchmarked path (SURVEY.md 8)")
+        self.r_max = float(r_max)
+        self.num_types = len(type_names)
+        self.norm_length_field = norm_length_field
+        self.register_buffer("_rmax_recip", torch.as_tensor(1.0 / self.r_max, dtype=_GLOBAL_DTYPE))
+        self._init_irreps(irreps_in=irreps_in, irreps_out={self.norm_length_field: Irreps("1x0e")})
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        data = with_edge_vectors_(data, with_lengths=False)
+        data["_nqa_rmax_recip"] = 1.0 / self.r_max
+        return data
+
+
+class BesselEdgeLengthEncoding(GraphModuleMixin, torch.nn.Module):
+    """``edge_embedding = sinc(n r/r_max) n * cutoff(r/r_max)`` (``nequip/nn/embedding/_edge.py:136-150``),
+    optionally pre-multiplied by a constant ``factor`` (the reference applies ``2 pi / r_max^2`` in a separate
+    ``ApplyFactor`` module, ``nequip_models.py:318-322``; here that module sets ``self.factor`` and becomes a no-op)."""
+
+    def __init__(self, cutoff: torch.nn.Module, num_bessels: int = 8, trainable: bool = False,
+                 edge_invariant_field: str = AtomicDataDict.EDGE_EMBEDDING_KEY,
+                 norm_length_field: str = AtomicDataDict.NORM_LENGTH_KEY, irreps_in=None):
+        super().__init__()
+        self.cutoff = cutoff
+        self.num_bessels = num_bessels
+        self.trainable = trainable
+        if trainable:
+            raise NotImplementedError("trainable Bessel roots are outside the benchmarked path")
+        self.edge_invariant_field = edge_invariant_field
+        self.norm_length_field = norm_length_field
+        bessel_weights = torch.linspace(1.0, num_bessels, num_bessels, dtype=_GLOBAL_DTYPE).unsqueeze(0)
+        self.register_buffer("bessel_weights", bessel_weights)
+        self.factor = 1.0
+        self._init_irreps(
+            irreps_in=irreps_in,
+            irreps_out={self.edge_invariant_field: Irreps([(num_bessels, (0, 1))])},
+        )
+        self._output_dtype = torch.get_default_dtype()
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        data = with_edge_vectors_(data, with_lengths=False)
+        cfg = dict(dtype=self._output_dtype, lmax=0, want_sh=False, want_emb=True, nb=self.num_bessels,
+                   rmax_recip=float(data["_nqa_rmax_recip"]), p=float(self.cutoff.p), factor=float(self.factor))
+        data[self.edge_invariant_field] = _EdgeEmbedFn.apply(
+            data[AtomicDataDict.EDGE_VECTORS_KEY], self.bessel_weights.view(-1), cfg
+        )
+        return data
+
+
+class SphericalHarmonicEdgeAttrs(GraphModuleMixin, torch.nn.Module):
+    """``edge_attrs = Y(edge_vectors)`` for ``l = 0..lmax`` (``nequip/nn/embedding/_edge.py:154-198``)."""
+
+    def __init__(self, irreps_edge_sh: Union[int, str, Irreps], edge_sh_normalization: str = "component",
+                 edge_sh_normalize: bool = True, irreps_in=None, out_field: str = AtomicDataDict.EDGE_ATTRS_KEY):
+        super().__init__()
+        self.out_field = out_field
+        if isinstance(irreps_edge_sh, int):
+            self.irreps_edge_sh = Irreps.spherical_harmonics(irreps_edge_sh)
+        else:
+            self.irreps_edge_sh = Irreps(str(irreps_edge_sh))
+        lmax = self.irreps_edge_sh.lmax
+        if self.irreps_edge_sh != Irreps.spherical_harmonics(lmax):
+            raise NotImplementedError("edge spherical harmonics must be the full range 0..lmax with parity (-1)^l")
+        if edge_sh_normalization != "component" or not edge_sh_normalize:
+            raise NotImplementedError("only the nequip defaults (normalize=True, 'component') are implemented")
+        self.lmax = lmax
+        self._init_irreps(irreps_in=irreps_in, irreps_out={out_field: self.irreps_edge_sh})
+        self._output_dtype = torch.get_default_dtype()
+        self.register_buffer("_dummy_bw", torch.ones(1, dtype=_GLOBAL_DTYPE), persistent=False)
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        data = with_edge_vectors_(data, with_lengths=False)
+        cfg = dict(dtype=self._output_dtype, lmax=self.lmax, want_sh=True, want_emb=False, nb=0, rmax_recip=1.0,
+                   p=6.0, factor=1.0)
+        data[self.out_field] = _EdgeEmbedFn.apply(data[AtomicDataDict.EDGE_VECTORS_KEY], self._dummy_bw, cfg)
+        return data

@@ -1,0 +1,31 @@
+"""Node type embedding (mirror of ``nequip/nn/embedding/node.py:39-175`` without categorical graph fields)."""
+
+from typing import List, Optional
+
+import torch
+
+from ...data import AtomicDataDict
+from ...o3.irreps import Irreps
+from .._graph_mixin import GraphModuleMixin
+
+
+class NodeTypeEmbed(GraphModuleMixin, torch.nn.Module):
+    def __init__(self, type_names: List[str], num_features: int, set_features: bool = True, irreps_in=None):
+        super().__init__()
+        self.num_types = len(type_names)
+        self.set_features = set_features
+        self.embed_module = torch.nn.Embedding(num_embeddings=self.num_types, embedding_dim=num_features)
+        irreps_out = {AtomicDataDict.NODE_ATTRS_KEY: Irreps([(num_features, (0, 1))])}
+        if set_features:
+            irreps_out[AtomicDataDict.NODE_FEATURES_KEY] = irreps_out[AtomicDataDict.NODE_ATTRS_KEY]
+        self._init_irreps(irreps_in=irreps_in, irreps_out=irreps_out)
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        atom_types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)
+        embedding = self.embed_module(atom_types)
+        data[AtomicDataDict.NODE_ATTRS_KEY] = embedding
+        # node_attrs == table[types]: lets the self-connection contract its weights per type first
+        data["_nqa_node_attrs_table"] = self.embed_module.weight
+        if self.set_features:
+            data[AtomicDataDict.NODE_FEATURES_KEY] = embedding
+        return data

@@ -1,0 +1,38 @@
+"""``GraphModel``: top-level wrapper (mirror of ``nequip/nn/graph_model.py:37-155``): copies the input dict,
+keeps only the model's input fields and exposes the custom-ops metadata of accelerated submodules."""
+
+from typing import List
+
+import torch
+
+from ..data import AtomicDataDict
+from ._graph_mixin import GraphModuleMixin
+
+
+class GraphModel(GraphModuleMixin, torch.nn.Module):
+    is_compile_graph_model: bool = False
+
+    def __init__(self, model: GraphModuleMixin, type_names: List[str] = (), model_dtype=torch.float32) -> None:
+        super().__init__()
+        self.model = model
+        self.type_names = list(type_names)
+        self.model_dtype = model_dtype
+        self.model_input_fields = [
+            AtomicDataDict.POSITIONS_KEY, AtomicDataDict.EDGE_INDEX_KEY, AtomicDataDict.ATOM_TYPE_KEY,
+            AtomicDataDict.CELL_KEY, AtomicDataDict.EDGE_CELL_SHIFT_KEY, AtomicDataDict.BATCH_KEY,
+            AtomicDataDict.NUM_NODES_KEY, AtomicDataDict.EDGE_VECTORS_KEY,
+        ]  # fmt: skip
+        self._init_irreps(irreps_in=self.model.irreps_in, irreps_out=self.model.irreps_out)
+
+    @property
+    def nequip_custom_ops_libs(self):
+        libs = []
+        for m in self.modules():
+            for lib in getattr(m, "_nequip_custom_ops_libs", ()):
+                if lib not in libs:
+                    libs.append(lib)
+        return tuple(libs)
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        new_data: AtomicDataDict.Type = {k: v for k, v in data.items() if k in self.model_input_fields}
+        return self.model(new_data)

@@ -1,0 +1,115 @@
+"""InteractionBlock: one message-passing convolution (mirror of ``nequip/nn/interaction_block.py:21-207``).
+
+``linear_1 -> 1/sqrt(avg_num_neighbors) -> TensorProductScatter(edge_mlp(edge_embedding)) -> linear_2 (+ sc)``
+with the instruction list, sorted ``irreps_mid`` and parameter names of the reference; the tensor product /
+gather / scatter is the fused HIP ``TensorProductScatter``.
+"""
+
+from typing import Dict, Optional, Sequence, Union
+
+import torch
+
+from ..data import AtomicDataDict
+from ..o3.irreps import Irreps
+from ..o3.modules import FullyConnectedTensorProduct, Linear
+from ._graph_mixin import GraphModuleMixin
+from ._tp_scatter_base import TensorProductScatter
+from .mlp import ScalarMLPFunction
+from .norm import AvgNumNeighborsNorm
+
+
+class InteractionBlock(GraphModuleMixin, torch.nn.Module):
+    use_sc: bool
+
+    def __init__(self, irreps_in, irreps_out, radial_mlp_depth: int = 1, radial_mlp_width: int = 8,
+                 use_sc: bool = True, is_first_layer: bool = False, type_names: Optional[Sequence[str]] = None,
+                 avg_num_neighbors: Optional[Union[float, Dict[str, float]]] = None) -> None:
+        super().__init__()
+        self._init_irreps(
+            irreps_in=irreps_in,
+            required_irreps_in=[
+                AtomicDataDict.EDGE_EMBEDDING_KEY,
+                AtomicDataDict.EDGE_ATTRS_KEY,
+                AtomicDataDict.NODE_FEATURES_KEY,
+                AtomicDataDict.NODE_ATTRS_KEY,
+            ],
+            irreps_out={AtomicDataDict.NODE_FEATURES_KEY: irreps_out},
+        )
+        self.avg_num_neighbors_norm = AvgNumNeighborsNorm(avg_num_neighbors=avg_num_neighbors, type_names=type_names)
+        self.use_sc = use_sc
+        feature_irreps_in = self.irreps_in[AtomicDataDict.NODE_FEATURES_KEY]
+        feature_irreps_out = self.irreps_out[AtomicDataDict.NODE_FEATURES_KEY]
+        irreps_edge_attr = self.irreps_in[AtomicDataDict.EDGE_ATTRS_KEY]
+
+        self.linear_1 = Linear(irreps_in=feature_irreps_in, irreps_out=feature_irreps_in)
+
+        # instruction list exactly as nequip/nn/interaction_block.py:89-109
+        irreps_mid = []
+        instructions = []
+        for i, (mul, ir_in) in enumerate(feature_irreps_in):
+            for j, (_, ir_edge) in enumerate(irreps_edge_attr):
+                for ir_out in ir_in * ir_edge:
+                    if ir_out in feature_irreps_out:
+                        k = len(irreps_mid)
+                        irreps_mid.append((mul, ir_out))
+                        instructions.append((i, j, k, "uvu", True))
+        irreps_mid = Irreps(irreps_mid)
+        irreps_mid, p, _ = irreps_mid.sort()
+        instructions = [(i_in1, i_in2, p[i_out], mode, train) for i_in1, i_in2, i_out, mode, train in instructions]
+
+        self.tp_scatter = TensorProductScatter(feature_irreps_in, irreps_edge_attr, irreps_mid, instructions)
+
+        self.edge_mlp = ScalarMLPFunction(
+            input_dim=self.irreps_in[AtomicDataDict.EDGE_EMBEDDING_KEY].num_irreps,
+            output_dim=self.tp_scatter.tp.weight_numel,
+            hidden_layers_depth=radial_mlp_depth,
+            hidden_layers_width=radial_mlp_width,
+            nonlinearity="silu",
+            bias=False,
+            forward_weight_init=True,
+        )
+
+        self.linear_2 = Linear(irreps_in=irreps_mid.simplify(), irreps_out=feature_irreps_out)
+
+        self.sc = None
+        if self.use_sc:
+            self.sc = FullyConnectedTensorProduct(
+                feature_irreps_in, self.irreps_in[AtomicDataDict.NODE_ATTRS_KEY], feature_irreps_out
+            )
+        self.is_first_layer = is_first_layer
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        num_local_nodes = AtomicDataDict.num_nodes(data)
+        x = data[AtomicDataDict.NODE_FEATURES_KEY]
+        if not self.is_first_layer:
+            x = x[:num_local_nodes]
+
+        if self.sc is not None:
+            node_attrs = data[AtomicDataDict.NODE_ATTRS_KEY]
+            if not self.is_first_layer:
+                node_attrs = node_attrs[:num_local_nodes]
+            table = data.get("_nqa_node_attrs_table")
+            if table is not None and table.shape[0] <= 16:
+                sc = self.sc.forward_typed(x, data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: x.shape[0]], table)
+            else:
+                sc = self.sc(x, node_attrs)
+
+        x = self.linear_1(x)
+
+        data[AtomicDataDict.NODE_FEATURES_KEY] = x
+        data = self.avg_num_neighbors_norm(data)
+        x = data[AtomicDataDict.NODE_FEATURES_KEY]
+
+        x = self.tp_scatter(
+            x=x,
+            edge_attr=data[AtomicDataDict.EDGE_ATTRS_KEY],
+            edge_weight=self.edge_mlp(data[AtomicDataDict.EDGE_EMBEDDING_KEY]),
+            edge_dst=data[AtomicDataDict.EDGE_INDEX_KEY][0],
+            edge_src=data[AtomicDataDict.EDGE_INDEX_KEY][1],
+        )[:num_local_nodes]
+
+        x = self.linear_2(x)
+        if self.sc is not None:
+            x = x + sc
+        data[AtomicDataDict.NODE_FEATURES_KEY] = x
+        return data

@@ -1,0 +1,85 @@
+"""Scalar MLPs (mirror of ``nequip/nn/mlp.py:34-271``): bias-free ``x @ (W * alpha)`` layers with
+``alpha = gain / sqrt(fan_in)`` and SiLU in between.  ``ScalarMLPFunction`` as the per-edge radial network
+(``InteractionBlock.edge_mlp``, ``nequip/nn/interaction_block.py:119-127``) is the dense-GEMM part of the hot
+path: on the GPU it runs through the fused MFMA kernel of ``nequip_amd/csrc/radial_mlp.hip`` when available
+for its shape, otherwise through hipBLASLt ``mm``."""
+
+from math import sqrt
+from typing import Optional
+
+import torch
+
+from ..data import AtomicDataDict
+from ..o3.irreps import Irreps
+from ._graph_mixin import GraphModuleMixin
+
+
+class ScalarLinearLayer(torch.nn.Module):
+    def __init__(self, in_features: int, out_features: int, alpha: float = 1.0, bias: bool = False,
+                 init_mode: str = "uniform") -> None:
+        super().__init__()
+        assert not bias, "the hot-path MLPs are bias-free (nequip/nn/interaction_block.py:125)"
+        self.in_features = in_features
+        self.out_features = out_features
+        self.register_buffer("alpha", torch.tensor(alpha), persistent=False)
+        self.weight = torch.nn.Parameter(torch.empty((in_features, out_features)))
+        if init_mode == "uniform":
+            torch.nn.init.uniform_(self.weight, -sqrt(3), sqrt(3))
+        elif init_mode == "normal":
+            torch.nn.init.normal_(self.weight, mean=0.0, std=1.0)
+        else:
+            raise ValueError(f"Unknown init_mode: {init_mode}")
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return torch.mm(input, self.weight * self.alpha)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, alpha={float(self.alpha):.6f}"
+
+
+class ScalarMLPFunction(torch.nn.Module):
+    def __init__(self, input_dim: int, output_dim: int, hidden_layers_depth: int = 0,
+                 hidden_layers_width: Optional[int] = None, nonlinearity: Optional[str] = "silu", bias: bool = False,
+                 forward_weight_init: bool = True, init_mode: str = "uniform"):
+        super().__init__()
+        assert nonlinearity in ("silu", None), "the hot path hard-codes SiLU (interaction_block.py:124)"
+        assert forward_weight_init
+        if hidden_layers_depth != 0:
+            assert hidden_layers_depth > 0 and hidden_layers_width > 0
+        self.dims = [input_dim] + hidden_layers_depth * [hidden_layers_width] + [output_dim]
+        self.num_layers = len(self.dims) - 1
+        self.is_nonlinear = False
+        mlp = torch.nn.Sequential()
+        for layer, (h_in, h_out) in enumerate(zip(self.dims, self.dims[1:])):
+            gain = 1.0 if nonlinearity is None or (layer == 0) else sqrt(2)
+            mlp.append(ScalarLinearLayer(h_in, h_out, alpha=gain / sqrt(h_in), bias=bias, init_mode=init_mode))
+            if (layer != self.num_layers - 1) and (nonlinearity is not None):
+                mlp.append(torch.nn.SiLU())
+                self.is_nonlinear = True
+        self.mlp = mlp
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class ScalarMLP(GraphModuleMixin, torch.nn.Module):
+    """Apply an MLP to a scalar node field (the per-atom energy readout, ``nequip_models.py:371-381``)."""
+
+    def __init__(self, output_dim: int, hidden_layers_depth: int = 0, hidden_layers_width: Optional[int] = None,
+                 nonlinearity: Optional[str] = "silu", bias: bool = False, forward_weight_init: bool = True,
+                 field: str = AtomicDataDict.NODE_FEATURES_KEY, out_field: Optional[str] = None, irreps_in=None):
+        super().__init__()
+        self.field = field
+        self.out_field = out_field if out_field is not None else field
+        self._init_irreps(irreps_in=irreps_in, required_irreps_in=[self.field])
+        assert len(self.irreps_in[self.field]) == 1 and self.irreps_in[self.field][0].ir == (0, 1)
+        self.mlp_module = ScalarMLPFunction(
+            input_dim=self.irreps_in[self.field][0].mul, output_dim=output_dim,
+            hidden_layers_depth=hidden_layers_depth, hidden_layers_width=hidden_layers_width,
+            nonlinearity=nonlinearity, bias=bias, forward_weight_init=forward_weight_init,
+        )
+        self.irreps_out[self.out_field] = Irreps([(self.mlp_module.dims[-1], (0, 1))])
+
+    def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        data[self.out_field] = self.mlp_module(data[self.field])
+        return data

@@ -1,0 +1,235 @@
+"""Node-side equivariant modules of the hot path: channel-mixing ``Linear``, the self-connection
+``FullyConnectedTensorProduct`` and ``Gate``.
+
+In the reference these are ``e3nn.o3.Linear`` (``nequip/nn/interaction_block.py:82-87,129-138``),
+``e3nn.o3.FullyConnectedTensorProduct`` (``:142-146``) and ``e3nn.nn.Gate``
+(``nequip/nn/convnetlayer.py:104-112``); semantics restated from SURVEY.md A.5-A.7.  They act on the N
+node rows only (dense GEMMs with K = mul), so they are expressed as plain matmuls that rocBLAS/hipBLASLt
+executes on MFMA -- "library GEMM" plumbing, not hand-written kernels.  Parameter names, shapes, flat
+weight layout and initialisation (N(0,1)) follow e3nn so that state dicts are interchangeable.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from .irreps import Irrep, Irreps
+
+
+class Linear(torch.nn.Module):
+    """``out[z, i_out, w, m] = sum_{i_in} fan_in(i_out)^-1/2 sum_u x[z, i_in, u, m] W[u, w]`` (no bias)."""
+
+    def __init__(self, irreps_in, irreps_out, internal_weights: bool = True, shared_weights: bool = True):
+        super().__init__()
+        assert internal_weights and shared_weights
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_out)
+        self.instructions = [
+            (i, o)
+            for i, (_, ir_in) in enumerate(self.irreps_in)
+            for o, (_, ir_out) in enumerate(self.irreps_out)
+            if ir_in == ir_out
+        ]
+        fan_in = [0] * len(self.irreps_out)
+        for i, o in self.instructions:
+            fan_in[o] += self.irreps_in[i].mul
+        self._scale = [1.0 / math.sqrt(f) if f > 0 else 0.0 for f in fan_in]
+        self.weight_numel = sum(self.irreps_in[i].mul * self.irreps_out[o].mul for i, o in self.instructions)
+        self.weight = torch.nn.Parameter(torch.randn(self.weight_numel))
+        self._in_slices = self.irreps_in.slices()
+        # e3nn-compatible view of where each 2-D weight sits in the flat parameter (cf. nequip/model/param_groups.py:71-88)
+        self.weight_index_slices = []
+        off = 0
+        for i, o in self.instructions:
+            n = self.irreps_in[i].mul * self.irreps_out[o].mul
+            self.weight_index_slices.append((slice(off, off + n), (self.irreps_in[i].mul, self.irreps_out[o].mul)))
+            off += n
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        Z = x.shape[0]
+        outs: List[Optional[torch.Tensor]] = [None] * len(self.irreps_out)
+        for (i, o), (sl, shape) in zip(self.instructions, self.weight_index_slices):
+            mul_in, ir = self.irreps_in[i]
+            d = ir.dim
+            W = self.weight[sl].view(shape) * self._scale[o]
+            xa = x[:, self._in_slices[i]]
+            if d == 1:
+                r = torch.mm(xa, W)
+            else:
+                # [Z, mul_in, d] -> [Z, d, mul_in] @ [mul_in, mul_out] -> [Z, mul_out, d]
+                r = torch.matmul(xa.reshape(Z, mul_in, d).transpose(1, 2), W).transpose(1, 2).reshape(Z, -1)
+            outs[o] = r if outs[o] is None else outs[o] + r
+        cols = [
+            outs[o] if outs[o] is not None else x.new_zeros(Z, mul_ir.dim) for o, mul_ir in enumerate(self.irreps_out)
+        ]
+        return torch.cat(cols, dim=-1) if len(cols) > 1 else cols[0]
+
+    def extra_repr(self) -> str:
+        return f"{self.irreps_in} -> {self.irreps_out} | {self.weight_numel} weights"
+
+
+class FullyConnectedTensorProduct(torch.nn.Module):
+    """Self-connection ``sc(x, node_attrs)`` with scalar (``Nx0e``) second operand.
+
+    ``out[z, w, m] = (sum_paths mul1*mul2)^-1/2 sum_{u,v} W[u, v, w] x[z, u, m] a[z, v]``.
+    Two evaluation orders are provided (identical in exact arithmetic):
+
+    * ``forward(x, a)``: the reference's order -- outer product ``x (x) a`` then one GEMM with K = mul1*mul2
+      (5.8 MFLOP/node/layer at 64 features, SURVEY.md hard part 6);
+    * ``forward_typed(x, types, table)``: when ``a = table[types]`` (an embedding lookup), contract the weights
+      with the T table rows first (``W_t[u, w] = sum_v table[t, v] W[u, v, w]``) and run one GEMM with
+      K = T*mul1 over one-hot-expanded features -- mul2/T times fewer FLOPs.
+    """
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out):
+        super().__init__()
+        self.irreps_in1 = Irreps(irreps_in1)
+        self.irreps_in2 = Irreps(irreps_in2)
+        self.irreps_out = Irreps(irreps_out)
+        if any(ir.l != 0 or ir.p != 1 for _, ir in self.irreps_in2):
+            raise NotImplementedError("self-connection second operand must be even scalars (node attributes)")
+        self.instructions = [
+            (i1, i2, io)
+            for i1, (_, ir1) in enumerate(self.irreps_in1)
+            for i2, (_, ir2) in enumerate(self.irreps_in2)
+            for io, (_, iro) in enumerate(self.irreps_out)
+            if iro in list(ir1 * ir2)
+        ]
+        fan = [0] * len(self.irreps_out)
+        for i1, i2, io in self.instructions:
+            fan[io] += self.irreps_in1[i1].mul * self.irreps_in2[i2].mul
+        self._scale = [1.0 / math.sqrt(f) if f > 0 else 0.0 for f in fan]
+        self.weight_numel = sum(
+            self.irreps_in1[i1].mul * self.irreps_in2[i2].mul * self.irreps_out[io].mul
+            for i1, i2, io in self.instructions
+        )
+        self.weight = torch.nn.Parameter(torch.randn(self.weight_numel))
+        self._s1 = self.irreps_in1.slices()
+        self._s2 = self.irreps_in2.slices()
+        self._wslices = []
+        off = 0
+        for i1, i2, io in self.instructions:
+            shape = (self.irreps_in1[i1].mul, self.irreps_in2[i2].mul, self.irreps_out[io].mul)
+            n = shape[0] * shape[1] * shape[2]
+            self._wslices.append((slice(off, off + n), shape))
+            off += n
+
+    def _assemble(self, outs, x):
+        Z = x.shape[0]
+        cols = [
+            outs[o] if outs[o] is not None else x.new_zeros(Z, mul_ir.dim) for o, mul_ir in enumerate(self.irreps_out)
+        ]
+        return torch.cat(cols, dim=-1) if len(cols) > 1 else cols[0]
+
+    def forward(self, x: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+        Z = x.shape[0]
+        outs: List[Optional[torch.Tensor]] = [None] * len(self.irreps_out)
+        for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+            mul1, ir = self.irreps_in1[i1]
+            d = ir.dim
+            W = self.weight[sl].view(shape[0] * shape[1], shape[2]) * self._scale[io]
+            xa = x[:, self._s1[i1]].reshape(Z, mul1, d)
+            av = a[:, self._s2[i2]]
+            # [Z, d, mul1, mul2] -> GEMM over (u v)
+            xx = xa.transpose(1, 2).unsqueeze(-1) * av.view(Z, 1, 1, -1)
+            r = torch.matmul(xx.reshape(Z, d, -1), W).transpose(1, 2).reshape(Z, -1)
+            outs[io] = r if outs[io] is None else outs[io] + r
+        return self._assemble(outs, x)
+
+    def forward_typed(self, x: torch.Tensor, types: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+        Z = x.shape[0]
+        T = table.shape[0]
+        onehot = torch.nn.functional.one_hot(types.view(-1), T).to(x.dtype)  # [Z, T]
+        outs: List[Optional[torch.Tensor]] = [None] * len(self.irreps_out)
+        for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+            mul1, ir = self.irreps_in1[i1]
+            d = ir.dim
+            W = self.weight[sl].view(shape)
+            tb = table[:, self._s2[i2]]  # [T, mul2]
+            Wt = torch.einsum("tv,uvw->tuw", tb, W).reshape(T * mul1, shape[2]) * self._scale[io]
+            xa = x[:, self._s1[i1]].reshape(Z, mul1, d).transpose(1, 2)  # [Z, d, mul1]
+            xx = onehot.view(Z, 1, T, 1) * xa.unsqueeze(2)  # [Z, d, T, mul1]
+            r = torch.matmul(xx.reshape(Z, d, T * mul1), Wt).transpose(1, 2).reshape(Z, -1)
+            outs[io] = r if outs[io] is None else outs[io] + r
+        return self._assemble(outs, x)
+
+    def extra_repr(self) -> str:
+        return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {self.weight_numel} weights"
+
+
+_NORMALIZE2MOM_CACHE = {}
+
+
+def normalize2mom_const(act: Callable, key: str) -> float:
+    """e3nn ``normalize2mom``: ``(E_{z~N(0,1)} act(z)^2)^-1/2`` from 1e6 seeded float64 samples."""
+    if key not in _NORMALIZE2MOM_CACHE:
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        z = torch.randn(1_000_000, generator=gen, dtype=torch.float64)
+        cst = act(z).pow(2).mean().pow(-0.5).item()
+        _NORMALIZE2MOM_CACHE[key] = 1.0 if abs(cst - 1.0) < 1e-4 else cst
+    return _NORMALIZE2MOM_CACHE[key]
+
+
+class Gate(torch.nn.Module):
+    """``scalars (+) gates (+) gated -> act(scalars) (+) act(gates)[u] * gated[u, :]``."""
+
+    def __init__(self, irreps_scalars, act_scalars: Sequence[Callable], irreps_gates, act_gates: Sequence[Callable],
+                 irreps_gated):
+        super().__init__()
+        self.irreps_scalars = Irreps(irreps_scalars)
+        self.irreps_gates = Irreps(irreps_gates)
+        self.irreps_gated = Irreps(irreps_gated)
+        assert all(ir.l == 0 for _, ir in self.irreps_scalars) and all(ir.l == 0 for _, ir in self.irreps_gates)
+        assert self.irreps_gates.num_irreps == self.irreps_gated.num_irreps
+        assert len(act_scalars) == len(self.irreps_scalars) and len(act_gates) == len(self.irreps_gates)
+        self.act_scalars = list(act_scalars)
+        self.act_gates = list(act_gates)
+        self._cst_scalars = [normalize2mom_const(a, getattr(a, "__name__", repr(a))) for a in self.act_scalars]
+        self._cst_gates = [normalize2mom_const(a, getattr(a, "__name__", repr(a))) for a in self.act_gates]
+        self.irreps_in = (self.irreps_scalars + self.irreps_gates + self.irreps_gated).simplify()
+        out_scalars = []
+        x = torch.linspace(0, 10, 256, dtype=torch.float64)
+        for (mul, ir), act in zip(self.irreps_scalars, self.act_scalars):
+            p_out = ir.p
+            if ir.p == -1:
+                a1, a2 = act(x), act(-x)
+                if (a1 - a2).abs().max() < 1e-5:
+                    p_out = 1  # even activation turns odd scalars even
+                elif (a1 + a2).abs().max() < 1e-5:
+                    p_out = -1
+                else:
+                    raise ValueError("activation of an odd scalar must be even or odd")
+            out_scalars.append((mul, (0, p_out)))
+        self.irreps_out = Irreps(out_scalars) + self.irreps_gated
+
+    @staticmethod
+    def _activate(t, irreps, acts, csts):
+        if len(irreps) == 1:
+            r = acts[0](t)
+            return r * csts[0] if csts[0] != 1.0 else r
+        cols, off = [], 0
+        for (mul, _), act, cst in zip(irreps, acts, csts):
+            r = act(t[:, off : off + mul])
+            cols.append(r * cst if cst != 1.0 else r)
+            off += mul
+        return torch.cat(cols, dim=-1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        ns, ng = self.irreps_scalars.dim, self.irreps_gates.dim
+        scalars = self._activate(x[:, :ns], self.irreps_scalars, self.act_scalars, self._cst_scalars)
+        if ng == 0:
+            return scalars
+        gates = self._activate(x[:, ns : ns + ng], self.irreps_gates, self.act_gates, self._cst_gates)
+        gated = x[:, ns + ng :]
+        Z = x.shape[0]
+        cols, goff, xoff = [scalars], 0, 0
+        for mul, ir in self.irreps_gated:
+            g = gates[:, goff : goff + mul]
+            goff += mul
+            blk = gated[:, xoff : xoff + mul * ir.dim].reshape(Z, mul, ir.dim)
+            xoff += mul * ir.dim
+            cols.append((blk * g.unsqueeze(-1)).reshape(Z, mul * ir.dim))
+        return torch.cat(cols, dim=-1)
