@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Benchmark of the NequIP message-passing hot path on MI355X.
+
+Metric (BASELINE.json): atom-steps/s = atoms / wall time of one *energy + forces* evaluation of the model
+(eval mode, neighbour list prebuilt and resident in HBM, float32 model / float64 positions).  Workload at N=1:
+BASELINE config "10k-atom periodic water box, l_max=2, 64 features, 3 interaction layers" (SURVEY.md 8(d) cfg-3:
+15^3 H2O = 10 125 atoms, r_max 4.5 A, parity=False, radial MLP 128x1).  With N>1 every rank evaluates its own
+copy of the box (frames are independent; replicas, no data-path collective) and the value is the aggregate.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant hand-written
+kernel: algorithmic bytes / HIP-event duration on the launching stream) and `cpu_baseline` (the CPU oracle,
+``oracle/``, timed on a bounded sample of the same workload on this host).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (box builder kwargs, model kwargs)
+    "water10k": dict(box="water", n_side=15, l_max=2, num_features=64, num_layers=3),
+    "si1k": dict(box="si", reps=5, l_max=2, num_features=64, num_layers=3),
+    "water_small": dict(box="water", n_side=5, l_max=2, num_features=64, num_layers=3),
+}
+
+
+def model_cfg(w, avg_num_neighbors):
+    return dict(
+        r_max=4.5, num_layers=w["num_layers"], l_max=w["l_max"], parity=False, num_features=w["num_features"],
+        radial_mlp_depth=1, radial_mlp_width=128, num_bessels=8, polynomial_cutoff_p=6,
+        avg_num_neighbors=float(avg_num_neighbors), model_dtype="float32",
+    )  # fmt: skip
+
+
+def build_box(w, seed=0):
+    from nequip_amd.utils import synthetic as syn
+
+    if w["box"] == "water":
+        pos, types, cell, names = syn.water_box(n_side=w["n_side"], seed=seed)
+    elif w["box"] == "si":
+        pos, types, cell, names = syn.silicon_box(reps=w["reps"], seed=seed)
+    else:
+        raise ValueError(w["box"])
+    data = syn.make_data(pos, types, 4.5, cell)
+    return data, names
+
+
+def build_model(cfg, names, device, seed=0):
+    from nequip_amd.model import NequIPGNNModel
+
+    kw = {k: v for k, v in cfg.items() if k not in ("model_dtype",)}
+    model = NequIPGNNModel(seed=seed, model_dtype=cfg["model_dtype"], type_names=names, **kw)
+    return model.to(device).eval()
+
+
+def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
+    """Time the CPU oracle (reference op order, PyTorch CPU ops) on a bounded sample of the same workload."""
+    from oracle import model as omodel
+
+    w = dict(WORKLOADS[workload_name])
+    # bounded sample: same density / r_max / model, smaller box
+    if w["box"] == "water":
+        w["n_side"] = min(w["n_side"], 5)
+    else:
+        w["reps"] = min(w["reps"], 3)
+    data, names = build_box(w, seed=1)
+    n_atoms = data["pos"].shape[0]
+    n_edges = data["edge_index"].shape[1]
+    cfg = model_cfg(w, n_edges / n_atoms)
+    model = build_model(cfg, names, torch.device("cpu"))
+    weights = {k.replace("model.func.", ""): v.detach() for k, v in model.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    specs = omodel.build_specs(cfg)
+    omodel.energy_forces(data, cfg, weights, specs)  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t_start) < max_seconds:
+        t0 = time.perf_counter()
+        omodel.energy_forces(data, cfg, weights, specs)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": n_atoms / med,
+        "unit": "atom-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_atoms}-atom {w['box']} box ({n_edges} edges), same density/r_max/model as the workload, "
+        f"median of {len(times)} energy+forces evaluations of the torch-CPU oracle (e3nn unavailable: restatement)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="water10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-steps", type=int, default=3, help="eager steps instrumented with HIP events for `roofline`")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.nn import topology_cache
+    from nequip_amd.utils import ktimer
+
+    w = WORKLOADS[args.workload]
+    data_cpu, names = build_box(w, seed=rank)
+    n_atoms = data_cpu["pos"].shape[0]
+    n_edges = data_cpu["edge_index"].shape[1]
+    cfg = model_cfg(w, n_edges / n_atoms)
+    model = build_model(cfg, names, device)
+    data = AtomicDataDict.to_device(data_cpu, device)
+    static_pos = data["pos"].clone()
+
+    def step_eager():
+        d = dict(data)
+        d["pos"] = static_pos
+        out = model(d)
+        # detach: nothing of the autograd graph must outlive the step (and be alive during hipGraph capture)
+        return out["total_energy"].detach(), out["forces"].detach()
+
+    # ---- warm-up (also builds CSR, allocator pools, hipBLASLt heuristics) -------------------------------
+    for _ in range(max(args.warmup, 1)):
+        e, f = step_eager()
+    torch.cuda.synchronize()
+
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            # the edge topology (CSR) is static for a fixed neighbour list: it is built once in the eager
+            # warm-up above and stays cached; the graph captures the model evaluation only
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step_eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                g_e, g_f = step_eager()
+            graph.replay()
+            torch.cuda.synchronize()
+            e2, f2 = step_eager()
+            torch.cuda.synchronize()
+            if not torch.allclose(g_f, f2, atol=1e-5, rtol=1e-5):
+                raise RuntimeError("graph replay disagrees with eager")
+        except Exception as exc:  # pragma: no cover
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); timing eager", file=sys.stderr)
+            graph = None
+            topology_cache.clear()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step_eager()
+
+    for _ in range(args.warmup):
+        step()
+
+    # ---- timed region ---------------------------------------------------------------------------------
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel HIP-event timing of the hand-written kernels (eager, on the launching stream) ------
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ktimer.reset()
+        ktimer.enable(True)
+        for _ in range(args.kernel_steps):
+            step_eager()
+        torch.cuda.synchronize()
+        ktimer.enable(False)
+        kernels = ktimer.summary()
+        if kernels:
+            dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
+            name, s = dom
+            roofline = {
+                "bound": "hbm",
+                "kernel": name,
+                "achieved": s["gbps"],
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": s["gbps"] / HBM_PEAK_GBPS,
+                "traffic": None,
+                "avg_launch_ms": s["avg_ms"],
+                "algorithmic_bytes_per_launch": s["bytes_per_call"],
+                "launches_per_step": s["calls"] / max(args.kernel_steps, 1),
+            }
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n_atoms * args.steps / elapsed
+        result = {
+            "metric": "atom-steps/s (energy+forces)",
+            "value": value,
+            "unit": "atom-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {n_atoms}-atom periodic {w['box']} box, {n_edges} edges, r_max 4.5, "
+                f"l_max={w['l_max']}, {w['num_features']} features, {w['num_layers']} layers, parity=False, "
+                "radial MLP 8-128-W, fp32 model / fp64 positions, energy+forces (autograd), random-init weights",
+                "atoms_per_gpu": n_atoms,
+                "edges_per_gpu": n_edges,
+                "parallelism": f"replicas x{world} (frames independent, no data-path collective)",
+                "launch": "hipGraph replay" if graph is not None else "eager",
+            },
+            "roofline": roofline,
+            "kernels_ms_per_step": {k: v["total_ms"] / max(args.kernel_steps, 1) for k, v in kernels.items()},
+            "kernels_gbps": {k: v["gbps"] for k, v in kernels.items()},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload)
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

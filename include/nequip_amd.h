@@ -53,7 +53,8 @@ enum nqa_plan_field {
   NQA_PLAN_WEIGHT_NUMEL = 3, /* e3nn TensorProduct.weight_numel                              */
   NQA_PLAN_NUM_INSTR = 4,
   NQA_PLAN_OUT_NEEDS_ZERO = 5, /* 1 if output slots are shared/uncovered (caller must zero `out`) */
-  NQA_PLAN_YPART_WIDTH = 6   /* columns of the per-edge dY partial buffer (bwd_edge workspace) */
+  NQA_PLAN_YPART_WIDTH = 6,  /* columns of the per-edge dY partial buffer (bwd_edge workspace) */
+  NQA_PLAN_HAS_SPECIALIZED = 7 /* 1 if structure-specialised (edge-outer) kernels are prebuilt for this plan */
 };
 
 typedef struct nqa_plan nqa_plan;

@@ -23,6 +23,7 @@ LIB_NAME = "libnequip_amd.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 OBJ_DIR = os.path.join(HERE, "build")
 GEN_DIR = os.path.join(HERE, "generated")
+SPEC_DIR = os.path.join(HERE, "generated_spec")
 
 SOURCES = ["plan.cpp", "csr.hip", "tp_generic.hip", "edge_embed.hip", "radial_mlp.hip", "tp_fused.hip"]
 ARCH = "gfx950"
@@ -64,7 +65,7 @@ def _digest(paths) -> str:
 
 def _headers() -> list:
     hs = [os.path.join(REPO, "include", "nequip_amd.h")]
-    for d in (HERE, GEN_DIR):
+    for d in (HERE, GEN_DIR):  # (generated_spec/*.hip are sources, each hashed on its own)
         if os.path.isdir(d):
             hs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
     return hs
@@ -84,9 +85,16 @@ def generate_tables(force: bool = False) -> None:
         f.write(want)
 
 
+def generate_specs() -> list:
+    sys.path.insert(0, HERE)
+    import gen_spec  # noqa: E402
+
+    return [os.path.relpath(p, HERE) for p in gen_spec.generate(SPEC_DIR)]
+
+
 def _compile_one(src: str, force: bool) -> str:
     src_path = os.path.join(HERE, src)
-    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
     stamp = obj + ".stamp"
     want = _digest([src_path] + _headers())
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
@@ -106,6 +114,7 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     generate_tables(force)
     sources = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    sources += generate_specs()
     jobs = jobs or min(len(sources), os.cpu_count() or 1)
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile_one(s, force), sources))

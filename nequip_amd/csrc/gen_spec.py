@@ -1,0 +1,426 @@
+#!/usr/bin/env python3
+"""Generate path-structure-specialised tensor-product/scatter kernels (one .hip per structure).
+
+The generic kernels (``tp_generic.hip``) visit one instruction per wavefront, so the per-edge operands of a
+node are fetched once *per path* and every iteration is a short dependent load chain (latency bound).  For the
+uniform-multiplicity structures NequIP actually builds (``nequip/nn/interaction_block.py:89-109``: every
+feature irrep has the same ``mul``) this generator emits "edge-outer" kernels instead: one wavefront owns 64
+channels of one node, and per edge it issues *all* loads of that edge at once -- the full coalesced weight-row
+segment of every path, the complete source-node row and the (scalar) spherical harmonics -- then evaluates every
+path from registers with the unrolled Clebsch-Gordan code of ``cg_generated.h``.  All per-node outputs stay in
+VGPRs across the neighbour loop and are stored once.
+
+A structure is: the ``l`` of each in1 / in2 / out irrep and the instruction triples; ``mul`` is a runtime
+argument (offsets scale with it), so one kernel serves 32/64/128... features.  ``STRUCTURES`` lists what is
+prebuilt (the BASELINE model shapes); plans whose structure is not listed run on the generic kernels.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+from typing import List, Sequence, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+
+from nequip_amd.o3.irreps import Irreps  # noqa: E402
+
+
+class Structure:
+    def __init__(self, in1_ls: Sequence[int], in2_ls: Sequence[int], out_ls: Sequence[int],
+                 instr: Sequence[Tuple[int, int, int]], name: str = ""):
+        self.in1_ls = list(in1_ls)
+        self.in2_ls = list(in2_ls)
+        self.out_ls = list(out_ls)
+        self.instr = [tuple(t) for t in instr]
+        self.name = name
+
+    def key(self) -> str:
+        """Must match ``structure_key`` in plan.cpp."""
+        s = "i1:" + ",".join(map(str, self.in1_ls))
+        s += "|i2:" + ",".join(map(str, self.in2_ls))
+        s += "|o:" + ",".join(map(str, self.out_ls))
+        s += "|p:" + ",".join(f"{a}-{b}-{c}" for a, b, c in self.instr)
+        return s
+
+    def tag(self) -> str:
+        return hashlib.sha1(self.key().encode()).hexdigest()[:12]
+
+
+def nequip_structure(feature_irreps_in: str, lmax_sh: int, feature_irreps_out: str, name: str) -> Structure:
+    """Replay InteractionBlock's instruction construction (interaction_block.py:89-109)."""
+    f_in = Irreps(feature_irreps_in)
+    e_at = Irreps.spherical_harmonics(lmax_sh)
+    f_out = Irreps(feature_irreps_out)
+    mid, ins = [], []
+    for i, (mul, ir_in) in enumerate(f_in):
+        for j, (_, ir_e) in enumerate(e_at):
+            for ir_out in ir_in * ir_e:
+                if ir_out in f_out:
+                    k = len(mid)
+                    mid.append((mul, ir_out))
+                    ins.append((i, j, k))
+    mid_sorted, p, _ = Irreps(mid).sort()
+    ins = [(a, b, p[c]) for a, b, c in ins]
+    return Structure([ir.l for _, ir in f_in], [ir.l for _, ir in e_at], [ir.l for _, ir in mid_sorted], ins, name)
+
+
+def baseline_structures() -> List[Structure]:
+    out = []
+    for lmax in (1, 2, 3):
+        for parity in (False, True):
+            hidden = "+".join(
+                f"1x{l}{'e' if p == 1 else 'o'}"
+                for l in range(lmax + 1)
+                for p in ((1, -1) if parity else ((1,) if l % 2 == 0 else (-1,)))
+            )
+            tag = f"l{lmax}{'p' if parity else 'n'}"
+            # conv output irreps = scalars (+ gate scalars) + gated, simplified -> same set of (l,p) as hidden
+            first = nequip_structure("1x0e", lmax, hidden, f"{tag}_first")
+            out.append(first)
+            if parity:
+                # second layer of a parity model sees only what layer 0 could produce: 0e, 1o, 2e, ...
+                reach = "+".join(f"1x{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lmax + 1))
+                out.append(nequip_structure(reach, lmax, hidden, f"{tag}_second"))
+                # layer >= 2 input = what the second layer produced (every hidden irrep reachable from `reach`)
+                out.append(nequip_structure(hidden, lmax, hidden, f"{tag}_mid"))
+                out.append(nequip_structure(hidden, lmax, "1x0e", f"{tag}_last"))
+                out.append(nequip_structure(reach, lmax, "1x0e", f"{tag}_last2"))
+            else:
+                out.append(nequip_structure(hidden, lmax, hidden, f"{tag}_mid"))
+                out.append(nequip_structure(hidden, lmax, "1x0e", f"{tag}_last"))
+    # de-duplicate by key
+    seen, uniq = set(), []
+    for s in out:
+        if s.key() not in seen and s.instr:
+            seen.add(s.key())
+            uniq.append(s)
+    return uniq
+
+
+# --------------------------------------------------------------------------------------------------------------
+
+
+def _emit(st: Structure) -> str:
+    NB, NY, NS, NP = len(st.in1_ls), len(st.in2_ls), len(st.out_ls), len(st.instr)
+    xpre = [sum(2 * l + 1 for l in st.in1_ls[:b]) for b in range(NB)]
+    ypre = [sum(2 * l + 1 for l in st.in2_ls[:j]) for j in range(NY)]
+    opre = [sum(2 * l + 1 for l in st.out_ls[:s]) for s in range(NS)]
+    XD = sum(2 * l + 1 for l in st.in1_ls)  # dim_in1 / mul
+    S = sum(2 * l + 1 for l in st.in2_ls)
+    OD = sum(2 * l + 1 for l in st.out_ls)  # dim_out / mul
+    n_into = [0] * NS
+    for _, _, s in st.instr:
+        n_into[s] += 1
+    coeff = [((2 * st.out_ls[s] + 1) / n_into[s]) ** 0.5 for _, _, s in st.instr]
+    used_blocks = sorted({b for b, _, _ in st.instr})
+    used_y = sorted({j for _, j, _ in st.instr})
+    tag = st.tag()
+    L = []
+    A = L.append
+    A(f"// GENERATED by gen_spec.py for structure '{st.name}': {st.key()}")
+    A("// Edge-outer specialised TensorProductScatter kernels (see gen_spec.py docstring).")
+    A('#include <hip/hip_runtime.h>')
+    A('#include <cstdint>')
+    A('#include "../generated/cg_generated.h"')
+    A('#include "../tp_spec.h"')
+    A("namespace nqa {")
+    A("namespace {")
+    A(f"constexpr int kXD = {XD}, kS = {S}, kOD = {OD}, kNP = {NP};")
+
+    def load_x(indent, row):
+        out = []
+        for b in used_blocks:
+            d = 2 * st.in1_ls[b] + 1
+            out.append(f"{indent}T xb{b}[{d}];")
+            out.append(f"{indent}{{ const T* __restrict__ p = {row} + (int64_t)mul * {xpre[b]} + (int64_t)u * {d};")
+            for i in range(d):
+                out.append(f"{indent}  xb{b}[{i}] = act ? p[{i}] : T(0);")
+            out.append(f"{indent}}}")
+        return out
+
+    def load_y(indent, row):
+        out = []
+        for j in used_y:
+            d = 2 * st.in2_ls[j] + 1
+            out.append(f"{indent}T yb{j}[{d}];")
+            for i in range(d):
+                out.append(f"{indent}yb{j}[{i}] = {row}[{ypre[j] + i}];")
+        return out
+
+    def load_w(indent, row, scale=False):
+        out = [f"{indent}T wv[kNP];"]
+        for p in range(NP):
+            c = f"T({coeff[p]!r}) * " if scale else ""
+            out.append(f"{indent}wv[{p}] = act ? {c}{row}[(int64_t)mul * {p}] : T(0);")
+        return out
+
+    # ------------------------------------------------------------------ forward
+    A("template <typename T, int WPN>")
+    A("__global__ __launch_bounds__(256) void fwd_kernel(const SpecArgs<T> a) {")
+    A("  const int lane = threadIdx.x & 63;")
+    A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+    A("  const int mul = a.mul;")
+    A("  const int nchunk = (mul + 63) >> 6;")
+    A("  int64_t item; int wsub;")
+    A("  if (WPN == 1) { item = (int64_t)blockIdx.x * 4 + wid; wsub = 0; } else { item = blockIdx.x; wsub = wid; }")
+    A("  const bool valid = item < (int64_t)a.N * nchunk;")
+    A("  if (WPN == 1 && !valid) return;")
+    A("  const int node = valid ? (int)(item / nchunk) : 0;")
+    A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
+    A("  const int u = chunk * 64 + lane;")
+    A("  const bool act = valid && (u < mul);")
+    A(f"  T acc[kOD];")
+    A("#pragma unroll")
+    A("  for (int k = 0; k < kOD; ++k) acc[k] = T(0);")
+    A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
+    A("  int idx = beg + wsub;")
+    A("  int e = 0, s = 0;")
+    A("  if (idx < end) { e = a.eid[idx]; s = a.nbr[idx]; }")
+    A("  while (idx < end) {")
+    A("    const int nidx = idx + WPN;")
+    A("    int e_n = 0, s_n = 0;")
+    A("    if (nidx < end) { e_n = a.eid[nidx]; s_n = a.nbr[nidx]; }")
+    A("    const T* __restrict__ xr = a.x + (int64_t)s * a.din;")
+    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn + u;")
+    A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
+    L.extend(load_w("    ", "wr"))
+    L.extend(load_x("    ", "xr"))
+    L.extend(load_y("    ", "yr"))
+    for p, (b, j, s) in enumerate(st.instr):
+        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
+        d3 = 2 * l3 + 1
+        A(f"    {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}, yb{j}, t);")
+        for k in range(d3):
+            A(f"      acc[{opre[s] + k}] += wv[{p}] * t[{k}]; }}" if k == d3 - 1 else f"      acc[{opre[s] + k}] += wv[{p}] * t[{k}];")
+    A("    idx = nidx; e = e_n; s = s_n;")
+    A("  }")
+    # scale by path coefficient: slots shared by several instructions have equal coeff per slot (same l3, same n_into)
+    slot_coeff = [None] * NS
+    for p, (_, _, s) in enumerate(st.instr):
+        slot_coeff[s] = coeff[p]
+    A("  if (WPN > 1) {")
+    A("    extern __shared__ __align__(16) unsigned char nqa_smem[];")
+    A("    T* red = reinterpret_cast<T*>(nqa_smem);")
+    A("    if (wsub > 0) {")
+    A("#pragma unroll")
+    A("      for (int k = 0; k < kOD; ++k) red[((wsub - 1) * kOD + k) * 64 + lane] = acc[k];")
+    A("    }")
+    A("    __syncthreads();")
+    A("    if (wsub > 0) return;")
+    A("#pragma unroll")
+    A("    for (int k = 0; k < kOD; ++k) {")
+    A("#pragma unroll")
+    A("      for (int w2 = 0; w2 < WPN - 1; ++w2) acc[k] += red[(w2 * kOD + k) * 64 + lane];")
+    A("    }")
+    A("  }")
+    A("  if (act) {")
+    A("    T* __restrict__ ob = a.out + (int64_t)node * a.dout;")
+    for s in range(NS):
+        d3 = 2 * st.out_ls[s] + 1
+        if slot_coeff[s] is None:
+            for k in range(d3):
+                A(f"    ob[(int64_t)mul * {opre[s]} + (int64_t)u * {d3} + {k}] = T(0);")
+        else:
+            for k in range(d3):
+                A(f"    ob[(int64_t)mul * {opre[s]} + (int64_t)u * {d3} + {k}] = T({slot_coeff[s]!r}) * acc[{opre[s] + k}];")
+    A("  }")
+    A("}")
+
+    # ------------------------------------------------------------------ backward (edge operands)
+    A("template <typename T, int WPN>")
+    A("__global__ __launch_bounds__(256) void bwd_edge_kernel(const SpecArgs<T> a) {")
+    A("  const int lane = threadIdx.x & 63;")
+    A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+    A("  const int mul = a.mul;")
+    A("  const int nchunk = (mul + 63) >> 6;")
+    A("  const int64_t witem = (int64_t)blockIdx.x * 4 + wid;")
+    A("  const int64_t item = witem / WPN;")
+    A("  const int wsub = (int)(witem - item * WPN);")
+    A("  if (item >= (int64_t)a.N * nchunk) return;")
+    A("  const int node = (int)(item / nchunk);")
+    A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
+    A("  const int u = chunk * 64 + lane;")
+    A("  const bool act = u < mul;")
+    A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
+    A("  if (beg + wsub >= end) return;")
+    A("  T gv[kOD];")
+    A("  {")
+    A("    const T* __restrict__ gb = a.g + (int64_t)node * a.dout;")
+    for s in range(NS):
+        d3 = 2 * st.out_ls[s] + 1
+        c = slot_coeff[s] if slot_coeff[s] is not None else 0.0
+        for k in range(d3):
+            A(f"    gv[{opre[s] + k}] = act ? T({c!r}) * gb[(int64_t)mul * {opre[s]} + (int64_t)u * {d3} + {k}] : T(0);")
+    A("  }")
+    A("  const bool need_gw = a.gw != nullptr;")
+    A("  const bool need_gy = a.gy != nullptr;")
+    A("  int idx = beg + wsub;")
+    A("  int e = a.eid[idx], s = a.nbr[idx];")
+    A("  while (idx < end) {")
+    A("    const int nidx = idx + WPN;")
+    A("    int e_n = 0, s_n = 0;")
+    A("    if (nidx < end) { e_n = a.eid[nidx]; s_n = a.nbr[nidx]; }")
+    A("    const T* __restrict__ xr = a.x + (int64_t)s * a.din;")
+    A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
+    L.extend(load_x("    ", "xr"))
+    A("    if (need_gw) {")
+    L.extend(load_y("      ", "yr"))
+    A("      T* __restrict__ gwr = a.gw + (int64_t)e * a.wn + u;")
+    for p, (b, j, s) in enumerate(st.instr):
+        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
+        d3 = 2 * l3 + 1
+        A(f"      {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}, yb{j}, t);")
+        terms = " + ".join(f"t[{k}] * gv[{opre[s] + k}]" for k in range(d3))
+        A(f"        const T r = {terms};")
+        A(f"        if (act) gwr[(int64_t)mul * {p}] = r; }}")
+    A("    }")
+    A("    if (need_gy) {")
+    A("      const T* __restrict__ wr = a.w + (int64_t)e * a.wn + u;")
+    L.extend(load_w("      ", "wr"))
+    A(f"      T q[kS];")
+    A("#pragma unroll")
+    A("      for (int j = 0; j < kS; ++j) q[j] = T(0);")
+    for p, (b, j, s) in enumerate(st.instr):
+        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
+        d2 = 2 * l2 + 1
+        A(f"      {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b}, gv + {opre[s]}, t);")
+        for i in range(d2):
+            A(f"        q[{ypre[j] + i}] += wv[{p}] * t[{i}];")
+        A("      }")
+    A("      T* __restrict__ gyr = a.gy + (int64_t)e * a.gy_stride + chunk * kS;")
+    A("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")
+    A("    }")
+    A("    idx = nidx; e = e_n; s = s_n;")
+    A("  }")
+    A("}")
+
+    # ------------------------------------------------------------------ backward (node features)
+    A("template <typename T, int WPN>")
+    A("__global__ __launch_bounds__(256) void bwd_x_kernel(const SpecArgs<T> a) {")
+    A("  const int lane = threadIdx.x & 63;")
+    A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+    A("  const int mul = a.mul;")
+    A("  const int nchunk = (mul + 63) >> 6;")
+    A("  int64_t item; int wsub;")
+    A("  if (WPN == 1) { item = (int64_t)blockIdx.x * 4 + wid; wsub = 0; } else { item = blockIdx.x; wsub = wid; }")
+    A("  const bool valid = item < (int64_t)a.N * nchunk;")
+    A("  if (WPN == 1 && !valid) return;")
+    A("  const int node = valid ? (int)(item / nchunk) : 0;")
+    A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
+    A("  const int u = chunk * 64 + lane;")
+    A("  const bool act = valid && (u < mul);")
+    A("  T acc[kXD];")
+    A("#pragma unroll")
+    A("  for (int i = 0; i < kXD; ++i) acc[i] = T(0);")
+    A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
+    A("  int idx = beg + wsub;")
+    A("  int e = 0, d = 0;")
+    A("  if (idx < end) { e = a.eid[idx]; d = a.nbr[idx]; }")
+    A("  while (idx < end) {")
+    A("    const int nidx = idx + WPN;")
+    A("    int e_n = 0, d_n = 0;")
+    A("    if (nidx < end) { e_n = a.eid[nidx]; d_n = a.nbr[nidx]; }")
+    A("    const T* __restrict__ gr = a.g + (int64_t)d * a.dout;")
+    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn + u;")
+    A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
+    L.extend(load_w("    ", "wr", scale=True))
+    used_slots = sorted({s for _, _, s in st.instr})
+    for s in used_slots:
+        d3 = 2 * st.out_ls[s] + 1
+        A(f"    T gs{s}[{d3}];")
+        A(f"    {{ const T* __restrict__ p = gr + (int64_t)mul * {opre[s]} + (int64_t)u * {d3};")
+        for k in range(d3):
+            A(f"      gs{s}[{k}] = act ? p[{k}] : T(0);")
+        A("    }")
+    L.extend(load_y("    ", "yr"))
+    for p, (b, j, s) in enumerate(st.instr):
+        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
+        d1 = 2 * l1 + 1
+        A(f"    {{ T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}, gs{s}, t);")
+        for i in range(d1):
+            A(f"      acc[{xpre[b] + i}] += wv[{p}] * t[{i}];")
+        A("    }")
+    A("    idx = nidx; e = e_n; d = d_n;")
+    A("  }")
+    A("  if (WPN > 1) {")
+    A("    extern __shared__ __align__(16) unsigned char nqa_smem[];")
+    A("    T* red = reinterpret_cast<T*>(nqa_smem);")
+    A("    if (wsub > 0) {")
+    A("#pragma unroll")
+    A("      for (int k = 0; k < kXD; ++k) red[((wsub - 1) * kXD + k) * 64 + lane] = acc[k];")
+    A("    }")
+    A("    __syncthreads();")
+    A("    if (wsub > 0) return;")
+    A("#pragma unroll")
+    A("    for (int k = 0; k < kXD; ++k) {")
+    A("#pragma unroll")
+    A("      for (int w2 = 0; w2 < WPN - 1; ++w2) acc[k] += red[(w2 * kXD + k) * 64 + lane];")
+    A("    }")
+    A("  }")
+    A("  if (act) {")
+    A("    T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+    for b in range(NB):
+        d = 2 * st.in1_ls[b] + 1
+        for i in range(d):
+            A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = acc[{xpre[b] + i}];")
+    A("  }")
+    A("}")
+
+    # ------------------------------------------------------------------ launchers + registration
+    A("template <int WPN>")
+    A("static int launch(int which, const SpecArgs<float>& a, hipStream_t stream) {")
+    A("  const int nchunk = (a.mul + 63) / 64;")
+    A("  const int64_t items = (int64_t)a.N * nchunk;")
+    A("  if (items == 0) return 0;")
+    A("  if (which == 1) {")
+    A("    const int64_t blocks = (items * WPN + 3) / 4;")
+    A("    hipLaunchKernelGGL((bwd_edge_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);")
+    A("    return 0;")
+    A("  }")
+    A("  const int64_t blocks = WPN == 1 ? (items + 3) / 4 : items;")
+    A("  if (which == 0) {")
+    A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kOD * 64 * sizeof(float) : 0;")
+    A("    hipLaunchKernelGGL((fwd_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
+    A("  } else {")
+    A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kXD * 64 * sizeof(float) : 0;")
+    A("    hipLaunchKernelGGL((bwd_x_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
+    A("  }")
+    A("  return 0;")
+    A("}")
+    A("static int launch_any(int which, int wpn, const SpecArgs<float>& a, hipStream_t stream) {")
+    A("  // LDS budget of the 4-way split: (WPN-1) * accumulators * 256 B per block")
+    A("  if (wpn >= 4 && kOD <= 64) return launch<4>(which, a, stream);")
+    A("  return launch<1>(which, a, stream);")
+    A("}")
+    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP);')
+    A("}  // namespace")
+    A("}  // namespace nqa")
+    return "\n".join(L) + "\n"
+
+
+def generate(out_dir: str) -> List[str]:
+    os.makedirs(out_dir, exist_ok=True)
+    files = []
+    for st in baseline_structures():
+        path = os.path.join(out_dir, f"tp_spec_{st.name}_{st.tag()}.hip")
+        src = _emit(st)
+        if not os.path.exists(path) or open(path).read() != src:
+            with open(path, "w") as f:
+                f.write(src)
+        files.append(path)
+    # drop stale files
+    keep = {os.path.basename(p) for p in files}
+    for fn in os.listdir(out_dir):
+        if fn.startswith("tp_spec_") and fn.endswith(".hip") and fn not in keep:
+            os.remove(os.path.join(out_dir, fn))
+    return files
+
+
+if __name__ == "__main__":
+    fs = generate(os.path.join(HERE, "generated_spec"))
+    for st in baseline_structures():
+        print(st.name, st.tag(), "paths", len(st.instr), "kOD", sum(2 * l + 1 for l in st.out_ls))
+    print(len(fs), "files")

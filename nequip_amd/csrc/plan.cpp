@@ -16,6 +16,7 @@
 #include <sstream>
 
 #include "generated/cg_generated.h"
+#include "tp_spec.h"
 
 namespace nqa {
 
@@ -24,6 +25,17 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+SpecEntry*& spec_registry_head() {
+  static SpecEntry* head = nullptr;
+  return head;
+}
+
+const SpecEntry* find_spec(const std::string& key) {
+  for (const SpecEntry* e = spec_registry_head(); e != nullptr; e = e->next)
+    if (e->key == key) return e;
+  return nullptr;
+}
 
 }  // namespace nqa
 
@@ -215,6 +227,32 @@ int nqa_plan_create(int32_t n_in1, const int32_t* in1_mul, const int32_t* in1_l,
     for (int u0 = 0; u0 < b.mul; u0 += 64) P->xchunks.push_back(XChunkDev{bi, u0});
   }
 
+  // structure key (must match Structure.key() in gen_spec.py) and specialised-kernel lookup: needs a common
+  // multiplicity over all feature / output irreps, mul_ir layouts and unit path weights
+  {
+    bool uniform = layout_in1 == NQA_LAYOUT_MUL_IR && layout_out == NQA_LAYOUT_MUL_IR && n_in1 > 0 && n_instr > 0;
+    const int32_t m0 = n_in1 > 0 ? in1_mul[0] : 0;
+    if (m0 <= 0) uniform = false;
+    for (int i = 0; i < n_in1 && uniform; ++i) uniform = in1_mul[i] == m0;
+    for (int i = 0; i < n_out && uniform; ++i) uniform = out_mul[i] == m0;
+    for (int i = 0; i < n_in2 && uniform; ++i) uniform = in2_mul[i] == 1;
+    for (int q = 0; q < n_instr && uniform; ++q) uniform = !instr_path_weight || instr_path_weight[q] == 1.0;
+    std::ostringstream key;
+    key << "i1:";
+    for (int i = 0; i < n_in1; ++i) key << (i ? "," : "") << in1_l[i];
+    key << "|i2:";
+    for (int i = 0; i < n_in2; ++i) key << (i ? "," : "") << in2_l[i];
+    key << "|o:";
+    for (int i = 0; i < n_out; ++i) key << (i ? "," : "") << out_l[i];
+    key << "|p:";
+    for (int q = 0; q < n_instr; ++q) key << (q ? "," : "") << instr_i1[q] << "-" << instr_i2[q] << "-" << instr_io[q];
+    P->structure_key = key.str();
+    if (uniform) {
+      P->spec = find_spec(P->structure_key);
+      P->uniform_mul = m0;
+    }
+  }
+
   // device image layout
   ImageLayout& L = P->layout;
   int64_t o = 0;
@@ -250,6 +288,7 @@ int64_t nqa_plan_query(const nqa_plan* plan, int32_t field) {
     case NQA_PLAN_NUM_INSTR: return (int64_t)plan->instr.size();
     case NQA_PLAN_OUT_NEEDS_ZERO: return plan->out_needs_zero;
     case NQA_PLAN_YPART_WIDTH: return plan->ypart_width;
+    case NQA_PLAN_HAS_SPECIALIZED: return plan->spec != nullptr ? 1 : 0;
     default: return -1;
   }
 }

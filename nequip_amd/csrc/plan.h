@@ -52,7 +52,14 @@ struct ImageLayout {
 
 }  // namespace nqa
 
+namespace nqa {
+struct SpecEntry;
+}
+
 struct nqa_plan {
+  const nqa::SpecEntry* spec = nullptr;  // structure-specialised kernels (gen_spec.py), if prebuilt
+  int32_t uniform_mul = 0;               // common multiplicity when spec != nullptr
+  std::string structure_key;
   int32_t dim_in1 = 0, dim_in2 = 0, dim_out = 0, weight_numel = 0;
   int32_t ypart_width = 0;
   int32_t out_needs_zero = 0;

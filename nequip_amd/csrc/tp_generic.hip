@@ -22,6 +22,9 @@
 
 #include "generated/cg_generated.h"
 #include "plan.h"
+#include "tp_spec.h"
+
+#include <cstdlib>
 
 namespace nqa {
 
@@ -415,6 +418,45 @@ static int launch_bwd_x(const nqa_plan* P, const void* image, const void* y, con
   return check_launch("nqa_tp_scatter_bwd_x");
 }
 
+// ---- structure-specialised ("edge-outer") kernels: used for float32 when prebuilt for the plan's structure ----
+static bool force_generic() {
+  static const bool v = [] {
+    const char* e = std::getenv("NQA_FORCE_GENERIC");
+    return e != nullptr && e[0] != '\0' && e[0] != '0';
+  }();
+  return v;
+}
+
+static bool use_spec(const nqa_plan* P, int32_t dtype) {
+  return P->spec != nullptr && dtype == NQA_F32 && !force_generic();
+}
+
+static int spec_wpn(const nqa_plan* P, int64_t N) {
+  // few (node, chunk) items -> split each node's edges over 4 wavefronts to fill the 256 CUs
+  const int64_t items = N * (int64_t)((P->uniform_mul + 63) / 64);
+  return items < 49152 ? 4 : 1;
+}
+
+__global__ __launch_bounds__(256) void spec_gy_reduce_kernel(const float* __restrict__ part, float* __restrict__ gy,
+                                                             int32_t S, int32_t nchunk, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t e = t / S;
+  const int j = (int)(t - e * S);
+  float r = 0.f;
+  for (int c = 0; c < nchunk; ++c) r += part[e * (int64_t)(nchunk * S) + c * S + j];
+  gy[t] = r;
+}
+
+static void spec_fill(SpecArgs<float>& a, const nqa_plan* P, int64_t N) {
+  a.N = (int32_t)N;
+  a.mul = P->uniform_mul;
+  a.din = P->dim_in1;
+  a.dout = P->dim_out;
+  a.wn = P->weight_numel;
+  a.gy_stride = P->dim_in2;
+}
+
 static int check_common(const nqa_plan* P, const void* image, int32_t dtype, const char* fn) {
   if (P == nullptr || image == nullptr) {
     set_error(std::string(fn) + ": NULL plan or plan image");
@@ -445,6 +487,20 @@ int nqa_tp_scatter_fwd(const nqa_plan* plan, const void* plan_image, int32_t dty
     return NQA_ERR_INVALID;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (use_spec(plan, dtype)) {
+    if (num_nodes == 0) return NQA_OK;
+    SpecArgs<float> a{};
+    spec_fill(a, plan, num_nodes);
+    a.x = static_cast<const float*>(x);
+    a.y = static_cast<const float*>(y);
+    a.w = static_cast<const float*>(w);
+    a.out = static_cast<float*>(out);
+    a.rowptr = rowptr_dst;
+    a.eid = edge_id_dst;
+    a.nbr = src_sorted;
+    plan->spec->launch(0, spec_wpn(plan, num_nodes), a, s);
+    return check_launch("nqa_tp_scatter_fwd(spec)");
+  }
   return dtype == NQA_F32
              ? launch_fwd<float>(plan, plan_image, x, y, w, rowptr_dst, edge_id_dst, src_sorted, out, num_nodes,
                                  num_edges, s)
@@ -476,6 +532,40 @@ int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_
     return NQA_ERR_WORKSPACE;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (use_spec(plan, dtype)) {
+    if (num_nodes == 0 || num_edges == 0) return NQA_OK;
+    SpecArgs<float> a{};
+    spec_fill(a, plan, num_nodes);
+    const int nchunk = (plan->uniform_mul + 63) / 64;
+    a.x = static_cast<const float*>(x);
+    a.y = static_cast<const float*>(y);
+    a.w = static_cast<const float*>(w);
+    a.g = static_cast<const float*>(grad_out);
+    a.gw = static_cast<float*>(grad_w);
+    a.rowptr = rowptr_dst;
+    a.eid = edge_id_dst;
+    a.nbr = src_sorted;
+    if (grad_y != nullptr) {
+      if (nchunk == 1) {
+        a.gy = static_cast<float*>(grad_y);
+        a.gy_stride = plan->dim_in2;
+      } else {
+        a.gy = static_cast<float*>(workspace);
+        a.gy_stride = plan->dim_in2 * nchunk;
+      }
+    }
+    plan->spec->launch(1, spec_wpn(plan, num_nodes), a, s);
+    rc = check_launch("nqa_tp_scatter_bwd_edge(spec)");
+    if (rc != NQA_OK) return rc;
+    if (grad_y != nullptr && nchunk > 1) {
+      const int64_t total = num_edges * (int64_t)plan->dim_in2;
+      hipLaunchKernelGGL(spec_gy_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                         static_cast<const float*>(workspace), static_cast<float*>(grad_y), plan->dim_in2, nchunk,
+                         total);
+      return check_launch("nqa_tp_scatter_bwd_edge(spec reduce)");
+    }
+    return NQA_OK;
+  }
   return dtype == NQA_F32 ? launch_bwd_edge<float>(plan, plan_image, x, y, w, grad_out, rowptr_dst, edge_id_dst,
                                                    src_sorted, grad_w, grad_y, workspace, num_nodes, num_edges, s)
                           : launch_bwd_edge<double>(plan, plan_image, x, y, w, grad_out, rowptr_dst, edge_id_dst,
@@ -494,6 +584,20 @@ int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t d
     return NQA_ERR_INVALID;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (use_spec(plan, dtype)) {
+    if (num_nodes == 0) return NQA_OK;
+    SpecArgs<float> a{};
+    spec_fill(a, plan, num_nodes);
+    a.y = static_cast<const float*>(y);
+    a.w = static_cast<const float*>(w);
+    a.g = static_cast<const float*>(grad_out);
+    a.out = static_cast<float*>(grad_x);
+    a.rowptr = rowptr_src;
+    a.eid = edge_id_src;
+    a.nbr = dst_sorted;
+    plan->spec->launch(2, spec_wpn(plan, num_nodes), a, s);
+    return check_launch("nqa_tp_scatter_bwd_x(spec)");
+  }
   return dtype == NQA_F32 ? launch_bwd_x<float>(plan, plan_image, y, w, grad_out, rowptr_src, edge_id_src,
                                                 dst_sorted, grad_x, num_nodes, num_edges, s)
                           : launch_bwd_x<double>(plan, plan_image, y, w, grad_out, rowptr_src, edge_id_src,

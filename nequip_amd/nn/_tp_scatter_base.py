@@ -23,6 +23,7 @@ from typing import Optional, Tuple
 import torch
 
 from .. import _lib
+from ..utils import ktimer
 from ..o3.irreps import Irreps
 from ..o3.tensor_product import NativePlan, TensorProduct
 from ._topology import EdgeTopology, _ptr, current_stream_ptr, topology_cache
@@ -65,7 +66,11 @@ class _Kernels:
         alloc = torch.zeros if self.out_needs_zero else torch.empty
         out = alloc((topo.num_nodes, self.dim_out), dtype=x.dtype, device=x.device)
         rowptr, eid, nbr = topo.by_dst
-        with torch.cuda.device(x.device):
+        es = x.element_size()
+        nbytes = topo.num_edges * (es * (self.weight_numel + self.dim_in2) + 16) + topo.num_nodes * es * (
+            self.dim_in1 + self.dim_out
+        )
+        with torch.cuda.device(x.device), ktimer.region("tp_fwd", nbytes):
             rc = lib.nqa_tp_scatter_fwd(
                 self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w),
                 _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(out), topo.num_nodes, topo.num_edges,
@@ -87,7 +92,12 @@ class _Kernels:
             ws_bytes = lib.nqa_tp_bwd_edge_workspace_bytes(self.plan.handle, _nqa_dtype(x.dtype), E)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
         rowptr, eid, nbr = topo.by_dst
-        with torch.cuda.device(x.device):
+        es = x.element_size()
+        nbytes = E * (es * (self.weight_numel + self.dim_in2) + 16) + topo.num_nodes * es * (
+            self.dim_in1 + self.dim_out
+        )
+        nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_edge", nbytes):
             rc = lib.nqa_tp_scatter_bwd_edge(
                 self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
                 _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gw), _ptr(gy), _ptr(ws), ws_bytes,
@@ -101,7 +111,11 @@ class _Kernels:
         lib = _lib.load()
         gx = torch.empty((topo.num_nodes, self.dim_in1), dtype=g.dtype, device=g.device)
         rowptr, eid, nbr = topo.by_src
-        with torch.cuda.device(g.device):
+        es = g.element_size()
+        nbytes = topo.num_edges * (es * (self.weight_numel + self.dim_in2) + 16) + topo.num_nodes * es * (
+            self.dim_in1 + self.dim_out
+        )
+        with torch.cuda.device(g.device), ktimer.region("tp_bwd_x", nbytes):
             rc = lib.nqa_tp_scatter_bwd_x(
                 self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(g),
                 _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gx), topo.num_nodes, topo.num_edges,

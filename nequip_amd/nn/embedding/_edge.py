@@ -16,6 +16,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from ... import _lib
+from ...utils import ktimer
 from ...data import AtomicDataDict
 from ...o3.irreps import Irreps
 from .._graph_mixin import GraphModuleMixin
@@ -44,7 +45,8 @@ class _EdgeEmbedFn(torch.autograd.Function):
         lmax = cfg["lmax"]
         sh = torch.empty((E, (lmax + 1) ** 2), dtype=out_dtype, device=vec.device) if cfg["want_sh"] else None
         emb = torch.empty((E, cfg["nb"]), dtype=out_dtype, device=vec.device) if cfg["want_emb"] else None
-        with torch.cuda.device(vec.device):
+        nbytes = E * (24 + out_dtype.itemsize * (((lmax + 1) ** 2 if cfg["want_sh"] else 0) + (cfg["nb"] if cfg["want_emb"] else 0)))
+        with torch.cuda.device(vec.device), ktimer.region("edge_embed_fwd", nbytes):
             rc = lib.nqa_edge_embed_fwd(
                 _dt(out_dtype), max(lmax, 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(), cfg["nb"],
                 _ptr(bessel_weights), cfg["p"], cfg["factor"], _ptr(sh), _ptr(emb), ctypes.c_void_p(),
@@ -69,7 +71,8 @@ class _EdgeEmbedFn(torch.autograd.Function):
         g_emb = g_emb.contiguous() if g_emb is not None else None
         E = vec.shape[0]
         g_vec = torch.empty((E, 3), dtype=torch.float64, device=vec.device)
-        with torch.cuda.device(vec.device):
+        nbytes = E * (48 + cfg["dtype"].itemsize * (((cfg["lmax"] + 1) ** 2 if g_sh is not None else 0) + (cfg["nb"] if g_emb is not None else 0)))
+        with torch.cuda.device(vec.device), ktimer.region("edge_embed_bwd", nbytes):
             rc = lib.nqa_edge_embed_bwd(
                 _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
                 cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(g_vec),

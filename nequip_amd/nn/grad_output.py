@@ -72,7 +72,8 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         data[K.FORCE_KEY] = torch.neg(grads[0])
         virial = grads[1].view(num_batch, 3, 3)
         if has_cell:
-            volume = torch.linalg.det(cell).abs().unsqueeze(-1)
+            # |a . (b x c)|, written out (no LAPACK call: keeps the step capturable in a hipGraph)
+            volume = torch.sum(cell[:, 0] * torch.linalg.cross(cell[:, 1], cell[:, 2], dim=-1), dim=-1).abs().unsqueeze(-1)
             data[K.STRESS_KEY] = virial / volume.view(num_batch, 1, 1)
             data[K.CELL_KEY] = orig_cell
         data[K.VIRIAL_KEY] = torch.neg(virial)
