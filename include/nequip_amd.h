@@ -145,6 +145,23 @@ int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t d
                          void* grad_x, int64_t num_nodes, int64_t num_edges, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Edge vectors: replaces with_edge_vectors_ (nequip/nn/utils.py:68-118),
+ *   edge_vec[e] = pos[edge_src[e]] - pos[edge_dst[e]] (+ edge_cell_shift[e] @ cell[batch[edge_dst[e]]]),
+ * (edge_dst = edge_index[0] = centre atom, edge_src = edge_index[1] = neighbour), all float64.
+ * cell [F,3,3] (rows = lattice vectors), edge_cell_shift [E,3] and batch [N] are optional (NULL: no
+ * periodic images / single frame).  The adjoint nqa_edge_vectors_bwd replaces the autograd of those
+ * index_select / baddbmm ops (the float64 atomic index_add kernels) by ordered per-atom sums over the
+ * two CSRs of nqa_csr_build: g_pos [N,3], and -- when g_cell_per_node [N,9] is non-NULL -- the per-atom
+ * contribution sum_{e: dst(e)=n} shift[e]^T g[e] to d/dcell (summed per frame by the caller).
+ * ------------------------------------------------------------------------------------------- */
+int nqa_edge_vectors_fwd(const double* pos, const int64_t* edge_dst, const int64_t* edge_src,
+                         const double* edge_cell_shift, const double* cell, const int64_t* batch,
+                         int64_t num_edges, double* edge_vec, nqa_stream stream);
+int nqa_edge_vectors_bwd(const double* g_edge_vec, const double* edge_cell_shift, const int32_t* rowptr_dst,
+                         const int32_t* edge_id_dst, const int32_t* rowptr_src, const int32_t* edge_id_src,
+                         int64_t num_nodes, double* g_pos, double* g_cell_per_node, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Edge embedding: real spherical harmonics + Bessel radial basis with polynomial cutoff.
  * Replaces, for precomputed float64 edge vectors (nequip/nn/utils.py:68-118),
  *   SphericalHarmonicEdgeAttrs.forward  (nequip/nn/embedding/_edge.py:193-198; e3nn

@@ -28,6 +28,7 @@ NQA_PLAN_WEIGHT_NUMEL = 3
 NQA_PLAN_NUM_INSTR = 4
 NQA_PLAN_OUT_NEEDS_ZERO = 5
 NQA_PLAN_YPART_WIDTH = 6
+NQA_PLAN_HAS_SPECIALIZED = 7
 
 _P32 = POINTER(c_int32)
 
@@ -66,6 +67,14 @@ SIGNATURES = {
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         + [c_int64, c_int64, c_void_p],
+    ),
+    "nqa_edge_vectors_fwd": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    ),
+    "nqa_edge_vectors_bwd": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     ),
     "nqa_edge_embed_fwd": (
         c_int32,

@@ -69,7 +69,7 @@ static int end_bit_for(int64_t N) {
 
 static size_t cub_temp_bytes(int64_t E, int end_bit) {
   size_t bytes = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
                                      (const int32_t*)nullptr, (int32_t*)nullptr, (int)E, 0, end_bit,
                                      (hipStream_t)0);
   return bytes;

@@ -32,10 +32,85 @@ def tp_path_exists(irreps_in1, irreps_in2, ir_out) -> bool:
     return False
 
 
+class _EdgeVectorsFn(torch.autograd.Function):
+    """(pos, cell) -> edge_vec on the GPU (``nqa_edge_vectors_fwd``); linear, so its adjoint ``_EdgeVectorsAdjFn``
+    and the adjoint's adjoint (this forward again) close the family for double backward."""
+
+    @staticmethod
+    def forward(ctx, pos, cell, edge_index, shift, batch):
+        from .. import _lib
+        from ._topology import _ptr, current_stream_ptr
+
+        lib = _lib.load()
+        pos_c = pos.contiguous()
+        E = edge_index.shape[1]
+        dst, src = edge_index[0].contiguous(), edge_index[1].contiguous()
+        vec = torch.empty((E, 3), dtype=torch.float64, device=pos.device)
+        cell_c = cell.contiguous() if cell is not None else None
+        with torch.cuda.device(pos.device):
+            rc = lib.nqa_edge_vectors_fwd(_ptr(pos_c), _ptr(dst), _ptr(src), _ptr(shift), _ptr(cell_c), _ptr(batch),
+                                          E, _ptr(vec), current_stream_ptr(pos.device))
+        _lib.check(rc, "nqa_edge_vectors_fwd")
+        ctx.edge_index, ctx.shift, ctx.batch = edge_index, shift, batch
+        ctx.num_nodes = pos.shape[0]
+        ctx.cell_shape = None if cell is None else tuple(cell.shape)
+        return vec
+
+    @staticmethod
+    def backward(ctx, g_vec):
+        need_cell = ctx.cell_shape is not None and ctx.needs_input_grad[1]
+        g_pos, g_cell = _EdgeVectorsAdjFn.apply(
+            g_vec, ctx.edge_index, ctx.shift, ctx.batch, ctx.num_nodes, ctx.cell_shape if need_cell else None
+        )
+        return g_pos, g_cell, None, None, None
+
+
+class _EdgeVectorsAdjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_vec, edge_index, shift, batch, num_nodes, cell_shape):
+        from .. import _lib
+        from ._topology import _ptr, current_stream_ptr, topology_cache
+
+        lib = _lib.load()
+        g = g_vec.contiguous()
+        topo = topology_cache.get(edge_index[0], edge_index[1], num_nodes)
+        rp_d, eid_d, _ = topo.by_dst
+        rp_s, eid_s, _ = topo.by_src
+        g_pos = torch.empty((num_nodes, 3), dtype=torch.float64, device=g.device)
+        part = torch.empty((num_nodes, 9), dtype=torch.float64, device=g.device) if cell_shape is not None else None
+        with torch.cuda.device(g.device):
+            rc = lib.nqa_edge_vectors_bwd(_ptr(g), _ptr(shift), _ptr(rp_d), _ptr(eid_d), _ptr(rp_s), _ptr(eid_s),
+                                          num_nodes, _ptr(g_pos), _ptr(part), current_stream_ptr(g.device))
+        _lib.check(rc, "nqa_edge_vectors_bwd")
+        g_cell = None
+        if cell_shape is not None:
+            nframes = 1
+            for d in cell_shape[:-2]:
+                nframes *= d
+            if batch is None or nframes == 1:
+                g_cell = part.sum(0).view(cell_shape)
+            else:
+                g_cell = torch.zeros((nframes, 9), dtype=torch.float64, device=g.device).index_add_(0, batch, part)
+                g_cell = g_cell.view(cell_shape)
+        ctx.edge_index, ctx.shift, ctx.batch = edge_index, shift, batch
+        ctx.has_cell = cell_shape is not None
+        return g_pos, g_cell
+
+    @staticmethod
+    def backward(ctx, c_pos, c_cell):
+        # adjoint of the adjoint = the (linear) forward map applied to the cotangents
+        if c_pos is None:
+            raise RuntimeError("double backward through edge vectors needs a position cotangent")
+        cell = c_cell if (ctx.has_cell and c_cell is not None) else None
+        vec = _EdgeVectorsFn.apply(c_pos, cell, ctx.edge_index, ctx.shift if cell is not None else None, ctx.batch)
+        return vec, None, None, None, None, None
+
+
 def with_edge_vectors_(data: AtomicDataDict.Type, with_lengths: bool = True) -> AtomicDataDict.Type:
     """Edge displacement vectors ``pos[edge_index[1]] - pos[edge_index[0]] (+ shift @ cell)``, differentiable
-    w.r.t. positions and cell (``nequip/nn/utils.py:68-118``).  A [E,3] float64 tensor: index plumbing done
-    with ATen; everything per-edge and heavy downstream of it is in the HIP kernels."""
+    w.r.t. positions and cell (``nequip/nn/utils.py:68-118``).  On the GPU this is the HIP kernel pair
+    ``nqa_edge_vectors_fwd/bwd`` (atomics-free adjoint); CPU tensors take the reference's ATen formulation
+    (host-side data preparation and tests only -- the modules downstream of it are GPU-only)."""
     K = AtomicDataDict
     if K.EDGE_VECTORS_KEY in data:
         if with_lengths and K.EDGE_LENGTH_KEY not in data:
@@ -43,6 +118,15 @@ def with_edge_vectors_(data: AtomicDataDict.Type, with_lengths: bool = True) -> 
         return data
     pos = data[K.POSITIONS_KEY]
     edge_index = data[K.EDGE_INDEX_KEY]
+    if pos.is_cuda:
+        cell = data.get(K.CELL_KEY)
+        shift = data[K.EDGE_CELL_SHIFT_KEY].contiguous() if cell is not None else None
+        batch = data[K.BATCH_KEY].contiguous() if (cell is not None and K.BATCH_KEY in data) else None
+        edge_vec = _EdgeVectorsFn.apply(pos, cell, edge_index, shift, batch)
+        data[K.EDGE_VECTORS_KEY] = edge_vec
+        if with_lengths:
+            data[K.EDGE_LENGTH_KEY] = edge_vec.square().sum(1, keepdim=True).sqrt()
+        return data
     edge_vec = torch.index_select(pos, 0, edge_index[1]) - torch.index_select(pos, 0, edge_index[0])
     if K.CELL_KEY in data:
         cell = data[K.CELL_KEY]
