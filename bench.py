@@ -263,6 +263,7 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: v["total_ms"] / max(args.kernel_steps, 1) for k, v in kernels.items()},
             "kernels_gbps": {k: v["gbps"] for k, v in kernels.items()},
+            "kernels_tflops": {k: v["tflops"] for k, v in kernels.items() if v.get("tflops", 0) > 0},
         }
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload)

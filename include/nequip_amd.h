@@ -188,6 +188,27 @@ int nqa_edge_embed_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int6
                        const double* bessel_weights, double cutoff_p, double factor, const void* g_sh,
                        const void* g_emb, double* g_edge_vec, nqa_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Radial network on MFMA: replaces ScalarMLPFunction.forward as InteractionBlock.edge_mlp
+ *   (nequip/nn/interaction_block.py:119-127,196; nequip/nn/mlp.py:141-156,194-196,262-268) for the
+ *   standard one-hidden-layer, bias-free, SiLU radial MLP:
+ *     edge_weight[E, W] = silu(edge_embedding[E, nb] @ (w0[nb, H] * alpha0)) @ (w1[H, W] * alpha1)
+ *   computed in exact float32 on v_mfma_f32_32x32x2_f32; the hidden layer never leaves the chip.
+ * nqa_radial_mlp_bwd is its vector-Jacobian product w.r.t. the edge embedding (inference forces:
+ *   nequip/nn/grad_output.py:217-221); pre-activations are recomputed, not stored.  Parameter gradients
+ *   (training) are not produced by these entry points -- the host side keeps the reference's mm/SiLU
+ *   formulation in training mode.
+ * nqa_radial_mlp_supported returns 1 when (dtype, nb, H, W) can run on the fused kernels
+ *   (float32, nb <= 8, H in {64, 128}, W % 4 == 0).
+ * ------------------------------------------------------------------------------------------- */
+int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, int32_t out_features);
+int nqa_radial_mlp_fwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
+                       double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features, int64_t num_edges,
+                       void* edge_weight, nqa_stream stream);
+int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
+                       double alpha1, const void* grad_edge_weight, int32_t num_basis, int32_t hidden,
+                       int32_t out_features, int64_t num_edges, void* grad_edge_embedding, nqa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,9 +9,52 @@ from typing import Optional
 
 import torch
 
+from .. import _lib
 from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
+from ..utils import ktimer
 from ._graph_mixin import GraphModuleMixin
+
+
+class _RadialMLPFn(torch.autograd.Function):
+    """Fused two-layer radial MLP on fp32 MFMA (``nqa_radial_mlp_fwd/bwd``); inference path: differentiable w.r.t.
+    the edge embedding only (that is what the force backward needs)."""
+
+    @staticmethod
+    def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float):
+        from ._topology import _ptr, current_stream_ptr
+
+        lib = _lib.load()
+        emb = emb.contiguous()
+        E, nb = emb.shape
+        H, W = w1.shape
+        out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
+        flops = 2.0 * E * (nb * H + H * W)
+        with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):
+            rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
+                                        _ptr(out), current_stream_ptr(emb.device))
+        _lib.check(rc, "nqa_radial_mlp_fwd")
+        ctx.save_for_backward(emb, w0, w1)
+        ctx.alphas = (alpha0, alpha1)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w):
+        from ._topology import _ptr, current_stream_ptr
+
+        emb, w0, w1 = ctx.saved_tensors
+        lib = _lib.load()
+        g_w = g_w.contiguous()
+        E, nb = emb.shape
+        H, W = w1.shape
+        g_emb = torch.empty_like(emb)
+        flops = 2.0 * E * (nb * H * 2 + H * W)
+        with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
+            rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, _ptr(emb), _ptr(w0), ctx.alphas[0], _ptr(w1), ctx.alphas[1],
+                                        _ptr(g_w), nb, H, W, E, _ptr(g_emb), current_stream_ptr(emb.device))
+        _lib.check(rc, "nqa_radial_mlp_bwd")
+        return g_emb, None, None, None, None
 
 
 class ScalarLinearLayer(torch.nn.Module):
@@ -58,7 +101,22 @@ class ScalarMLPFunction(torch.nn.Module):
                 self.is_nonlinear = True
         self.mlp = mlp
 
+    def _fused_ok(self, x: torch.Tensor) -> bool:
+        if self.training or not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear:
+            return False
+        ok = getattr(self, "_fused_supported", None)
+        if ok is None:
+            lib = _lib.load()
+            ok = bool(lib.nqa_radial_mlp_supported(_lib.NQA_F32, self.dims[0], self.dims[1], self.dims[2]))
+            self._fused_supported = ok
+            self._alphas = (float(self.mlp[0].alpha), float(self.mlp[2].alpha))
+        return ok
+
     def forward(self, x):
+        # inference on the GPU: one fused MFMA kernel (hidden layer stays on chip); training keeps the
+        # mm/SiLU formulation so that parameter gradients and double backward come from autograd
+        if self._fused_ok(x):
+            return _RadialMLPFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0], self._alphas[1])
         return self.mlp(x)
 
 

@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 import torch
 
 enabled = False
-_records: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event, float]]] = defaultdict(list)
+_records: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event, float, float]]] = defaultdict(list)
 
 
 def enable(flag: bool = True) -> None:
@@ -27,7 +27,7 @@ def reset() -> None:
 
 
 @contextlib.contextmanager
-def region(name: str, algorithmic_bytes: float = 0.0):
+def region(name: str, algorithmic_bytes: float = 0.0, algorithmic_flops: float = 0.0):
     if not enabled:
         yield
         return
@@ -38,15 +38,16 @@ def region(name: str, algorithmic_bytes: float = 0.0):
         yield
     finally:
         stop.record()
-        _records[name].append((start, stop, float(algorithmic_bytes)))
+        _records[name].append((start, stop, float(algorithmic_bytes), float(algorithmic_flops)))
 
 
 def summary() -> Dict[str, dict]:
     """name -> {calls, total_ms, avg_ms, bytes_per_call, gbps}; call after torch.cuda.synchronize()."""
     out = {}
     for name, recs in _records.items():
-        ms = [a.elapsed_time(b) for a, b, _ in recs]
-        nbytes = [c for _, _, c in recs]
+        ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+        nbytes = [c for _, _, c, _ in recs]
+        nflops = [f for _, _, _, f in recs]
         total = sum(ms)
         out[name] = {
             "calls": len(recs),
@@ -54,5 +55,7 @@ def summary() -> Dict[str, dict]:
             "avg_ms": total / max(len(recs), 1),
             "bytes_per_call": sum(nbytes) / max(len(recs), 1),
             "gbps": (sum(nbytes) / 1e9) / (total / 1e3) if total > 0 else 0.0,
+            "flops_per_call": sum(nflops) / max(len(recs), 1),
+            "tflops": (sum(nflops) / 1e12) / (total / 1e3) if total > 0 else 0.0,
         }
     return out

@@ -11,5 +11,6 @@ print("value", round(d["value"]), "ms/step", round(d["ms_per_step"], 3), d["conf
 print("roofline", d["roofline"])
 print("kernels ms/step", {k: round(v, 3) for k, v in d["kernels_ms_per_step"].items()})
 print("kernels GB/s", {k: round(v) for k, v in d["kernels_gbps"].items()})
+print("kernels TFLOP/s", {k: round(v, 1) for k, v in d.get("kernels_tflops", {}).items()})
 PY
 grep -v Warn gpurun_out/bench.err | grep -v amdgpu.ids | tail -5

@@ -76,6 +76,21 @@ def test_energy_forces_water_two_types(device):
 
 
 @pytest.mark.gpu
+def test_energy_forces_fused_radial_mlp_width(device):
+    """radial_mlp_width 64/128 runs the fused MFMA radial kernel in eval mode; 64 features -> 64-lane chunks."""
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=5)
+    data = syn.make_data(pos, types, 4.5, cell)
+    for width, nf in ((64, 32), (128, 64)):
+        cfg = _cfg(num_features=nf, radial_mlp_width=width, avg_num_neighbors=38.0)
+        out, ref = _run_both(cfg, data, names, device)
+        fscale = float(ref["forces"].abs().max())
+        torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=5e-5 * len(pos), rtol=5e-5)
+        torch.testing.assert_close(ref["forces"], out["forces"].cpu(), atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+
+
+@pytest.mark.gpu
 def test_batched_molecules_no_cell(device):
     """cfg-1 shape: batch of 5 non-periodic 21-atom frames (configs/tutorial.yaml:74), l_max=1, parity=True."""
     from nequip_amd.data import AtomicDataDict
