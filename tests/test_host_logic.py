@@ -1,0 +1,152 @@
+"""CPU tests (no GPU): host-side irreps bookkeeping, instruction building, native plan creation and the C ABI."""
+
+import os
+import re
+
+import pytest
+import torch
+
+from nequip_amd.o3 import Irrep, Irreps
+from oracle import irreps as oir
+from oracle import tp as otp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_irreps_parse_sort_simplify():
+    ir = Irreps("8x0e + 8x2e + 8x1o")
+    assert ir.dim == 8 + 40 + 24 and ir.num_irreps == 24 and ir.lmax == 2
+    s, p, inv = ir.sort()
+    assert str(s) == "8x0e+8x1o+8x2e" and p == (0, 2, 1) and inv == (0, 2, 1)
+    mid = Irreps("64x0e+64x0e+64x1o+64x1o+64x2e")
+    assert str(mid.simplify()) == "128x0e+128x1o+64x2e"
+    # tuple order (l, p): odd before even at equal l (e3nn convention)
+    assert str(Irreps("1x1e+1x1o+1x0e+1x0o").sort().irreps) == "1x0o+1x0e+1x1o+1x1e"
+    assert list(Irrep("1o") * Irrep("2e")) == [Irrep("1o"), Irrep("2o"), Irrep("3o")]
+    assert str(Irreps.spherical_harmonics(3)) == "1x0e+1x1o+1x2e+1x3o"
+    assert Irrep("2e") in Irreps("3x2e") and Irrep("2o") not in Irreps("3x2e")
+    assert Irreps("4x0e + 3x1o").randn(5, -1).shape == (5, 13)
+
+
+@pytest.mark.parametrize("f_in,lmax,f_out", [
+    ("64x0e", 2, "64x0e+64x1o+64x2e"),
+    ("64x0e+64x1o+64x2e", 2, "192x0e+64x1o+64x2e"),
+    ("64x0e+64x1o+64x2e", 2, "64x0e"),
+    ("32x0e+32x0o+32x1e+32x1o", 1, "32x0e"),
+    ("128x0e+128x1o+128x2e+128x3o", 3, "512x0e+128x1o+128x2e+128x3o"),
+])
+def test_instruction_building_matches_oracle_and_survey(f_in, lmax, f_out):
+    """InteractionBlock-style instruction list (nequip/nn/interaction_block.py:89-109) built by the product module
+    and, independently, by the oracle; path counts / W / D_mid against SURVEY.md Appendix B."""
+    from nequip_amd.csrc.gen_spec import nequip_structure
+
+    st = nequip_structure(f_in, lmax, f_out, "t")
+    mid, instr = otp.build_instructions(f_in, oir.to_str(oir.spherical_harmonics(lmax)), f_out)
+    assert [(a, b, c) for a, b, c, *_ in instr] == st.instr
+    assert [l for _, l, _ in mid] == st.out_ls
+    expected = {  # (paths, W, D_mid) from SURVEY.md App. B
+        ("64x0e", 2): (3, 192, 576), ("64x0e+64x1o+64x2e", 2, "192x0e+64x1o+64x2e"): (11, 704, 2240),
+    }
+    key = (f_in, lmax, f_out) if (f_in, lmax, f_out) in expected else (f_in, lmax)
+    if key in expected:
+        paths, W, dmid = expected[key]
+        assert len(instr) == paths and otp.weight_numel(f_in, oir.to_str(oir.spherical_harmonics(lmax)), instr) == W
+        assert oir.dim(mid) == dmid
+
+
+def test_capi_exports_every_declared_symbol():
+    """libnequip_amd.so loads (no GPU needed) and exports every function include/nequip_amd.h declares."""
+    import ctypes
+
+    from nequip_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "nequip_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(nqa_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in nequip_amd.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert lib.nqa_abi_version() == 1 and lib.nqa_lmax() >= 3 and lib.nqa_sh_lmax() >= 3
+
+
+def test_native_plan_matches_host_bookkeeping():
+    from nequip_amd import _lib
+    from nequip_amd.nn import TensorProductScatter
+
+    f_in, e_at = Irreps("64x0e+64x1o+64x2e"), Irreps.spherical_harmonics(2)
+    mid, instr = otp.build_instructions(str(f_in), str(e_at), "192x0e+64x1o+64x2e")
+    tps = TensorProductScatter(f_in, e_at, Irreps(oir.to_str(mid)), instr)
+    plan = tps._plan
+    assert plan.query(_lib.NQA_PLAN_DIM_IN1) == 576 and plan.query(_lib.NQA_PLAN_DIM_IN2) == 9
+    assert plan.query(_lib.NQA_PLAN_DIM_OUT) == 2240 and plan.query(_lib.NQA_PLAN_WEIGHT_NUMEL) == 704
+    assert tps.tp.weight_numel == 704 and plan.query(_lib.NQA_PLAN_NUM_INSTR) == 11
+    assert plan.query(_lib.NQA_PLAN_HAS_SPECIALIZED) == 1, "BASELINE mid-layer structure must have prebuilt kernels"
+    assert plan.query(_lib.NQA_PLAN_OUT_NEEDS_ZERO) == 0
+    # no persistent state: the module adds nothing to the state dict (reference contract)
+    assert list(tps.state_dict().keys()) == []
+    # irregular irreps fall back to the generic kernels
+    mid2, instr2 = otp.build_instructions("4x0e + 3x1o + 2x2e", "0e + 1o", "0e + 1o + 2e")
+    tps2 = TensorProductScatter(Irreps("4x0e + 3x1o + 2x2e"), Irreps("0e + 1o"), Irreps(oir.to_str(mid2)), instr2)
+    assert tps2._plan.query(_lib.NQA_PLAN_HAS_SPECIALIZED) == 0
+
+
+def test_native_plan_rejects_invalid_instructions():
+    from nequip_amd.nn import TensorProductScatter
+
+    with pytest.raises(RuntimeError, match="parity"):
+        TensorProductScatter(Irreps("2x1o"), Irreps("1x1o"), Irreps("2x1o"), [(0, 0, 0, "uvu", True)])
+    with pytest.raises(RuntimeError, match="triangle"):
+        TensorProductScatter(Irreps("2x0e"), Irreps("1x1o"), Irreps("2x2e"), [(0, 0, 0, "uvu", True)])
+    with pytest.raises(RuntimeError, match="l_max|l=|supported"):
+        TensorProductScatter(Irreps("2x5o"), Irreps("1x0e"), Irreps("2x5o"), [(0, 0, 0, "uvu", True)])
+    with pytest.raises(ValueError):
+        TensorProductScatter(Irreps("2x0e"), Irreps("1x0e"), Irreps("3x0e"), [(0, 0, 0, "uvu", True)])
+
+
+def test_gpu_only_modules_fail_loudly_on_cpu():
+    """No CPU fallback: the kernel-backed modules raise on CPU tensors."""
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.silicon_box(reps=1, seed=0)
+    data = syn.make_data(pos, types, 4.5, cell)
+    model = NequIPGNNModel(r_max=4.5, type_names=names, num_layers=2, l_max=1, num_features=4, radial_mlp_width=8,
+                           avg_num_neighbors=10.0)
+    with pytest.raises(RuntimeError, match="GPU only|no CPU fallback"):
+        model(data)
+
+
+def test_model_parameter_names_and_count():
+    """Parameter names follow the reference (nequip/model/param_groups.py:62-71); cfg-2/3/4 model has ~1.85 M."""
+    from nequip_amd.model import NequIPGNNModel
+
+    m = NequIPGNNModel(r_max=4.5, type_names=["H", "O"], num_layers=3, l_max=2, parity=False, num_features=64,
+                       radial_mlp_depth=1, radial_mlp_width=128, avg_num_neighbors=38.0)
+    names = dict(m.named_parameters())
+    for k in ("layer1_convnet.conv.linear_1.weight", "layer1_convnet.conv.linear_2.weight",
+              "layer1_convnet.conv.sc.weight", "layer1_convnet.conv.edge_mlp.mlp.0.weight",
+              "layer1_convnet.conv.edge_mlp.mlp.2.weight", "type_embed.embed_module.weight",
+              "per_atom_energy_readout.mlp_module.mlp.0.weight"):
+        assert "model.func." + k in names
+    assert "model.func.layer0_convnet.conv.sc.weight" not in names  # no self-connection in the first layer
+    assert sum(p.numel() for p in m.parameters()) == 1_846_464
+    assert names["model.func.layer1_convnet.conv.sc.weight"].numel() == 64 * 64 * 192 + 2 * 64 * 64 * 64
+    assert m.nequip_custom_ops_libs == ("nequip_amd",)
+
+
+def test_neighbor_list_known_answer():
+    """2-atom Si primitive cell, r = 2.5 -> 8 edges (reference tests/unit/data/test_neighborlist.py:88-100)."""
+    import numpy as np
+
+    from nequip_amd.utils import synthetic as syn
+
+    a = 5.43
+    cell = np.array([[0, a / 2, a / 2], [a / 2, 0, a / 2], [a / 2, a / 2, 0]])
+    pos = np.array([[0, 0, 0], [a / 4, a / 4, a / 4]])
+    ei, S = syn.neighbor_list(pos, 2.5, cell)
+    assert ei.shape == (2, 8) and (ei[0] == [0, 0, 0, 0, 1, 1, 1, 1]).all() and (ei[1, :4] == 1).all()
+    vec = pos[ei[1]] - pos[ei[0]] + S @ cell
+    assert np.allclose(np.linalg.norm(vec, axis=1), a * np.sqrt(3) / 4)
