@@ -150,3 +150,21 @@ def test_neighbor_list_known_answer():
     assert ei.shape == (2, 8) and (ei[0] == [0, 0, 0, 0, 1, 1, 1, 1]).all() and (ei[1, :4] == 1).all()
     vec = pos[ei[1]] - pos[ei[0]] + S @ cell
     assert np.allclose(np.linalg.norm(vec, axis=1), a * np.sqrt(3) / 4)
+
+
+def test_modifier_registration_on_stand_in_class():
+    """enable_NequipAMD attaches to a TensorProductScatter-like class the way the reference's enable_* modifiers
+    do (decorated classmethod carrying the `_nequip_model_modifier_is_persistent` marker)."""
+    from nequip_amd.integrations import nequip_extension as ext
+    from nequip_amd.nn.model_modifier_utils import is_model_modifier
+
+    class FakeTPS(torch.nn.Module):
+        pass
+
+    ext.register(FakeTPS)
+    fn = getattr(FakeTPS, ext.MODIFIER_NAME)
+    assert is_model_modifier(fn) and fn._nequip_model_modifier_is_persistent is False
+    assert fn._nequip_model_modifier_unsupported_devices == ["cpu"]
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            fn(torch.nn.Sequential(FakeTPS()))
