@@ -205,9 +205,35 @@ int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, i
 int nqa_radial_mlp_fwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
                        double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features, int64_t num_edges,
                        void* edge_weight, nqa_stream stream);
+int64_t nqa_radial_mlp_bwd_workspace_bytes(int32_t hidden, int32_t out_features);
 int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
                        double alpha1, const void* grad_edge_weight, int32_t num_basis, int32_t hidden,
-                       int32_t out_features, int64_t num_edges, void* grad_edge_embedding, nqa_stream stream);
+                       int32_t out_features, int64_t num_edges, void* grad_edge_embedding, void* workspace,
+                       int64_t workspace_bytes, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Node-side channel mixing in one launch: replaces e3nn o3.Linear (linear_1 / linear_2,
+ *   nequip/nn/interaction_block.py:82-87,129-138,177,201), the self-connection
+ *   FullyConnectedTensorProduct with scalar node attributes (interaction_block.py:142-146,175; weights
+ *   pre-contracted per atom type by the caller) and the residual add `x + sc` (:203-204):
+ *     out[z, ob, w, m] = scale * sum_{(ib->ob)} sum_u x[z, ib, u, m] * W[type(z)][ib->ob][u, w]  (+ addend[z,...])
+ *   mul_ir layout.  chunk_table: int32 records {o_off, d, mul_out, c0, instr_begin, instr_end, 0, 0} (one per
+ *   64-channel chunk of an output irrep block, every output element covered exactly once); instr_table: int32
+ *   records {x_off, mul_in, w_off, 0} ([mul_in, mul_out] row-major matrix at weights + type*weight_stride + w_off).
+ *   atom_types (int64 [N]) is required iff n_types > 1.  The backward w.r.t. x is the same call with transposed
+ *   tables/weights.  All tables are device pointers.
+ * nqa_gate: e3nn Gate (nequip/nn/convnetlayer.py:104-112,162-164): in = scalars (+) gates (+) gated ->
+ *   out = act(scalars) (+) act(gates)[u] * gated[u, :]; seg_table: {begin, end, act, pad, double cst} per scalar/gate
+ *   segment (act 0 = identity, 1 = silu, 2 = tanh; cst = e3nn normalize2mom constant); blk_table: int32
+ *   {in_off, out_off, mul, d, gate_off, 0, 0, 0} per gated block.  backward != 0 computes grad_in from grad_out.
+ * ------------------------------------------------------------------------------------------- */
+int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
+                    const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
+                    int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
+                    double scale, nqa_stream stream);
+int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
+             const void* seg_table, int32_t n_segs, const void* blk_table, int32_t n_blks, int32_t num_scalars,
+             int32_t num_gates, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
 #ifdef __cplusplus
 }

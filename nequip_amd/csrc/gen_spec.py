@@ -165,7 +165,8 @@ def _emit(st: Structure) -> str:
     A("  const int mul = a.mul;")
     A("  const int nchunk = (mul + 63) >> 6;")
     A("  int64_t item; int wsub;")
-    A("  if (WPN == 1) { item = (int64_t)blockIdx.x * 4 + wid; wsub = 0; } else { item = blockIdx.x; wsub = wid; }")
+    A("  const unsigned bid = spec_xcd_remap(blockIdx.x, gridDim.x);")
+    A("  if (WPN == 1) { item = (int64_t)bid * 4 + wid; wsub = 0; } else { item = bid; wsub = wid; }")
     A("  const bool valid = item < (int64_t)a.N * nchunk;")
     A("  if (WPN == 1 && !valid) return;")
     A("  const int node = valid ? (int)(item / nchunk) : 0;")
@@ -236,7 +237,7 @@ def _emit(st: Structure) -> str:
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
     A("  const int mul = a.mul;")
     A("  const int nchunk = (mul + 63) >> 6;")
-    A("  const int64_t witem = (int64_t)blockIdx.x * 4 + wid;")
+    A("  const int64_t witem = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
     A("  const int64_t item = witem / WPN;")
     A("  const int wsub = (int)(witem - item * WPN);")
     A("  if (item >= (int64_t)a.N * nchunk) return;")
@@ -305,7 +306,8 @@ def _emit(st: Structure) -> str:
     A("  const int mul = a.mul;")
     A("  const int nchunk = (mul + 63) >> 6;")
     A("  int64_t item; int wsub;")
-    A("  if (WPN == 1) { item = (int64_t)blockIdx.x * 4 + wid; wsub = 0; } else { item = blockIdx.x; wsub = wid; }")
+    A("  const unsigned bid = spec_xcd_remap(blockIdx.x, gridDim.x);")
+    A("  if (WPN == 1) { item = (int64_t)bid * 4 + wid; wsub = 0; } else { item = bid; wsub = wid; }")
     A("  const bool valid = item < (int64_t)a.N * nchunk;")
     A("  if (WPN == 1 && !valid) return;")
     A("  const int node = valid ? (int)(item / nchunk) : 0;")

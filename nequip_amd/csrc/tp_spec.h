@@ -53,6 +53,16 @@ struct SpecRegistrar {
   }
 };
 
+// Workgroup b is dispatched to XCD b % 8 (observed placement, used for speed only): hand each XCD a contiguous
+// range of work items so that the node rows gathered by neighbouring atoms (x[src], grad_out[dst]) are re-used out
+// of that XCD's private 4 MiB L2 instead of being fetched by all eight.  Bijective for any grid size.
+__device__ __forceinline__ unsigned spec_xcd_remap(unsigned b, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned xcd = b & 7u, idx = b >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
 // ---- wave64 reductions -------------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wavefront with DPP row operations (no LDS traffic):
 //   quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8  -> every lane holds its 16-lane row sum

@@ -84,6 +84,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         if not self.is_first_layer:
             x = x[:num_local_nodes]
 
+        sc = None
         if self.sc is not None:
             node_attrs = data[AtomicDataDict.NODE_ATTRS_KEY]
             if not self.is_first_layer:
@@ -108,8 +109,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             edge_src=data[AtomicDataDict.EDGE_INDEX_KEY][1],
         )[:num_local_nodes]
 
-        x = self.linear_2(x)
-        if self.sc is not None:
-            x = x + sc
+        # linear_2 with the residual `+ sc` fused into the same launch
+        x = self.linear_2(x, addend=sc if self.sc is not None else None)
         data[AtomicDataDict.NODE_FEATURES_KEY] = x
         return data

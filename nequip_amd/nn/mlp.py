@@ -50,9 +50,12 @@ class _RadialMLPFn(torch.autograd.Function):
         H, W = w1.shape
         g_emb = torch.empty_like(emb)
         flops = 2.0 * E * (nb * H * 2 + H * W)
+        ws_bytes = lib.nqa_radial_mlp_bwd_workspace_bytes(H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
         with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
             rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, _ptr(emb), _ptr(w0), ctx.alphas[0], _ptr(w1), ctx.alphas[1],
-                                        _ptr(g_w), nb, H, W, E, _ptr(g_emb), current_stream_ptr(emb.device))
+                                        _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes,
+                                        current_stream_ptr(emb.device))
         _lib.check(rc, "nqa_radial_mlp_bwd")
         return g_emb, None, None, None, None
 

@@ -1,0 +1,245 @@
+"""Host side of the fused node kernels (``nqa_node_linear`` / ``nqa_gate``, ``nequip_amd/csrc/node_ops.hip``).
+
+Builds the chunk / instruction tables from irreps bookkeeping and wraps the launches in autograd Functions:
+
+* ``node_linear(x, Wp, types, meta, addend)``: every per-irrep channel-mixing matrix of an e3nn ``o3.Linear`` (or of
+  the type-pre-contracted self-connection) in ONE launch; the gradient w.r.t. ``x`` is the same kernel run on
+  transposed tables; the gradient w.r.t. the packed weights (training only) is formed with a few small einsums.
+* ``gate(x, meta)``: e3nn ``Gate`` forward / backward in one launch each.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import struct
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib
+from ..utils import ktimer
+from .irreps import Irreps
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dt(dtype):
+    if dtype == torch.float32:
+        return _lib.NQA_F32
+    if dtype == torch.float64:
+        return _lib.NQA_F64
+    raise RuntimeError(f"node kernels support float32/float64, got {dtype}")
+
+
+class NodeLinearMeta:
+    """Tables for ``out = sum_{(i -> o)} x_i @ W_(i,o)`` over irreps blocks, forward and transposed (backward)."""
+
+    def __init__(self, irreps_in: Irreps, irreps_out: Irreps, instructions: Sequence[Tuple[int, int]]):
+        self.irreps_in, self.irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+        self.instructions = [(int(i), int(o)) for i, o in instructions]
+        self.din, self.dout = self.irreps_in.dim, self.irreps_out.dim
+        in_off, out_off = self.irreps_in.offsets(), self.irreps_out.offsets()
+        # forward weights: instruction order, each [mul_in, mul_out] row-major
+        self.w_off, off = [], 0
+        for i, o in self.instructions:
+            self.w_off.append(off)
+            off += self.irreps_in[i].mul * self.irreps_out[o].mul
+        self.wstride = off
+        # transposed weights: same instruction order, each [mul_out, mul_in]
+        self.fwd = self._tables(self.irreps_out, out_off, in_off, self.irreps_in, by_out=True)
+        self.bwd = self._tables(self.irreps_in, in_off, out_off, self.irreps_out, by_out=False)
+        self._dev = {}
+
+    def _tables(self, side_out: Irreps, off_out, off_in, side_in: Irreps, by_out: bool):
+        chunks: List[Tuple[int, ...]] = []
+        instr: List[Tuple[int, ...]] = []
+        for b, (mul_o, ir) in enumerate(side_out):
+            if mul_o == 0:
+                continue
+            begin = len(instr)
+            for k, (i, o) in enumerate(self.instructions):
+                tgt, srcb = (o, i) if by_out else (i, o)
+                if tgt == b:
+                    instr.append((off_in[srcb], side_in[srcb].mul, self.w_off[k], 0))
+            end = len(instr)
+            for c0 in range(0, mul_o, 64):
+                chunks.append((off_out[b], ir.dim, mul_o, c0, begin, end, 0, 0))
+        return chunks, instr
+
+    def device_tables(self, device, which: str):
+        key = (str(device), which)
+        if key not in self._dev:
+            chunks, instr = self.fwd if which == "fwd" else self.bwd
+            ct = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 8).to(device)
+            it = torch.tensor(instr if instr else [(0, 0, 0, 0)], dtype=torch.int32).reshape(-1, 4).to(device)
+            self._dev[key] = (ct, len(chunks), it)
+        return self._dev[key]
+
+    def transpose_weights(self, wp: torch.Tensor) -> torch.Tensor:
+        """[T, wstride] packed forward weights -> packed transposed weights with the same offsets."""
+        T = wp.shape[0]
+        parts = []
+        for (i, o), off in zip(self.instructions, self.w_off):
+            mi, mo = self.irreps_in[i].mul, self.irreps_out[o].mul
+            parts.append(wp[:, off : off + mi * mo].view(T, mi, mo).transpose(1, 2).reshape(T, mi * mo))
+        return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+
+
+def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale: float):
+    lib = _lib.load()
+    ct, nchunks, it = meta.device_tables(x.device, which)
+    din, dout = (meta.din, meta.dout) if which == "fwd" else (meta.dout, meta.din)
+    N = x.shape[0]
+    out = torch.empty((N, dout), dtype=x.dtype, device=x.device)
+    flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
+    with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
+        rc = lib.nqa_node_linear(
+            _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types), _ptr(ct), nchunks, _ptr(it),
+            wp.shape[0], wp.shape[1], din, dout, N, float(scale), _stream(x.device),
+        )  # fmt: skip
+    _lib.check(rc, "nqa_node_linear")
+    return out
+
+
+class _NodeLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wp, addend, types, meta: NodeLinearMeta, scale: float):
+        x = x.contiguous()
+        wp = wp.contiguous()
+        if addend is not None:
+            addend = addend.contiguous()
+        out = _launch_linear(x, wp, addend, types, meta, "fwd", scale)
+        ctx.save_for_backward(x, wp, types)
+        ctx.meta, ctx.scale, ctx.has_addend = meta, scale, addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wp, types = ctx.saved_tensors
+        meta: NodeLinearMeta = ctx.meta
+        gx = gwp = gadd = None
+        if ctx.needs_input_grad[0]:
+            gx = _NodeLinearFn.apply(g, meta_transposed_weights(meta, wp), None, types, _transposed(meta), ctx.scale)
+        if ctx.needs_input_grad[1]:
+            gwp = _weight_grad(x, g, types, meta, wp.shape[0]) * ctx.scale
+        if ctx.has_addend and ctx.needs_input_grad[2]:
+            gadd = g
+        return gx, gwp, gadd, None, None, None
+
+
+_TRANSPOSED_CACHE = {}
+
+
+def _transposed(meta: NodeLinearMeta) -> NodeLinearMeta:
+    """The adjoint map as a NodeLinearMeta of its own (so that double backward closes on the same kernel)."""
+    key = id(meta)
+    if key not in _TRANSPOSED_CACHE:
+        mt = NodeLinearMeta(meta.irreps_out, meta.irreps_in, [(o, i) for i, o in meta.instructions])
+        mt._adjoint_of = meta
+        _TRANSPOSED_CACHE[key] = mt
+    return _TRANSPOSED_CACHE[key]
+
+
+def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Tensor:
+    return meta.transpose_weights(wp)
+
+
+def _weight_grad(x, g, types, meta: NodeLinearMeta, T: int):
+    """d/dWp of sum(out * g): per instruction  gW[t, u, w] = sum_{z: type z = t} sum_m x[z,u,m] g[z,w,m]."""
+    Z = x.shape[0]
+    in_off, out_off = meta.irreps_in.offsets(), meta.irreps_out.offsets()
+    parts = []
+    onehot = None
+    if T > 1:
+        onehot = torch.nn.functional.one_hot(types.view(-1), T).to(x.dtype)
+    for i, o in meta.instructions:
+        mi, ir = meta.irreps_in[i]
+        mo = meta.irreps_out[o].mul
+        d = ir.dim
+        xb = x[:, in_off[i] : in_off[i] + mi * d].reshape(Z, mi, d)
+        gb = g[:, out_off[o] : out_off[o] + mo * d].reshape(Z, mo, d)
+        if T == 1:
+            parts.append(torch.einsum("zum,zwm->uw", xb, gb).reshape(1, mi * mo))
+        else:
+            parts.append(torch.einsum("zt,zum,zwm->tuw", onehot, xb, gb).reshape(T, mi * mo))
+    return torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+
+
+def node_linear(x, wp, types, meta: NodeLinearMeta, addend=None, scale: float = 1.0):
+    return _NodeLinearFn.apply(x, wp, addend, types, meta, scale)
+
+
+# ---- Gate --------------------------------------------------------------------------------------------------------
+_ACT_IDS = {"identity": 0, "silu": 1, "tanh": 2}
+
+
+class GateMeta:
+    def __init__(self, irreps_scalars: Irreps, act_scalars: Sequence[Tuple[str, float]], irreps_gates: Irreps,
+                 act_gates: Sequence[Tuple[str, float]], irreps_gated: Irreps):
+        self.ns, self.ng = irreps_scalars.dim, irreps_gates.dim
+        self.din = self.ns + self.ng + irreps_gated.dim
+        self.dout = self.ns + irreps_gated.dim
+        segs = b""
+        off = 0
+        n = 0
+        for (mul, _), (name, cst) in list(zip(irreps_scalars, act_scalars)) + list(zip(irreps_gates, act_gates)):
+            segs += struct.pack("<iiiid", off, off + mul, _ACT_IDS[name], 0, float(cst))
+            off += mul
+            n += 1
+        self.n_segs = n
+        self._segs = segs
+        blks = []
+        in_off, out_off, goff = self.ns + self.ng, self.ns, 0
+        for mul, ir in irreps_gated:
+            blks.append((in_off, out_off, mul, ir.dim, goff, 0, 0, 0))
+            in_off += mul * ir.dim
+            out_off += mul * ir.dim
+            goff += mul
+        self.n_blks = len(blks)
+        self._blks = blks
+        self._dev = {}
+
+    def device_tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            st = torch.frombuffer(bytearray(self._segs if self._segs else b"\0" * 24), dtype=torch.uint8).clone().to(device)
+            bt = torch.tensor(self._blks if self._blks else [(0,) * 8], dtype=torch.int32).reshape(-1, 8).to(device)
+            self._dev[key] = (st, bt)
+        return self._dev[key]
+
+
+def _launch_gate(x, gout, meta: GateMeta, backward: bool):
+    lib = _lib.load()
+    st, bt = meta.device_tables(x.device)
+    N = x.shape[0]
+    out = torch.empty((N, meta.din if backward else meta.dout), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device), ktimer.region("gate", x.element_size() * N * (meta.din + meta.dout)):
+        rc = lib.nqa_gate(_dt(x.dtype), 1 if backward else 0, _ptr(x), _ptr(gout), _ptr(out), _ptr(st), meta.n_segs,
+                          _ptr(bt), meta.n_blks, meta.ns, meta.ng, meta.din, meta.dout, N, _stream(x.device))
+    _lib.check(rc, "nqa_gate")
+    return out
+
+
+class _GateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, meta: GateMeta):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.meta = meta
+        return _launch_gate(x, None, meta, False)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _launch_gate(x, g.contiguous(), ctx.meta, True), None
+
+
+def gate(x, meta: GateMeta, differentiable_twice: bool = False):
+    return _GateFn.apply(x, meta)

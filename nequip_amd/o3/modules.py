@@ -17,6 +17,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from .irreps import Irrep, Irreps
+from ._node_kernels import GateMeta, NodeLinearMeta, gate as _gate_kernel, node_linear as _node_linear
 
 
 class Linear(torch.nn.Module):
@@ -40,6 +41,7 @@ class Linear(torch.nn.Module):
         self.weight_numel = sum(self.irreps_in[i].mul * self.irreps_out[o].mul for i, o in self.instructions)
         self.weight = torch.nn.Parameter(torch.randn(self.weight_numel))
         self._in_slices = self.irreps_in.slices()
+        self._in_sizes = [mul_ir.dim for mul_ir in self.irreps_in]
         # e3nn-compatible view of where each 2-D weight sits in the flat parameter (cf. nequip/model/param_groups.py:71-88)
         self.weight_index_slices = []
         off = 0
@@ -47,20 +49,38 @@ class Linear(torch.nn.Module):
             n = self.irreps_in[i].mul * self.irreps_out[o].mul
             self.weight_index_slices.append((slice(off, off + n), (self.irreps_in[i].mul, self.irreps_out[o].mul)))
             off += n
+        # fused HIP path: all per-irrep matrices in one launch (csrc/node_ops.hip)
+        self._meta = NodeLinearMeta(self.irreps_in, self.irreps_out, self.instructions)
+        scale_vec = torch.cat(
+            [torch.full((sl.stop - sl.start,), self._scale[o]) for (i, o), (sl, _) in zip(self.instructions, self.weight_index_slices)]
+        ) if self.instructions else torch.zeros(0)
+        self.register_buffer("_scale_vec", scale_vec, persistent=False)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, addend: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+        if x.is_cuda and x.dtype in (torch.float32, torch.float64) and self.weight_numel > 0:
+            # eval mode: parameter gradients are not produced (inference fast path, as for the radial MLP)
+            w = self.weight if self.training else self.weight.detach()
+            wp = (w * self._scale_vec).unsqueeze(0)
+            return _node_linear(x, wp, None, self._meta, addend=addend, scale=scale)
+        out = self._forward_reference(x)
+        if scale != 1.0:
+            out = out * scale
+        return out if addend is None else out + addend
+
+    def _forward_reference(self, x: torch.Tensor) -> torch.Tensor:
+        """ATen formulation (CPU tensors: host-side tests of the module algebra only)."""
         Z = x.shape[0]
         outs: List[Optional[torch.Tensor]] = [None] * len(self.irreps_out)
+        # torch.split (backward = one cat) instead of slicing (backward = zero-fill + copy + add per slice)
+        xs = torch.split(x, self._in_sizes, dim=1) if len(self._in_sizes) > 1 else (x,)
         for (i, o), (sl, shape) in zip(self.instructions, self.weight_index_slices):
             mul_in, ir = self.irreps_in[i]
             d = ir.dim
             W = self.weight[sl].view(shape) * self._scale[o]
-            xa = x[:, self._in_slices[i]]
             if d == 1:
-                r = torch.mm(xa, W)
+                r = torch.mm(xs[i], W)
             else:
-                # [Z, mul_in, d] -> [Z, d, mul_in] @ [mul_in, mul_out] -> [Z, mul_out, d]
-                r = torch.matmul(xa.reshape(Z, mul_in, d).transpose(1, 2), W).transpose(1, 2).reshape(Z, -1)
+                r = torch.einsum("zum,uw->zwm", xs[i].view(Z, mul_in, d), W).reshape(Z, -1)
             outs[o] = r if outs[o] is None else outs[o] + r
         cols = [
             outs[o] if outs[o] is not None else x.new_zeros(Z, mul_ir.dim) for o, mul_ir in enumerate(self.irreps_out)
@@ -109,6 +129,7 @@ class FullyConnectedTensorProduct(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.randn(self.weight_numel))
         self._s1 = self.irreps_in1.slices()
         self._s2 = self.irreps_in2.slices()
+        self._sizes1 = [mul_ir.dim for mul_ir in self.irreps_in1]
         self._wslices = []
         off = 0
         for i1, i2, io in self.instructions:
@@ -116,6 +137,11 @@ class FullyConnectedTensorProduct(torch.nn.Module):
             n = shape[0] * shape[1] * shape[2]
             self._wslices.append((slice(off, off + n), shape))
             off += n
+        self._meta = (
+            NodeLinearMeta(self.irreps_in1, self.irreps_out, [(i1, io) for i1, _, io in self.instructions])
+            if len(self.irreps_in2) == 1
+            else None
+        )
 
     def _assemble(self, outs, x):
         Z = x.shape[0]
@@ -140,19 +166,33 @@ class FullyConnectedTensorProduct(torch.nn.Module):
         return self._assemble(outs, x)
 
     def forward_typed(self, x: torch.Tensor, types: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and self._meta is not None and x.dtype in (torch.float32, torch.float64):
+            # per-type pre-contraction W_t[u, w] = sum_v table[t, v] W[u, v, w] (tiny), then ONE fused launch
+            parts = []
+            weight = self.weight if self.training else self.weight.detach()
+            table = table if self.training else table.detach()
+            for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+                Wt = torch.einsum("tv,uvw->tuw", table, weight[sl].view(shape)) * self._scale[io]
+                parts.append(Wt.reshape(table.shape[0], -1))
+            wp = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+            return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)
         Z = x.shape[0]
         T = table.shape[0]
         onehot = torch.nn.functional.one_hot(types.view(-1), T).to(x.dtype)  # [Z, T]
         outs: List[Optional[torch.Tensor]] = [None] * len(self.irreps_out)
+        xs = torch.split(x, self._sizes1, dim=1) if len(self._sizes1) > 1 else (x,)
         for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
             mul1, ir = self.irreps_in1[i1]
             d = ir.dim
             W = self.weight[sl].view(shape)
             tb = table[:, self._s2[i2]]  # [T, mul2]
             Wt = torch.einsum("tv,uvw->tuw", tb, W).reshape(T * mul1, shape[2]) * self._scale[io]
-            xa = x[:, self._s1[i1]].reshape(Z, mul1, d).transpose(1, 2)  # [Z, d, mul1]
-            xx = onehot.view(Z, 1, T, 1) * xa.unsqueeze(2)  # [Z, d, T, mul1]
-            r = torch.matmul(xx.reshape(Z, d, T * mul1), Wt).transpose(1, 2).reshape(Z, -1)
+            # one-hot expansion over the atom types: [Z, T*mul1, d], then one GEMM with K = T*mul1
+            xt = (onehot.view(Z, T, 1, 1) * xs[i1].view(Z, 1, mul1, d)).view(Z, T * mul1, d)
+            if d == 1:
+                r = torch.mm(xt.view(Z, T * mul1), Wt)
+            else:
+                r = torch.einsum("zkm,kw->zwm", xt, Wt).reshape(Z, -1)
             outs[io] = r if outs[io] is None else outs[io] + r
         return self._assemble(outs, x)
 
@@ -204,6 +244,14 @@ class Gate(torch.nn.Module):
                     raise ValueError("activation of an odd scalar must be even or odd")
             out_scalars.append((mul, (0, p_out)))
         self.irreps_out = Irreps(out_scalars) + self.irreps_gated
+        names = {torch.nn.functional.silu: "silu", torch.tanh: "tanh"}
+        self._kernel_meta = None
+        if all(a in names for a in self.act_scalars + self.act_gates):
+            self._kernel_meta = GateMeta(
+                self.irreps_scalars, [(names[a], c) for a, c in zip(self.act_scalars, self._cst_scalars)],
+                self.irreps_gates, [(names[a], c) for a, c in zip(self.act_gates, self._cst_gates)],
+                self.irreps_gated,
+            )
 
     @staticmethod
     def _activate(t, irreps, acts, csts):
@@ -218,18 +266,19 @@ class Gate(torch.nn.Module):
         return torch.cat(cols, dim=-1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and not self.training and self._kernel_meta is not None and x.dtype in (torch.float32, torch.float64):
+            # inference: one fused launch (first-order differentiable); training keeps the autograd formulation
+            return _gate_kernel(x, self._kernel_meta)
         ns, ng = self.irreps_scalars.dim, self.irreps_gates.dim
-        scalars = self._activate(x[:, :ns], self.irreps_scalars, self.act_scalars, self._cst_scalars)
         if ng == 0:
-            return scalars
-        gates = self._activate(x[:, ns : ns + ng], self.irreps_gates, self.act_gates, self._cst_gates)
-        gated = x[:, ns + ng :]
+            return self._activate(x, self.irreps_scalars, self.act_scalars, self._cst_scalars)
+        sizes = [ns, ng] + [mul_ir.dim for mul_ir in self.irreps_gated]
+        parts = torch.split(x, sizes, dim=1)
+        scalars = self._activate(parts[0], self.irreps_scalars, self.act_scalars, self._cst_scalars)
+        gates = self._activate(parts[1], self.irreps_gates, self.act_gates, self._cst_gates)
         Z = x.shape[0]
-        cols, goff, xoff = [scalars], 0, 0
-        for mul, ir in self.irreps_gated:
-            g = gates[:, goff : goff + mul]
-            goff += mul
-            blk = gated[:, xoff : xoff + mul * ir.dim].reshape(Z, mul, ir.dim)
-            xoff += mul * ir.dim
-            cols.append((blk * g.unsqueeze(-1)).reshape(Z, mul * ir.dim))
+        gsplit = torch.split(gates, [mul for mul, _ in self.irreps_gated], dim=1) if len(self.irreps_gated) > 1 else (gates,)
+        cols = [scalars]
+        for (mul, ir), g, blk in zip(self.irreps_gated, gsplit, parts[2:]):
+            cols.append((blk.view(Z, mul, ir.dim) * g.unsqueeze(-1)).view(Z, mul * ir.dim))
         return torch.cat(cols, dim=-1)
