@@ -42,6 +42,17 @@ __device__ __forceinline__ float silu_grad_f(float x) {
 // ------------------------------------------------------------------------------------------------------------
 // forward: out[E, W] = silu(emb[E, NB] @ W0s[NB, H]) @ W1s[H, W]
 // ------------------------------------------------------------------------------------------------------------
+// MFMA 32x32x2 f32 register maps (cdna guide): A: lane l holds A[i = l&31][k = l>>5]; B: B[k = l>>5][j = l&31];
+// D: 16 regs, D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+//
+// Everything is computed transposed, with j = edge:  step 1  hT[k][e] = sum_c W0s[c][k] emb[e][c]  (4 MFMAs per
+// 32 hidden rows) leaves lane (e, half) holding the hidden values k = 32*kb + (r&3) + 8*(r>>2) + 4*half -- exactly
+// one value per MFMA k-pair of step 2 if step s = 16*kb + r pairs the hidden indices {kmap(s), kmap(s) + 4}.  So the
+// SiLU-activated accumulators of step 1 ARE the B operands of step 2 (no shuffles, the hidden layer never leaves
+// the VGPRs), and  step 2  outT[n][e] = sum_k W1s[k][n] h[e][k]  leaves lane (e, half) holding 4 consecutive output
+// columns per register quad -> float4 stores.
+__device__ __forceinline__ constexpr int mlp_kmap(int s) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2); }
+
 template <int H>
 __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float* __restrict__ emb,
                                                              const float* __restrict__ W0,
@@ -58,17 +69,18 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float* __rest
   const int half = lane >> 5;
   const int l31 = lane & 31;
   const int64_t row0 = (int64_t)blockIdx.x * kMlpRows + wv * 32;
+  const int64_t myrow = row0 + l31;
+  const bool row_ok = myrow < E;
 
   for (int i = tid; i < H * kMaxNb; i += 256) {
     const int k = i / kMaxNb, c = i - k * kMaxNb;
-    w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;  // zero padding: the unrolled dot products run over kMaxNb
+    w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;  // zero padding: the k-pair loop runs over kMaxNb
   }
-  // first W1 chunk
   const int nchunks = (W + BN - 1) / BN;
   // global -> registers (issued early) and registers -> LDS (written late): the L2 latency of the next W1 chunk
   // hides under the MFMAs of the current one
   constexpr int NV = H * (BN / 4) / 256;  // float4 per thread per chunk
-  float4 pre[NV];
+  float4 pre4[NV];
   auto stage_load = [&](int n0) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -77,7 +89,7 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float* __rest
       const int n = n0 + q * 4;
       float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n + 3 < W) t4 = *reinterpret_cast<const float4*>(W1 + (int64_t)k * W + n);  // W % 4 == 0
-      pre[v] = t4;
+      pre4[v] = t4;
     }
   };
   auto stage_store = [&](int buf) {
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float* __rest
     for (int v = 0; v < NV; ++v) {
       const int i = tid + v * 256;
       const int k = i / (BN / 4), q = i - k * (BN / 4);
-      float4 t4 = pre[v];
+      float4 t4 = pre4[v];
       t4.x *= a1; t4.y *= a1; t4.z *= a1; t4.w *= a1;
       *reinterpret_cast<float4*>(&bs[buf][k * BN + q * 4]) = t4;
     }
@@ -94,78 +106,76 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float* __rest
   stage_store(0);
   __syncthreads();
 
-  // hidden activations of this lane's row as A fragments: a[t] = h[row][2t + half]
-  float a[KP];
+  // ---- step 1: hidden layer on MFMA, SiLU in registers -----------------------------------------------------
+  float hreg[KP];  // hreg[s] = h[myrow][mlp_kmap(s) + 4*half]
   {
-    const int64_t row = row0 + l31;
     float ev[kMaxNb];
 #pragma unroll
-    for (int c = 0; c < kMaxNb; ++c) ev[c] = (c < nb && row < E) ? emb[row * nb + c] : 0.f;
+    for (int c = 0; c < kMaxNb; ++c) ev[c] = (c < nb && row_ok) ? emb[myrow * nb + c] : 0.f;
 #pragma unroll
-    for (int t = 0; t < KP; ++t) {
-      const int k = 2 * t + half;
-      float pre = 0.f;
+    for (int kb = 0; kb < H / 32; ++kb) {
+      f32x16 hacc = {0};
 #pragma unroll
-      for (int c = 0; c < kMaxNb; ++c) pre += ev[c] * w0s[k * kMaxNb + c];
-      a[t] = (row < E) ? silu_f(pre) : 0.f;
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];  // A[i = hidden][c]
+        const float bv = half ? ev[2 * s2 + 1] : ev[2 * s2];               // B[c][j = edge]
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hreg[kb * 16 + r] = row_ok ? silu_f(hacc[r]) : 0.f;
     }
   }
 
+  // ---- step 2: out^T chunks -----------------------------------------------------------------------------------
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunks && !(dbg & 2)) stage_load((ch + 1) * BN);
-    const float* __restrict__ b = bs[buf] + half * BN + l31;
+    const float* __restrict__ b = bs[buf] + (4 * half) * BN + l31;
     f32x16 acc0 = {0}, acc1 = {0};
-    // B fragments are fetched from LDS one register batch (TB k-pairs) ahead of the MFMAs that consume them
+    // W1 fragments are fetched from LDS one register batch (TB k-pairs) ahead of the MFMAs that consume them
     constexpr int TB = 8;
     float bq[2][TB][2];
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
-      bq[0][i][0] = b[(2 * i) * BN];
-      bq[0][i][1] = b[(2 * i) * BN + 32];
+      bq[0][i][0] = b[mlp_kmap(i) * BN];
+      bq[0][i][1] = b[mlp_kmap(i) * BN + 32];
     }
 #pragma unroll
     for (int tb = 0; tb < KP / TB; ++tb) {
       if (tb + 1 < KP / TB) {
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
-          bq[(tb + 1) & 1][i][0] = b[(2 * ((tb + 1) * TB + i)) * BN];
-          bq[(tb + 1) & 1][i][1] = b[(2 * ((tb + 1) * TB + i)) * BN + 32];
+          bq[(tb + 1) & 1][i][0] = b[mlp_kmap((tb + 1) * TB + i) * BN];
+          bq[(tb + 1) & 1][i][1] = b[mlp_kmap((tb + 1) * TB + i) * BN + 32];
         }
       }
       // pin the order: the compiler otherwise sinks each LDS read next to its MFMA and waits lgkmcnt(0) per pair
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TB; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tb * TB + i], bq[tb & 1][i][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tb * TB + i], bq[tb & 1][i][1], acc1, 0, 0, 0);
+        // A[i = n][k] = W1s[k][n] (LDS), B[k][j = edge] = h (registers)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[tb & 1][i][0], hreg[tb * TB + i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[tb & 1][i][1], hreg[tb * TB + i], acc1, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // next chunk registers -> LDS first (its loads were issued before the MFMAs and have landed), then the output
-    // stores of this chunk, which nothing below waits for
+    // stores of this chunk, which nothing below waits for (lds_barrier does not drain vmcnt)
     if (ch + 1 < nchunks && !(dbg & 2)) stage_store(buf ^ 1);
     const int n0 = ch * BN;
     if (dbg & 1) {
-      if (acc0[0] == 12345.f && acc1[3] == 777.f) out[0] = 1.f;  // keep the MFMAs live, skip the stores
-    } else if (row0 + 32 <= E && n0 + BN <= W) {
-      // interior tile (wave-uniform test): 32 unpredicated stores, each writing two full 128 B row segments
-      float* __restrict__ o = out + (row0 + 4 * half) * W + n0 + l31;
+      if (acc0[0] == 12345.f && acc1[3] == 777.f) out[0] = 1.f;  // ablation: keep the MFMAs live, skip the stores
+    } else if (row_ok) {
+      // lane (edge, half) holds columns n0 + 32*tile + 8*g + 4*half + (0..3) in registers 4g..4g+3
+      float* __restrict__ o = out + myrow * W + n0 + 4 * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t ro = (int64_t)((r & 3) + 8 * (r >> 2)) * W;
-        o[ro] = acc0[r];
-        o[ro + 32] = acc1[r];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < E) {
-          const int c0 = n0 + l31, c1 = n0 + 32 + l31;
-          if (c0 < W) out[row * W + c0] = acc0[r];
-          if (c1 < W) out[row * W + c1] = acc1[r];
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = n0 + 4 * half + 8 * g;
+        if (c0 + 3 < W)
+          *reinterpret_cast<float4*>(o + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+        if (c0 + 32 + 3 < W)
+          *reinterpret_cast<float4*>(o + 32 + 8 * g) =
+              make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
       }
     }
     lds_barrier();
@@ -301,32 +311,50 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float* __rest
     lds_barrier();
   }
 
-  // epilogue (re-using the staging buffers): g_h -> LDS, g_pre = g_h * silu'(pre) in place, then the NB-wide GEMV
-  float* __restrict__ gp = smem;
+  // epilogue: pre-activations recomputed on MFMA in the accumulator layout (pre[row][k] = sum_c emb[row][c] W0s[c][k]:
+  // 4 MFMAs per 32x32 tile), g_pre = g_h * silu'(pre) in registers, one pass through LDS for the NB-wide GEMV
+  float* __restrict__ gp = smem;  // re-uses the staging buffers (all waves passed the last lds_barrier)
+  {
+    const float* __restrict__ erow = es + (wv * 32 + l31) * kMaxNb;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = t * 32 + l31;  // hidden index
+    for (int t = 0; t < NT; ++t) {
+      f32x16 pacc = {0};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // row within the block
-      gp[lr * GS + col] = acc[t][r];
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const float av = erow[2 * s2 + half];                          // A[i = row][c]
+        const float bv = w0t[(2 * s2 + half) * H + t * 32 + l31];      // B[c][j = hidden]
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, pacc, 0, 0, 0);
+      }
+      const int col = t * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // row within the block
+        gp[lr * GS + col] = acc[t][r] * silu_grad_f(pacc[r]);
+      }
     }
   }
   __syncthreads();
-  for (int i = tid; i < kMlpRows * H; i += 256) {
-    const int r = i / H, k = i - r * H;
-    float pre = 0.f;
-    for (int c = 0; c < nb; ++c) pre += es[r * kMaxNb + c] * w0t[c * H + k];
-    gp[r * GS + k] *= silu_grad_f(pre);
-  }
-  __syncthreads();
-  for (int o = tid; o < kMlpRows * nb; o += 256) {
-    const int r = o / nb, c = o - r * nb;
-    if (blk0 + r >= E) continue;
-    float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < H; ++k) s += gp[r * GS + k] * w0s[k * kMaxNb + c];
-    g_emb[(blk0 + r) * nb + c] = s;
+  {
+    // g_emb[r][c] = sum_k g_pre[r][k] W0s[c][k]: two threads per row, each over half of k, all NB columns at once
+    const int r = tid >> 1, kh = tid & 1;
+    float sacc[kMaxNb];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) sacc[c] = 0.f;
+    const float* __restrict__ gr = gp + r * GS + kh * (H / 2);
+    const float* __restrict__ wr = w0s + kh * (H / 2) * kMaxNb;
+#pragma unroll 4
+    for (int k = 0; k < H / 2; ++k) {
+      const float gv = gr[k];
+      const float4 w0 = *reinterpret_cast<const float4*>(wr + k * kMaxNb);
+      const float4 w1 = *reinterpret_cast<const float4*>(wr + k * kMaxNb + 4);
+      sacc[0] += gv * w0.x; sacc[1] += gv * w0.y; sacc[2] += gv * w0.z; sacc[3] += gv * w0.w;
+      sacc[4] += gv * w1.x; sacc[5] += gv * w1.y; sacc[6] += gv * w1.z; sacc[7] += gv * w1.w;
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) sacc[c] += __shfl_xor(sacc[c], 1, 64);
+    if (kh == 0 && blk0 + r < E) {
+      for (int c = 0; c < nb; ++c) g_emb[(blk0 + r) * nb + c] = sacc[c];
+    }
   }
 }
 
