@@ -55,7 +55,7 @@ def build_box(w, seed=0):
         pos, types, cell, names = syn.silicon_box(reps=w["reps"], seed=seed)
     else:
         raise ValueError(w["box"])
-    data = syn.make_data(pos, types, 4.5, cell)
+    data = syn.make_data(pos, types, 4.5, cell, spatial_sort=os.environ.get("NQA_BENCH_SORT", "0") != "0")
     return data, names
 
 

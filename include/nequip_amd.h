@@ -187,6 +187,15 @@ int nqa_edge_embed_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int6
                        double rmax_recip, const double* rmax_recip_edge, int32_t num_bessels,
                        const double* bessel_weights, double cutoff_p, double factor, const void* g_sh,
                        const void* g_emb, double* g_edge_vec, nqa_stream stream);
+/* Second order (force-matching training, nequip/nn/grad_output.py:220 create_graph=True): for the cotangent
+ * cot_g_edge_vec [E,3] of the VJP output above, gg_sh / gg_emb = J(v) c (gradients w.r.t. g_sh / g_emb) and
+ * g_edge_vec2 = (sum_k g_k Hessian_k(v)) c (gradient w.r.t. the edge vector).  Evaluated with forward-mode dual
+ * numbers through the same per-edge code as the first-order kernels.  Any output may be NULL. */
+int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges,
+                           double rmax_recip, const double* rmax_recip_edge, int32_t num_bessels,
+                           const double* bessel_weights, double cutoff_p, double factor, const void* g_sh,
+                           const void* g_emb, const double* cot_g_edge_vec, void* gg_sh, void* gg_emb,
+                           double* g_edge_vec2, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Radial network on MFMA: replaces ScalarMLPFunction.forward as InteractionBlock.edge_mlp

@@ -86,6 +86,11 @@ SIGNATURES = {
         [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]
         + [c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "nqa_edge_embed_bwd_bwd": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]
+        + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "nqa_radial_mlp_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "nqa_radial_mlp_fwd": (
         c_int32,

@@ -1,5 +1,6 @@
-// Edge embedding kernels: real spherical harmonics + Bessel radial basis x polynomial cutoff, and their
-// vector-Jacobian product (the edge -> position leg of the force backward).
+// Edge embedding kernels: real spherical harmonics + Bessel radial basis x polynomial cutoff, their
+// vector-Jacobian product (the edge -> position leg of the force backward) and the derivative of that product
+// (second order, needed when forces enter a training loss).
 //
 // Replaces, for float64 edge vectors (nequip/nn/utils.py:68-118), the chain of small ATen ops behind
 //   SphericalHarmonicEdgeAttrs.forward (nequip/nn/embedding/_edge.py:193-198),
@@ -7,17 +8,65 @@
 //   BesselEdgeLengthEncoding.forward   (nequip/nn/embedding/_edge.py:136-150),
 //   PolynomialCutoff.forward           (nequip/nn/embedding/cutoffs.py:17-27),
 //   ApplyFactor                        (nequip/model/nequip_models.py:318-322)
-// with one pass over the edges: 24 B read, (S + nb) * sizeof(T) written per edge.  HBM-bound,
-// one thread per edge (the per-edge work is a few hundred f64 FLOPs, the loads/stores are coalesced
-// across the wave because consecutive threads handle consecutive edges).
+// with one pass over the edges: 24 B read, (S + nb) * sizeof(T) written per edge.  HBM-bound, one thread per
+// edge (a few hundred f64 FLOPs each; consecutive threads handle consecutive edges).
 // Arithmetic is float64 (the reference evaluates on float64 data and casts, _edge.py:140-142,196-197).
+//
+// The per-edge maps are written once, templated on the scalar type S: S = double gives the forward and the VJP;
+// S = Dual (forward-mode dual number seeded with the cotangent of the VJP output) gives, from the very same code,
+// the Jacobian-vector product J c and the Hessian contraction (sum_k g_k H_k) c that the double backward of
+// ForceStressOutput (nequip/nn/grad_output.py:217-221 with create_graph=True) needs.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <string>
 
-#include "generated/sh_generated.h"
 #include "plan.h"
+
+namespace nqa {
+
+// ---- forward-mode dual numbers --------------------------------------------------------------------------------
+struct Dual {
+  double v, d;
+  __device__ __forceinline__ Dual() : v(0.0), d(0.0) {}
+  __device__ __forceinline__ Dual(double a) : v(a), d(0.0) {}
+  __device__ __forceinline__ Dual(double a, double b) : v(a), d(b) {}
+};
+__device__ __forceinline__ Dual operator+(const Dual& a, const Dual& b) { return Dual(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(const Dual& a, const Dual& b) { return Dual(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator-(const Dual& a) { return Dual(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator*(const Dual& a, const Dual& b) { return Dual(a.v * b.v, a.v * b.d + a.d * b.v); }
+__device__ __forceinline__ Dual operator/(const Dual& a, const Dual& b) {
+  const double q = a.v / b.v;
+  return Dual(q, (a.d - q * b.d) / b.v);
+}
+__device__ __forceinline__ Dual operator+(const Dual& a, double b) { return Dual(a.v + b, a.d); }
+__device__ __forceinline__ Dual operator+(double a, const Dual& b) { return Dual(a + b.v, b.d); }
+__device__ __forceinline__ Dual operator-(const Dual& a, double b) { return Dual(a.v - b, a.d); }
+__device__ __forceinline__ Dual operator-(double a, const Dual& b) { return Dual(a - b.v, -b.d); }
+__device__ __forceinline__ Dual operator*(const Dual& a, double b) { return Dual(a.v * b, a.d * b); }
+__device__ __forceinline__ Dual operator*(double a, const Dual& b) { return Dual(a * b.v, a * b.d); }
+__device__ __forceinline__ Dual operator/(const Dual& a, double b) { return Dual(a.v / b, a.d / b); }
+__device__ __forceinline__ Dual operator/(double a, const Dual& b) { return Dual(a) / b; }
+__device__ __forceinline__ Dual& operator+=(Dual& a, const Dual& b) { a.v += b.v; a.d += b.d; return a; }
+__device__ __forceinline__ Dual dsqrt(const Dual& a) {
+  const double s = sqrt(a.v);
+  return Dual(s, s > 0.0 ? 0.5 * a.d / s : 0.0);
+}
+__device__ __forceinline__ Dual dsin(const Dual& a) { return Dual(sin(a.v), cos(a.v) * a.d); }
+__device__ __forceinline__ Dual dcos(const Dual& a) { return Dual(cos(a.v), -sin(a.v) * a.d); }
+__device__ __forceinline__ double dsqrt(double a) { return sqrt(a); }
+__device__ __forceinline__ double dsin(double a) { return sin(a); }
+__device__ __forceinline__ double dcos(double a) { return cos(a); }
+__device__ __forceinline__ double val(double a) { return a; }
+__device__ __forceinline__ double val(const Dual& a) { return a.v; }
+__device__ __forceinline__ double tan_part(double) { return 0.0; }
+__device__ __forceinline__ double tan_part(const Dual& a) { return a.d; }
+
+}  // namespace nqa
+
+using nqa::Dual;
+#include "generated/sh_generated.h"
 
 namespace nqa {
 
@@ -36,47 +85,136 @@ struct EdgeEmbedParams {
   int32_t p_int;  // p as integer if integral, else -1
 };
 
-__device__ __forceinline__ double ipow_rt(double x, int n) {
-  double r = 1.0, b = x;
+template <typename S>
+__device__ __forceinline__ S ipow_rt(const S& x, int n) {
+  S r = S(1.0), b = x;
   while (n > 0) {
-    if (n & 1) r *= b;
-    b *= b;
+    if (n & 1) r = r * b;
+    b = b * b;
     n >>= 1;
   }
   return r;
 }
 
 __device__ __forceinline__ double pow_p(double x, double p, int p_int, int shift) {
-  // x^(p + shift)
   if (p_int >= 0) {
     const int n = p_int + shift;
-    return n >= 0 ? ipow_rt(x, n) : 1.0 / ipow_rt(x, -n);
+    return n >= 0 ? ipow_rt<double>(x, n) : 1.0 / ipow_rt<double>(x, -n);
   }
   return pow(x, p + (double)shift);
 }
+__device__ __forceinline__ Dual pow_p(const Dual& x, double p, int p_int, int shift) {
+  // d/dx x^q = q x^(q-1)
+  const double q = (p_int >= 0 ? (double)p_int : p) + (double)shift;
+  const double v = pow_p(x.v, p, p_int, shift);
+  const double dv = q == 0.0 ? 0.0 : q * pow_p(x.v, p, p_int, shift - 1);
+  return Dual(v, dv * x.d);
+}
 
 // cutoff(x) = 1 - (p+1)(p+2)/2 x^p + p(p+2) x^(p+1) - p(p+1)/2 x^(p+2), masked by x < 1 (cutoffs.py:23-27)
-__device__ __forceinline__ double poly_cutoff(double x, double p, int p_int) {
-  double out = 1.0;
+template <typename S>
+__device__ __forceinline__ S poly_cutoff(const S& x, double p, int p_int) {
+  if (!(val(x) < 1.0)) return S(0.0);
+  S out = S(1.0);
   out = out - (((p + 1.0) * (p + 2.0) / 2.0) * pow_p(x, p, p_int, 0));
   out = out + (p * (p + 2.0) * pow_p(x, p, p_int, 1));
   out = out - ((p * (p + 1.0) / 2.0) * pow_p(x, p, p_int, 2));
-  return x < 1.0 ? out : 0.0;
+  return out;
 }
-
-__device__ __forceinline__ double poly_cutoff_grad(double x, double p, int p_int) {
-  if (!(x < 1.0)) return 0.0;
-  double g = -(((p + 1.0) * (p + 2.0) / 2.0) * p * pow_p(x, p, p_int, -1));
-  g += p * (p + 2.0) * (p + 1.0) * pow_p(x, p, p_int, 0);
-  g -= (p * (p + 1.0) / 2.0) * (p + 2.0) * pow_p(x, p, p_int, 1);
+template <typename S>
+__device__ __forceinline__ S poly_cutoff_grad(const S& x, double p, int p_int) {
+  if (!(val(x) < 1.0)) return S(0.0);
+  S g = -(((p + 1.0) * (p + 2.0) / 2.0) * p * pow_p(x, p, p_int, -1));
+  g = g + p * (p + 2.0) * (p + 1.0) * pow_p(x, p, p_int, 0);
+  g = g - (p * (p + 1.0) / 2.0) * (p + 2.0) * pow_p(x, p, p_int, 1);
   return g;
 }
 
 // torch.sinc: sin(pi t)/(pi t), 1 at t == 0
-__device__ __forceinline__ double sinc_pi(double t) {
-  if (t == 0.0) return 1.0;
-  const double a = kPi * t;
-  return sin(a) / a;
+template <typename S>
+__device__ __forceinline__ S sinc_pi(const S& t) {
+  if (val(t) == 0.0) return S(1.0);
+  const S a = kPi * t;
+  return dsin(a) / a;
+}
+
+// ---- per-edge maps, templated on the scalar type ---------------------------------------------------------------
+// geometry shared by all maps: r = |v|, u = v / max(r, 1e-12)  (torch.nn.functional.normalize)
+template <typename S>
+struct Geom {
+  S r, inv, ux, uy, uz;
+  bool clamped;
+};
+template <typename S>
+__device__ __forceinline__ Geom<S> geom(const S& vx, const S& vy, const S& vz) {
+  Geom<S> g;
+  g.r = dsqrt(vx * vx + vy * vy + vz * vz);
+  g.clamped = !(val(g.r) >= 1e-12);
+  g.inv = g.clamped ? S(1e12) : 1.0 / g.r;
+  g.ux = vx * g.inv;
+  g.uy = vy * g.inv;
+  g.uz = vz * g.inv;
+  return g;
+}
+
+// radial embedding value (before the cast / factor): b_n(x) and cutoff(x), x = r * rr
+template <typename S>
+__device__ __forceinline__ S bessel_n(const S& x, double w) {
+  return sinc_pi(x * w) * w;
+}
+// d/dx [sinc(x w) w] = w^2 (cos(pi t) - sinc(t)) / t,  t = x w
+template <typename S>
+__device__ __forceinline__ S bessel_n_grad(const S& x, double w) {
+  const S t = x * w;
+  if (val(t) == 0.0) return S(0.0);
+  return (w * w) * (dcos(kPi * t) - sinc_pi(t)) / t;
+}
+
+// VJP of (sh, emb) w.r.t. the edge vector for cotangents (g_sh, g_emb); returns the three components in S.
+template <typename T, int L, typename S>
+__device__ __forceinline__ void embed_vjp(const EdgeEmbedParams& prm, int64_t e, const S& vx, const S& vy, const S& vz,
+                                          const T* __restrict__ g_sh, const T* __restrict__ g_emb, S* out3) {
+  constexpr int NS = (L + 1) * (L + 1);
+  const Geom<S> gm = geom(vx, vy, vz);
+  S gx = S(0.0), gy = S(0.0), gz = S(0.0);
+  if (g_sh != nullptr) {
+    double g[NS];
+    const T* __restrict__ gi = g_sh + e * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) g[s] = (double)gi[s];
+    S G[3];
+    nqa_sh<L, S>::vjp(gm.ux, gm.uy, gm.uz, g, G);
+    if (!gm.clamped) {
+      // d(v/|v|)/dv = (I - u u^T)/|v|
+      const S ug = gm.ux * G[0] + gm.uy * G[1] + gm.uz * G[2];
+      gx = (G[0] - gm.ux * ug) * gm.inv;
+      gy = (G[1] - gm.uy * ug) * gm.inv;
+      gz = (G[2] - gm.uz * ug) * gm.inv;
+    } else {
+      gx = G[0] * gm.inv;
+      gy = G[1] * gm.inv;
+      gz = G[2] * gm.inv;
+    }
+  }
+  if (g_emb != nullptr) {
+    const double rr = prm.rr_edge ? prm.rr_edge[e] : prm.rr;
+    const S x = gm.r * rr;
+    const S c = poly_cutoff(x, prm.p, prm.p_int);
+    const S dc = poly_cutoff_grad(x, prm.p, prm.p_int);
+    const T* __restrict__ gi = g_emb + e * prm.nb;
+    S acc = S(0.0);
+    for (int n = 0; n < prm.nb; ++n) {
+      const double w = prm.bw[n];
+      acc += (double)gi[n] * (bessel_n_grad(x, w) * c + bessel_n(x, w) * dc);
+    }
+    const S gr = acc * (prm.factor * rr);  // dE/dr ; d|v|/dv = u
+    gx += gr * gm.ux;
+    gy += gr * gm.uy;
+    gz += gr * gm.uz;
+  }
+  out3[0] = gx;
+  out3[1] = gy;
+  out3[2] = gz;
 }
 
 template <typename T, int L>
@@ -84,30 +222,26 @@ __global__ __launch_bounds__(256) void edge_embed_fwd_kernel(const EdgeEmbedPara
                                                              T* __restrict__ emb, T* __restrict__ cutoff) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= prm.E) return;
-  constexpr int S = (L + 1) * (L + 1);
-  const double vx = prm.vec[3 * e + 0], vy = prm.vec[3 * e + 1], vz = prm.vec[3 * e + 2];
-  const double r = sqrt(vx * vx + vy * vy + vz * vz);
+  constexpr int NS = (L + 1) * (L + 1);
+  const Geom<double> gm = geom<double>(prm.vec[3 * e + 0], prm.vec[3 * e + 1], prm.vec[3 * e + 2]);
   if (sh != nullptr) {
-    // torch.nn.functional.normalize: v / max(|v|, 1e-12)
-    const double inv = 1.0 / fmax(r, 1e-12);
-    double Y[S];
-    nqa_sh_eval<L>(vx * inv, vy * inv, vz * inv, Y);
-    T* __restrict__ o = sh + e * S;
+    double Y[NS];
+    nqa_sh<L, double>::eval(gm.ux, gm.uy, gm.uz, Y);
+    T* __restrict__ o = sh + e * NS;
 #pragma unroll
-    for (int s = 0; s < S; ++s) o[s] = (T)Y[s];
+    for (int s = 0; s < NS; ++s) o[s] = (T)Y[s];
   }
   if (emb != nullptr || cutoff != nullptr) {
     const double rr = prm.rr_edge ? prm.rr_edge[e] : prm.rr;
-    const double x = r * rr;
-    const T c = (T)poly_cutoff(x, prm.p, prm.p_int);
+    const double x = gm.r * rr;
+    const T c = (T)poly_cutoff<double>(x, prm.p, prm.p_int);
     if (cutoff != nullptr) cutoff[e] = c;
     if (emb != nullptr) {
       const T f = (T)prm.factor;
       T* __restrict__ o = emb + e * prm.nb;
       for (int n = 0; n < prm.nb; ++n) {
-        const double w = prm.bw[n];
-        const T b = (T)(sinc_pi(x * w) * w);
-        o[n] = f * (b * c);
+        const T b = (T)bessel_n<double>(x, prm.bw[n]);
+        o[n] = f * (b * c);  // same rounding order as the reference: factor * (bessel.to(T) * cutoff.to(T))
       }
     }
   }
@@ -119,56 +253,53 @@ __global__ __launch_bounds__(256) void edge_embed_bwd_kernel(const EdgeEmbedPara
                                                              double* __restrict__ g_vec) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= prm.E) return;
-  constexpr int S = (L + 1) * (L + 1);
-  const double vx = prm.vec[3 * e + 0], vy = prm.vec[3 * e + 1], vz = prm.vec[3 * e + 2];
-  const double r = sqrt(vx * vx + vy * vy + vz * vz);
-  const double inv = 1.0 / fmax(r, 1e-12);
-  const double ux = vx * inv, uy = vy * inv, uz = vz * inv;
-  double gx = 0.0, gy = 0.0, gz = 0.0;
-  if (g_sh != nullptr) {
-    double g[S];
-    const T* __restrict__ gi = g_sh + e * S;
+  double o[3];
+  embed_vjp<T, L, double>(prm, e, prm.vec[3 * e + 0], prm.vec[3 * e + 1], prm.vec[3 * e + 2], g_sh, g_emb, o);
+  g_vec[3 * e + 0] = o[0];
+  g_vec[3 * e + 1] = o[1];
+  g_vec[3 * e + 2] = o[2];
+}
+
+// Second order: given the cotangent c[E,3] of the VJP output g_vec = J(v)^T g,
+//   gg_sh / gg_emb = J(v) c          (gradient w.r.t. the first-order cotangents g_sh / g_emb)
+//   g_vec2         = (sum_k g_k H_k(v)) c   (gradient w.r.t. the edge vector)
+template <typename T, int L>
+__global__ __launch_bounds__(256) void edge_embed_bwd_bwd_kernel(const EdgeEmbedParams prm,
+                                                                 const T* __restrict__ g_sh,
+                                                                 const T* __restrict__ g_emb,
+                                                                 const double* __restrict__ c, T* __restrict__ gg_sh,
+                                                                 T* __restrict__ gg_emb,
+                                                                 double* __restrict__ g_vec2) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= prm.E) return;
+  constexpr int NS = (L + 1) * (L + 1);
+  const Dual vx(prm.vec[3 * e + 0], c[3 * e + 0]), vy(prm.vec[3 * e + 1], c[3 * e + 1]),
+      vz(prm.vec[3 * e + 2], c[3 * e + 2]);
+  if (g_vec2 != nullptr) {
+    Dual o[3];
+    embed_vjp<T, L, Dual>(prm, e, vx, vy, vz, g_sh, g_emb, o);
+    g_vec2[3 * e + 0] = o[0].d;
+    g_vec2[3 * e + 1] = o[1].d;
+    g_vec2[3 * e + 2] = o[2].d;
+  }
+  const Geom<Dual> gm = geom<Dual>(vx, vy, vz);
+  if (gg_sh != nullptr) {
+    Dual Y[NS];
+    nqa_sh<L, Dual>::eval(gm.ux, gm.uy, gm.uz, Y);
+    T* __restrict__ o = gg_sh + e * NS;
 #pragma unroll
-    for (int s = 0; s < S; ++s) g[s] = (double)gi[s];
-    double G[3];
-    nqa_sh_vjp<L>(ux, uy, uz, g, G);
-    if (r >= 1e-12) {
-      // d(v/|v|)/dv = (I - u u^T)/|v|
-      const double ug = ux * G[0] + uy * G[1] + uz * G[2];
-      gx = (G[0] - ux * ug) * inv;
-      gy = (G[1] - uy * ug) * inv;
-      gz = (G[2] - uz * ug) * inv;
-    } else {
-      // clamped branch of normalize: v * 1e12
-      gx = G[0] * inv;
-      gy = G[1] * inv;
-      gz = G[2] * inv;
-    }
+    for (int s = 0; s < NS; ++s) o[s] = (T)Y[s].d;
   }
-  if (g_emb != nullptr) {
+  if (gg_emb != nullptr) {
     const double rr = prm.rr_edge ? prm.rr_edge[e] : prm.rr;
-    const double x = r * rr;
-    const double c = poly_cutoff(x, prm.p, prm.p_int);
-    const double dc = poly_cutoff_grad(x, prm.p, prm.p_int);
-    const T* __restrict__ gi = g_emb + e * prm.nb;
-    double acc = 0.0;
+    const Dual x = gm.r * rr;
+    const Dual cf = poly_cutoff<Dual>(x, prm.p, prm.p_int);
+    T* __restrict__ o = gg_emb + e * prm.nb;
     for (int n = 0; n < prm.nb; ++n) {
-      const double w = prm.bw[n];
-      const double t = x * w;
-      const double sc = sinc_pi(t);
-      // d/dx [sinc(x w) w] = w^2 (cos(pi t) - sinc(t)) / t
-      const double db = (t == 0.0) ? 0.0 : w * w * (cos(kPi * t) - sc) / t;
-      acc += (double)gi[n] * (db * c + sc * w * dc);
+      const Dual b = bessel_n<Dual>(x, prm.bw[n]);
+      o[n] = (T)(prm.factor * (b.d * cf.v + b.v * cf.d));
     }
-    const double gr = acc * prm.factor * rr;  // dE/dr
-    // d|v|/dv = u (sqrt backward; 0-length edges do not occur in neighbour lists)
-    gx += gr * ux;
-    gy += gr * uy;
-    gz += gr * uz;
   }
-  g_vec[3 * e + 0] = gx;
-  g_vec[3 * e + 1] = gy;
-  g_vec[3 * e + 2] = gz;
 }
 
 static int make_params(EdgeEmbedParams& prm, const double* edge_vec, int64_t E, double rmax_recip,
@@ -201,6 +332,25 @@ static int make_params(EdgeEmbedParams& prm, const double* edge_vec, int64_t E, 
   return NQA_OK;
 }
 
+static int finish(const char* fn) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string(fn) + ": " + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+#define NQA_SWITCH_L(lmax, LAUNCH, fn)                                                  \
+  switch (lmax) {                                                                       \
+    case 0: LAUNCH(0); break;                                                           \
+    case 1: LAUNCH(1); break;                                                           \
+    case 2: LAUNCH(2); break;                                                           \
+    case 3: LAUNCH(3); break;                                                           \
+    case 4: LAUNCH(4); break;                                                           \
+    default: set_error(std::string(fn) + ": lmax exceeds supported maximum"); return NQA_ERR_UNSUPPORTED; \
+  }
+
 template <typename T>
 static int launch_fwd(int lmax, const EdgeEmbedParams& prm, void* sh, void* emb, void* cutoff, hipStream_t s) {
   if (prm.E == 0) return NQA_OK;
@@ -208,21 +358,9 @@ static int launch_fwd(int lmax, const EdgeEmbedParams& prm, void* sh, void* emb,
 #define NQA_LAUNCH(L)                                                                                      \
   hipLaunchKernelGGL((edge_embed_fwd_kernel<T, L>), dim3(grid), dim3(256), 0, s, prm, static_cast<T*>(sh), \
                      static_cast<T*>(emb), static_cast<T*>(cutoff))
-  switch (lmax) {
-    case 0: NQA_LAUNCH(0); break;
-    case 1: NQA_LAUNCH(1); break;
-    case 2: NQA_LAUNCH(2); break;
-    case 3: NQA_LAUNCH(3); break;
-    case 4: NQA_LAUNCH(4); break;
-    default: set_error("nqa_edge_embed_fwd: lmax exceeds supported maximum"); return NQA_ERR_UNSUPPORTED;
-  }
+  NQA_SWITCH_L(lmax, NQA_LAUNCH, "nqa_edge_embed_fwd")
 #undef NQA_LAUNCH
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) {
-    set_error(std::string("nqa_edge_embed_fwd: ") + hipGetErrorString(err));
-    return NQA_ERR_LAUNCH;
-  }
-  return NQA_OK;
+  return finish("nqa_edge_embed_fwd");
 }
 
 template <typename T>
@@ -230,24 +368,26 @@ static int launch_bwd(int lmax, const EdgeEmbedParams& prm, const void* g_sh, co
                       hipStream_t s) {
   if (prm.E == 0) return NQA_OK;
   const unsigned grid = (unsigned)((prm.E + 255) / 256);
-#define NQA_LAUNCH(L)                                                                                    \
-  hipLaunchKernelGGL((edge_embed_bwd_kernel<T, L>), dim3(grid), dim3(256), 0, s, prm,                    \
+#define NQA_LAUNCH(L)                                                                 \
+  hipLaunchKernelGGL((edge_embed_bwd_kernel<T, L>), dim3(grid), dim3(256), 0, s, prm, \
                      static_cast<const T*>(g_sh), static_cast<const T*>(g_emb), g_vec)
-  switch (lmax) {
-    case 0: NQA_LAUNCH(0); break;
-    case 1: NQA_LAUNCH(1); break;
-    case 2: NQA_LAUNCH(2); break;
-    case 3: NQA_LAUNCH(3); break;
-    case 4: NQA_LAUNCH(4); break;
-    default: set_error("nqa_edge_embed_bwd: lmax exceeds supported maximum"); return NQA_ERR_UNSUPPORTED;
-  }
+  NQA_SWITCH_L(lmax, NQA_LAUNCH, "nqa_edge_embed_bwd")
 #undef NQA_LAUNCH
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) {
-    set_error(std::string("nqa_edge_embed_bwd: ") + hipGetErrorString(err));
-    return NQA_ERR_LAUNCH;
-  }
-  return NQA_OK;
+  return finish("nqa_edge_embed_bwd");
+}
+
+template <typename T>
+static int launch_bwd_bwd(int lmax, const EdgeEmbedParams& prm, const void* g_sh, const void* g_emb, const double* c,
+                          void* gg_sh, void* gg_emb, double* g_vec2, hipStream_t s) {
+  if (prm.E == 0) return NQA_OK;
+  const unsigned grid = (unsigned)((prm.E + 255) / 256);
+#define NQA_LAUNCH(L)                                                                                         \
+  hipLaunchKernelGGL((edge_embed_bwd_bwd_kernel<T, L>), dim3(grid), dim3(256), 0, s, prm,                     \
+                     static_cast<const T*>(g_sh), static_cast<const T*>(g_emb), c, static_cast<T*>(gg_sh),    \
+                     static_cast<T*>(gg_emb), g_vec2)
+  NQA_SWITCH_L(lmax, NQA_LAUNCH, "nqa_edge_embed_bwd_bwd")
+#undef NQA_LAUNCH
+  return finish("nqa_edge_embed_bwd_bwd");
 }
 
 }  // namespace nqa
@@ -297,6 +437,29 @@ int nqa_edge_embed_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int6
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == NQA_F32 ? launch_bwd<float>(lmax, prm, g_sh, g_emb, g_edge_vec, s)
                           : launch_bwd<double>(lmax, prm, g_sh, g_emb, g_edge_vec, s);
+}
+
+int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges, double rmax_recip,
+                           const double* rmax_recip_edge, int32_t num_bessels, const double* bessel_weights,
+                           double cutoff_p, double factor, const void* g_sh, const void* g_emb,
+                           const double* cot_g_edge_vec, void* gg_sh, void* gg_emb, double* g_edge_vec2,
+                           nqa_stream stream) {
+  if (dtype != NQA_F32 && dtype != NQA_F64) {
+    set_error("nqa_edge_embed_bwd_bwd: unsupported dtype");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (lmax < 0 || (num_edges > 0 && cot_g_edge_vec == nullptr) || (gg_sh != nullptr && g_sh == nullptr && false)) {
+    set_error("nqa_edge_embed_bwd_bwd: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  EdgeEmbedParams prm{};
+  int rc = make_params(prm, edge_vec, num_edges, rmax_recip, rmax_recip_edge, num_bessels, bessel_weights, cutoff_p,
+                       factor, g_emb != nullptr || gg_emb != nullptr, "nqa_edge_embed_bwd_bwd");
+  if (rc != NQA_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == NQA_F32
+             ? launch_bwd_bwd<float>(lmax, prm, g_sh, g_emb, cot_g_edge_vec, gg_sh, gg_emb, g_edge_vec2, s)
+             : launch_bwd_bwd<double>(lmax, prm, g_sh, g_emb, cot_g_edge_vec, gg_sh, gg_emb, g_edge_vec2, s);
 }
 
 }  // extern "C"

@@ -130,31 +130,35 @@ def _emit(st: Structure) -> str:
     A("namespace {")
     A(f"constexpr int kXD = {XD}, kS = {S}, kOD = {OD}, kNP = {NP};")
 
-    def load_x(indent, row):
-        out = []
+    def decl_x(indent, sfx=""):
+        return [f"{indent}T xb{b}{sfx}[{2 * st.in1_ls[b] + 1}];" for b in used_blocks]
+
+    def decl_y(indent, sfx=""):
+        return [f"{indent}T yb{j}{sfx}[{2 * st.in2_ls[j] + 1}];" for j in used_y]
+
+    def load_x(indent, row, sfx="", decl=True):
+        out = decl_x(indent, sfx) if decl else []
         for b in used_blocks:
             d = 2 * st.in1_ls[b] + 1
-            out.append(f"{indent}T xb{b}[{d}];")
             out.append(f"{indent}{{ const T* __restrict__ p = {row} + (int64_t)mul * {xpre[b]} + (int64_t)u * {d};")
             for i in range(d):
-                out.append(f"{indent}  xb{b}[{i}] = act ? p[{i}] : T(0);")
+                out.append(f"{indent}  xb{b}{sfx}[{i}] = act ? p[{i}] : T(0);")
             out.append(f"{indent}}}")
         return out
 
-    def load_y(indent, row):
-        out = []
+    def load_y(indent, row, sfx="", decl=True):
+        out = decl_y(indent, sfx) if decl else []
         for j in used_y:
             d = 2 * st.in2_ls[j] + 1
-            out.append(f"{indent}T yb{j}[{d}];")
             for i in range(d):
-                out.append(f"{indent}yb{j}[{i}] = {row}[{ypre[j] + i}];")
+                out.append(f"{indent}yb{j}{sfx}[{i}] = {row}[{ypre[j] + i}];")
         return out
 
-    def load_w(indent, row, scale=False):
-        out = [f"{indent}T wv[kNP];"]
+    def load_w(indent, row, scale=False, sfx="", decl=True):
+        out = [f"{indent}T wv{sfx}[kNP];"] if decl else []
         for p in range(NP):
             c = f"T({coeff[p]!r}) * " if scale else ""
-            out.append(f"{indent}wv[{p}] = act ? {c}{row}[(int64_t)mul * {p}] : T(0);")
+            out.append(f"{indent}wv{sfx}[{p}] = act ? {c}{row}[(int64_t)mul * {p}] : T(0);")
         return out
 
     # ------------------------------------------------------------------ forward
@@ -177,26 +181,55 @@ def _emit(st: Structure) -> str:
     A("#pragma unroll")
     A("  for (int k = 0; k < kOD; ++k) acc[k] = T(0);")
     A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
+    A("  // Two register sets (A/B): the operands of edge i+1 are requested before edge i is evaluated, the indices of")
+    A("  // edge i+2 before that -- every HBM/L2 round trip of an edge hides behind the arithmetic of the previous one.")
+    L.extend(["  T wvA[kNP], wvB[kNP];"] + decl_x("  ", "A") + decl_x("  ", "B") + decl_y("  ", "A") + decl_y("  ", "B"))
+
+    def fwd_loads(sfx, e, sv):
+        out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
+               f"      const T* __restrict__ wr = a.w + (int64_t){e} * a.wn + u;",
+               f"      const T* __restrict__ yr = a.y + (int64_t){e} * kS;"]
+        out += load_w("      ", "wr", sfx=sfx, decl=False)
+        out += load_x("      ", "xr", sfx=sfx, decl=False)
+        out += load_y("      ", "yr", sfx=sfx, decl=False)
+        out.append("    }")
+        return out
+
+    def fwd_compute(sfx):
+        out = []
+        for p, (b, j, sl) in enumerate(st.instr):
+            l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[sl]
+            d3 = 2 * l3 + 1
+            out.append(f"    {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}{sfx}, yb{j}{sfx}, t);")
+            for k in range(d3):
+                out.append(f"      acc[{opre[sl] + k}] += wv{sfx}[{p}] * t[{k}];")
+            out.append("    }")
+        return out
+
     A("  int idx = beg + wsub;")
-    A("  int e = 0, s = 0;")
-    A("  if (idx < end) { e = a.eid[idx]; s = a.nbr[idx]; }")
+    A("  int nidx = idx + WPN;")
+    A("  int e0 = 0, s0 = 0, e1 = 0, s1 = 0;")
+    A("  if (idx < end) { e0 = a.eid[idx]; s0 = a.nbr[idx]; }")
+    A("  if (idx < end) {")
+    L.extend(fwd_loads("A", "e0", "s0"))
+    A("  }")
+    A("  if (nidx < end) { e1 = a.eid[nidx]; s1 = a.nbr[nidx]; }")
     A("  while (idx < end) {")
-    A("    const int nidx = idx + WPN;")
-    A("    int e_n = 0, s_n = 0;")
-    A("    if (nidx < end) { e_n = a.eid[nidx]; s_n = a.nbr[nidx]; }")
-    A("    const T* __restrict__ xr = a.x + (int64_t)s * a.din;")
-    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn + u;")
-    A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
-    L.extend(load_w("    ", "wr"))
-    L.extend(load_x("    ", "xr"))
-    L.extend(load_y("    ", "yr"))
-    for p, (b, j, s) in enumerate(st.instr):
-        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
-        d3 = 2 * l3 + 1
-        A(f"    {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}, yb{j}, t);")
-        for k in range(d3):
-            A(f"      acc[{opre[s] + k}] += wv[{p}] * t[{k}]; }}" if k == d3 - 1 else f"      acc[{opre[s] + k}] += wv[{p}] * t[{k}];")
-    A("    idx = nidx; e = e_n; s = s_n;")
+    A("    if (nidx < end) {")
+    L.extend(fwd_loads("B", "e1", "s1"))
+    A("    }")
+    A("    int nn = nidx + WPN;")
+    A("    if (nn < end) { e0 = a.eid[nn]; s0 = a.nbr[nn]; }")
+    L.extend(fwd_compute("A"))
+    A("    idx = nidx; nidx = nn;")
+    A("    if (idx >= end) break;")
+    A("    if (nidx < end) {")
+    L.extend(fwd_loads("A", "e0", "s0"))
+    A("    }")
+    A("    nn = nidx + WPN;")
+    A("    if (nn < end) { e1 = a.eid[nn]; s1 = a.nbr[nn]; }")
+    L.extend(fwd_compute("B"))
+    A("    idx = nidx; nidx = nn;")
     A("  }")
     # scale by path coefficient: slots shared by several instructions have equal coeff per slot (same l3, same n_into)
     slot_coeff = [None] * NS

@@ -59,14 +59,21 @@ class _EdgeEmbedFn(torch.autograd.Function):
         return outs if len(outs) > 1 else outs[0]
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         vec, bw = ctx.saved_tensors
         cfg = ctx.cfg
-        lib = _lib.load()
         grads = list(grads)
         g_sh = grads.pop(0) if cfg["want_sh"] else None
         g_emb = grads.pop(0) if cfg["want_emb"] else None
+        return _EdgeEmbedBwdFn.apply(vec, bw, g_sh, g_emb, cfg), None, None
+
+
+class _EdgeEmbedBwdFn(torch.autograd.Function):
+    """(edge_vec, g_sh, g_emb) -> g_edge_vec = J^T g; differentiable once more through ``nqa_edge_embed_bwd_bwd``."""
+
+    @staticmethod
+    def forward(ctx, vec, bw, g_sh, g_emb, cfg):
+        lib = _lib.load()
         g_sh = g_sh.contiguous() if g_sh is not None else None
         g_emb = g_emb.contiguous() if g_emb is not None else None
         E = vec.shape[0]
@@ -79,7 +86,30 @@ class _EdgeEmbedFn(torch.autograd.Function):
                 current_stream_ptr(vec.device),
             )  # fmt: skip
         _lib.check(rc, "nqa_edge_embed_bwd")
-        return g_vec, None, None
+        ctx.save_for_backward(vec, bw, g_sh, g_emb)
+        ctx.cfg = cfg
+        return g_vec
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, c):
+        vec, bw, g_sh, g_emb = ctx.saved_tensors
+        cfg = ctx.cfg
+        lib = _lib.load()
+        c = c.contiguous()
+        E = vec.shape[0]
+        need_vec, _, need_gsh, need_gemb = ctx.needs_input_grad[:4]
+        g_vec2 = torch.empty((E, 3), dtype=torch.float64, device=vec.device) if need_vec else None
+        gg_sh = torch.empty_like(g_sh) if (g_sh is not None and need_gsh) else None
+        gg_emb = torch.empty_like(g_emb) if (g_emb is not None and need_gemb) else None
+        with torch.cuda.device(vec.device):
+            rc = lib.nqa_edge_embed_bwd_bwd(
+                _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
+                cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(c), _ptr(gg_sh),
+                _ptr(gg_emb), _ptr(g_vec2), current_stream_ptr(vec.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_edge_embed_bwd_bwd")
+        return g_vec2, None, gg_sh, gg_emb, None
 
 
 class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):

@@ -130,8 +130,9 @@ def energy_model(data, cfg, weights, specs=None):
     return total, e_atom
 
 
-def energy_forces(data, cfg, weights, specs=None, with_virial=False):
-    """ForceStressOutput.forward (nequip/nn/grad_output.py:107-298): forces = -dE/dpos by autograd."""
+def energy_forces(data, cfg, weights, specs=None, with_virial=False, create_graph=False):
+    """ForceStressOutput.forward (nequip/nn/grad_output.py:107-298): forces = -dE/dpos by autograd
+    (``create_graph=True`` = training mode, grad_output.py:220)."""
     data = dict(data)
     pos = data["pos"].detach().clone().requires_grad_(True)
     data["pos"] = pos
@@ -152,8 +153,11 @@ def energy_forces(data, cfg, weights, specs=None, with_virial=False):
                 data["cell"] = cell + torch.bmm(cell, sym)
     total, e_atom = energy_model(data, cfg, weights, specs)
     wrt = [pos] + ([disp] if with_virial else [])
-    grads = torch.autograd.grad([total.sum()], wrt)
-    out = {"total_energy": total.detach(), "atomic_energy": e_atom.detach(), "forces": -grads[0]}
+    grads = torch.autograd.grad([total.sum()], wrt, create_graph=create_graph)
+    if create_graph:
+        out = {"total_energy": total, "atomic_energy": e_atom, "forces": -grads[0]}
+    else:
+        out = {"total_energy": total.detach(), "atomic_energy": e_atom.detach(), "forces": -grads[0]}
     if with_virial:
         out["virial"] = -grads[1].view(-1, 3, 3)
     return out
