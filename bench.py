@@ -29,6 +29,13 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), same guide
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")  # HBM bytes per launch from rocprofv3 --pmc
+
+TRAIN_WORKLOADS = {
+    # BASELINE config 4: DDP training on synthetic 5-species 256-atom frames, l_max=2, batch=32 per rank
+    "train256": dict(n_atoms=256, n_species=5, batch=32, l_max=2, num_features=64, num_layers=3),
+}
 
 WORKLOADS = {
     # name: (box builder kwargs, model kwargs)
@@ -105,12 +112,82 @@ def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
     }
 
 
+def train_bench(args, world, rank, device, distributed):
+    """BASELINE config 4: force-matching training step (forward, double backward, flat gradient all-reduce over
+    RCCL, Adam) on `batch` random frames per rank.  Metric: atoms x optimizer-steps / s, aggregate over ranks."""
+    import torch.distributed as dist
+
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.train import SimpleDDPStrategy
+    from nequip_amd.utils import synthetic as syn
+
+    w = TRAIN_WORKLOADS[args.workload]
+    frames = []
+    for f in range(w["batch"]):
+        pos, types, cell, names = syn.random_frame(w["n_atoms"], w["n_species"], seed=1000 * rank + f)
+        frames.append(syn.make_data(pos, types, 4.5, cell))
+    data = AtomicDataDict.to_device(AtomicDataDict.batched_from_list(frames), device)
+    n_atoms = data["pos"].shape[0]
+    n_edges = data["edge_index"].shape[1]
+    gen = torch.Generator().manual_seed(rank)
+    f_target = torch.randn(n_atoms, 3, generator=gen, dtype=torch.float64).to(device)
+    e_target = torch.randn(w["batch"], 1, generator=gen, dtype=torch.float64).to(device)
+    model = NequIPGNNModel(
+        seed=0, model_dtype="float32", r_max=4.5, type_names=names, num_layers=w["num_layers"], l_max=w["l_max"],
+        parity=False, num_features=w["num_features"], radial_mlp_depth=1, radial_mlp_width=128,
+        avg_num_neighbors=n_edges / n_atoms, per_type_energy_scales=1.0, per_type_energy_shifts=0.0,
+    ).to(device).train()
+    strategy = SimpleDDPStrategy(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(dict(data))
+        loss = (out["forces"] - f_target).square().mean() + (out["total_energy"] - e_target).square().mean()
+        (loss * strategy.world_size).backward()  # nequip/train/lightning.py:259-266
+        strategy.post_backward(loss)
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "atom-optimizer-steps/s (DDP force-matching training)",
+            "value": world * n_atoms * args.steps / elapsed, "unit": "atom-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['batch']} frames x {w['n_atoms']} atoms per rank "
+                       f"({n_edges} edges), {w['n_species']} species, l_max={w['l_max']}, {w['num_features']} features, "
+                       "energy+force MSE loss, Adam, flat gradient all-reduce (SimpleDDP)",
+                       "parallelism": f"dp{world}", "final_loss": float(loss)},
+        }))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="water10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="water10k", choices=sorted(WORKLOADS) + sorted(TRAIN_WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-steps", type=int, default=3, help="eager steps instrumented with HIP events for `roofline`")
@@ -133,6 +210,9 @@ def main():
     from nequip_amd.data import AtomicDataDict
     from nequip_amd.nn import topology_cache
     from nequip_amd.utils import ktimer
+
+    if args.workload in TRAIN_WORKLOADS:
+        return train_bench(args, world, rank, device, distributed)
 
     w = WORKLOADS[args.workload]
     data_cpu, names = build_box(w, seed=rank)
@@ -222,18 +302,36 @@ def main():
         if kernels:
             dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
             name, s = dom
-            roofline = {
-                "bound": "hbm",
-                "kernel": name,
-                "achieved": s["gbps"],
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": s["gbps"] / HBM_PEAK_GBPS,
-                "traffic": None,
-                "avg_launch_ms": s["avg_ms"],
-                "algorithmic_bytes_per_launch": s["bytes_per_call"],
-                "launches_per_step": s["calls"] / max(args.kernel_steps, 1),
-            }
+            traffic = None
+            try:  # per-launch HBM bytes of this kernel from the committed PMC passes (scripts/profile.sh), if present
+                pmc = json.load(open(PMC_SUMMARY))["bench_kernels"]
+                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+            if s.get("flops_per_call", 0) > 0 and name.startswith("radial_mlp"):
+                roofline = {
+                    "bound": "mfma", "kernel": name, "achieved": s["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": s["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                    "avg_launch_ms": s["avg_ms"], "algorithmic_flops_per_launch": s["flops_per_call"],
+                    "algorithmic_bytes_per_launch": s["bytes_per_call"],
+                    "launches_per_step": s["calls"] / max(args.kernel_steps, 1),
+                }
+            else:
+                roofline = {
+                    "bound": "hbm", "kernel": name, "achieved": s["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": s["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": s["avg_ms"],
+                    "algorithmic_bytes_per_launch": s["bytes_per_call"],
+                    "launches_per_step": s["calls"] / max(args.kernel_steps, 1),
+                }
+            # the hottest HBM-bound hand-written kernel as well (the tensor-product/scatter family)
+            tp = {k: v for k, v in kernels.items() if k.startswith("tp_")}
+            if tp:
+                tname, ts = max(tp.items(), key=lambda kv: kv[1]["total_ms"])
+                roofline["tp_scatter"] = {
+                    "bound": "hbm", "kernel": tname, "achieved": ts["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ts["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ts["avg_ms"],
+                    "algorithmic_bytes_per_launch": ts["bytes_per_call"],
+                }
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
