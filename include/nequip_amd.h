@@ -226,8 +226,9 @@ int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0
  *   FullyConnectedTensorProduct with scalar node attributes (interaction_block.py:142-146,175; weights
  *   pre-contracted per atom type by the caller) and the residual add `x + sc` (:203-204):
  *     out[z, ob, w, m] = scale * sum_{(ib->ob)} sum_u x[z, ib, u, m] * W[type(z)][ib->ob][u, w]  (+ addend[z,...])
- *   mul_ir layout.  chunk_table: int32 records {o_off, d, mul_out, c0, instr_begin, instr_end, 0, 0} (one per
- *   64-channel chunk of an output irrep block, every output element covered exactly once); instr_table: int32
+ *   mul_ir layout.  chunk_table: int32 records {o_off, d, mul_out, c0, instr_begin, instr_end, width, 0} (one per
+ *   `chunk_width`-channel chunk of an output irrep block, every output element covered exactly once; chunk_width
+ *   128 + float32 runs on fp32 MFMA, 64 on the VALU kernel that also serves float64); instr_table: int32
  *   records {x_off, mul_in, w_off, 0} ([mul_in, mul_out] row-major matrix at weights + type*weight_stride + w_off).
  *   atom_types (int64 [N]) is required iff n_types > 1.  The backward w.r.t. x is the same call with transposed
  *   tables/weights.  All tables are device pointers.
@@ -239,7 +240,7 @@ int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0
 int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
                     int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
-                    double scale, nqa_stream stream);
+                    double scale, int32_t chunk_width, nqa_stream stream);
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
              const void* seg_table, int32_t n_segs, const void* blk_table, int32_t n_blks, int32_t num_scalars,
              int32_t num_gates, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);

@@ -24,9 +24,9 @@ namespace nqa {
 
 constexpr int kNZ = 4;  // atoms per workgroup
 
-struct NodeChunk {  // one 64-channel chunk of one output irrep block
+struct NodeChunk {  // one chunk of `width` channels (64: VALU kernel, 128: MFMA kernel) of one output irrep block
   int32_t o_off, d, mul_out, c0;
-  int32_t instr_begin, instr_end, pad0, pad1;
+  int32_t instr_begin, instr_end, width, pad1;
 };
 struct NodeInstr {  // one (input block -> output block) weight matrix [mul_in, mul_out], row-major
   int32_t x_off, mul_in, w_off, pad;
@@ -163,6 +163,95 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs<T
       case 9: node_linear_chunk<T, 9>(a, ch, xs, tz, z0, lane); break;
       default: break;
     }
+  }
+}
+
+// ---- float32 on the matrix cores ---------------------------------------------------------------------------------
+// Transposed product  D[i = w][j = (z, m)] = sum_u A[i][u] B[u][j]  on v_mfma_f32_32x32x2_f32 (exact fp32):
+//   A[i = w][k = u]   = W[u][w]               weight rows, coalesced global loads (L2 resident), one value per lane
+//   B[k = u][j = z,m] = x[z, x_off + u*d + m]  node rows straight from global/L1 (each lane walks its own row)
+// A wavefront owns floor(32/d) atoms (their d components fill the 32 columns) and up to four 32-channel row tiles of
+// one output block, so every B value feeds up to four MFMAs.  No LDS, no barriers; masks handle ragged edges
+// (odd mul, mul_out not a multiple of 32, partial atom groups) and, for the per-type self-connection, columns whose
+// atom type differs from the weight set being applied.  (A register-double-buffered variant of the batch loop was
+// measured slower -- 0.85 vs 0.69 ms per cfg-3 step -- and is not used.)
+using f32x16n = __attribute__((ext_vector_type(16))) float;
+
+template <int D>
+__device__ __forceinline__ void node_linear_mfma_item(const NodeLinearArgs<float>& a, const NodeChunk& ch, int64_t g,
+                                                      int lane) {
+  constexpr int NZT = 32 / D;
+  constexpr int TB = 8;  // k-pairs per register batch
+  const int half = lane >> 5, j = lane & 31;
+  const int zl = j / D, m = j - zl * D;
+  const int64_t z = g * NZT + zl;
+  const bool col_ok = (zl < NZT) && (z < a.N);
+  const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
+  const int cw = min(ch.width, ch.mul_out - ch.c0);
+  const int nwt = (cw + 31) >> 5;  // 32-channel row tiles in this chunk (<= 4)
+  f32x16n acc[4];
+#pragma unroll
+  for (int wt = 0; wt < 4; ++wt) acc[wt] = (f32x16n){0};
+  for (int q = ch.instr_begin; q < ch.instr_end; ++q) {
+    const NodeInstr ins = a.instr[q];
+    const int K = ins.mul_in;
+    const float* __restrict__ xrow = a.x + (col_ok ? z : 0) * a.din + ins.x_off + m;
+    for (int t = 0; t < a.n_types; ++t) {
+      const float* __restrict__ wbase = a.w + (int64_t)t * a.wstride + ins.w_off + ch.c0 + j;
+      const bool bsel = col_ok && (a.n_types == 1 || tzj == t);
+      for (int k0 = 0; k0 < K; k0 += 2 * TB) {
+        float bq[TB], aq[TB][4];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int u = k0 + 2 * i + half;
+          const bool uok = u < K;
+          bq[i] = (bsel && uok) ? xrow[(int64_t)u * D] : 0.f;
+#pragma unroll
+          for (int wt = 0; wt < 4; ++wt)
+            aq[i][wt] = (uok && wt < nwt && (wt * 32 + j) < cw) ? wbase[(int64_t)u * ch.mul_out + wt * 32] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+#pragma unroll
+          for (int wt = 0; wt < 4; ++wt)
+            if (wt < nwt) acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][wt], bq[i], acc[wt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (col_ok) {
+    const int64_t obase = z * a.dout + ch.o_off + m;
+#pragma unroll
+    for (int wt = 0; wt < 4; ++wt) {
+      if (wt >= nwt) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int wl = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (wl < cw) {
+          const int64_t o = obase + (int64_t)(ch.c0 + wl) * D;
+          float v = a.scale * acc[wt][r];
+          if (a.addend != nullptr) v += a.addend[o];
+          a.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void node_linear_mfma_kernel(const NodeLinearArgs<float> a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const NodeChunk ch = a.chunks[blockIdx.y];
+  const int64_t g = (int64_t)blockIdx.x * 4 + wv;
+  const int nzt = 32 / ch.d;
+  if (g * nzt >= a.N) return;
+  switch (ch.d) {
+    case 1: node_linear_mfma_item<1>(a, ch, g, lane); break;
+    case 3: node_linear_mfma_item<3>(a, ch, g, lane); break;
+    case 5: node_linear_mfma_item<5>(a, ch, g, lane); break;
+    case 7: node_linear_mfma_item<7>(a, ch, g, lane); break;
+    case 9: node_linear_mfma_item<9>(a, ch, g, lane); break;
+    default: break;
   }
 }
 
@@ -304,7 +393,13 @@ extern "C" {
 int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
                     int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
-                    double scale, nqa_stream stream) {
+                    double scale, int32_t chunk_width, nqa_stream stream) {
+  // chunk_width 128: float32 tables for the MFMA kernel; 64: tables for the VALU kernel (float64, or float32 by choice)
+  const bool use_mfma = dtype == NQA_F32 && chunk_width == 128;
+  if (chunk_width != 64 && chunk_width != 128) {
+    set_error("nqa_node_linear: chunk_width must be 64 or 128");
+    return NQA_ERR_INVALID;
+  }
   if (dtype != NQA_F32 && dtype != NQA_F64) {
     set_error("nqa_node_linear: unsupported dtype");
     return NQA_ERR_UNSUPPORTED;
@@ -341,10 +436,18 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     a.wstride = weight_stride;
     a.N = num_nodes;
     a.scale = (float)scale;
-    if (smem > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(node_linear_kernel<float>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(node_linear_kernel<float>, grid, dim3(256), smem, s, a);
+    if (use_mfma) {
+      // grid.x is sized for the irrep with the fewest atoms per wavefront (d = 9 -> 3 atoms); surplus wavefronts of
+      // chunks with smaller d exit immediately
+      const int64_t groups = (num_nodes + 2) / 3;
+      const dim3 mgrid((unsigned)((groups + 3) / 4), (unsigned)n_chunks);
+      hipLaunchKernelGGL(node_linear_mfma_kernel, mgrid, dim3(256), 0, s, a);
+    } else {
+      if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(node_linear_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(node_linear_kernel<float>, grid, dim3(256), smem, s, a);
+    }
   } else {
     NodeLinearArgs<double> a{};
     a.x = static_cast<const double*>(x);

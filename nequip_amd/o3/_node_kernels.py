@@ -52,11 +52,13 @@ class NodeLinearMeta:
             off += self.irreps_in[i].mul * self.irreps_out[o].mul
         self.wstride = off
         # transposed weights: same instruction order, each [mul_out, mul_in]
-        self.fwd = self._tables(self.irreps_out, out_off, in_off, self.irreps_in, by_out=True)
-        self.bwd = self._tables(self.irreps_in, in_off, out_off, self.irreps_out, by_out=False)
+        self.fwd = self._tables(self.irreps_out, out_off, in_off, self.irreps_in, True, 64)
+        self.bwd = self._tables(self.irreps_in, in_off, out_off, self.irreps_out, False, 64)
+        self.fwd128 = self._tables(self.irreps_out, out_off, in_off, self.irreps_in, True, 128)
+        self.bwd128 = self._tables(self.irreps_in, in_off, out_off, self.irreps_out, False, 128)
         self._dev = {}
 
-    def _tables(self, side_out: Irreps, off_out, off_in, side_in: Irreps, by_out: bool):
+    def _tables(self, side_out: Irreps, off_out, off_in, side_in: Irreps, by_out: bool, width: int):
         chunks: List[Tuple[int, ...]] = []
         instr: List[Tuple[int, ...]] = []
         for b, (mul_o, ir) in enumerate(side_out):
@@ -68,14 +70,14 @@ class NodeLinearMeta:
                 if tgt == b:
                     instr.append((off_in[srcb], side_in[srcb].mul, self.w_off[k], 0))
             end = len(instr)
-            for c0 in range(0, mul_o, 64):
-                chunks.append((off_out[b], ir.dim, mul_o, c0, begin, end, 0, 0))
+            for c0 in range(0, mul_o, width):
+                chunks.append((off_out[b], ir.dim, mul_o, c0, begin, end, width, 0))
         return chunks, instr
 
-    def device_tables(self, device, which: str):
-        key = (str(device), which)
+    def device_tables(self, device, which: str, width: int = 64):
+        key = (str(device), which, width)
         if key not in self._dev:
-            chunks, instr = self.fwd if which == "fwd" else self.bwd
+            chunks, instr = getattr(self, which + ("128" if width == 128 else ""))
             ct = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 8).to(device)
             it = torch.tensor(instr if instr else [(0, 0, 0, 0)], dtype=torch.int32).reshape(-1, 4).to(device)
             self._dev[key] = (ct, len(chunks), it)
@@ -93,7 +95,8 @@ class NodeLinearMeta:
 
 def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale: float):
     lib = _lib.load()
-    ct, nchunks, it = meta.device_tables(x.device, which)
+    width = 128 if x.dtype == torch.float32 else 64  # float32: fp32-MFMA kernel; float64: VALU kernel
+    ct, nchunks, it = meta.device_tables(x.device, which, width)
     din, dout = (meta.din, meta.dout) if which == "fwd" else (meta.dout, meta.din)
     N = x.shape[0]
     out = torch.empty((N, dout), dtype=x.dtype, device=x.device)
@@ -101,7 +104,7 @@ def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale
     with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
         rc = lib.nqa_node_linear(
             _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types), _ptr(ct), nchunks, _ptr(it),
-            wp.shape[0], wp.shape[1], din, dout, N, float(scale), _stream(x.device),
+            wp.shape[0], wp.shape[1], din, dout, N, float(scale), width, _stream(x.device),
         )  # fmt: skip
     _lib.check(rc, "nqa_node_linear")
     return out
