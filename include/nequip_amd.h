@@ -144,6 +144,21 @@ int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t d
                          const int32_t* rowptr_src, const int32_t* edge_id_src, const int32_t* dst_sorted,
                          void* grad_x, int64_t num_nodes, int64_t num_edges, nqa_stream stream);
 
+/* All three gradients of the op in one pass over grad_out (same maths as the two calls above, i.e. the
+ * autograd of nequip/nn/_tp_scatter_base.py:77-120 w.r.t. x, edge_attr and the weights): the edge kernel
+ * (dst-CSR, grad_out[dst] resident in registers) additionally emits each edge's contribution to
+ * grad_x[src(e)] as a row of `workspace`; a second kernel sums those rows per source node through the
+ * src-CSR (rowptr_src, edge_id_src) -- deterministic, no atomics, and grad_out rows are never gathered
+ * per edge.  grad_w, grad_y and grad_x are all required (callers needing fewer use the calls above).  Only plans with a structure-specialised
+ * kernel (NQA_PLAN_HAS_SPECIALIZED) in float32 support it: nqa_tp_bwd_fused_workspace_bytes returns -1
+ * otherwise and the caller uses nqa_tp_scatter_bwd_edge + nqa_tp_scatter_bwd_x. */
+int64_t nqa_tp_bwd_fused_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges);
+int nqa_tp_scatter_bwd_fused(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                             const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                             const int32_t* edge_id_dst, const int32_t* src_sorted, const int32_t* rowptr_src,
+                             const int32_t* edge_id_src, void* grad_w, void* grad_y, void* grad_x, void* workspace,
+                             int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, nqa_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Edge vectors: replaces with_edge_vectors_ (nequip/nn/utils.py:68-118),
  *   edge_vec[e] = pos[edge_src[e]] - pos[edge_dst[e]] (+ edge_cell_shift[e] @ cell[batch[edge_dst[e]]]),

@@ -63,6 +63,13 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         + [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p],
     ),
+    "nqa_tp_bwd_fused_workspace_bytes": (c_int64, [c_void_p, c_int32, c_int64]),
+    "nqa_tp_scatter_bwd_fused": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]  # plan, image, dtype, x, y, w, grad_out
+        + [c_void_p] * 5  # rowptr_dst, edge_id_dst, src_sorted, rowptr_src, edge_id_src
+        + [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p],
+    ),
     "nqa_tp_scatter_bwd_x": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -136,14 +136,25 @@ def _emit(st: Structure) -> str:
     def decl_y(indent, sfx=""):
         return [f"{indent}T yb{j}{sfx}[{2 * st.in2_ls[j] + 1}];" for j in used_y]
 
+    # Addressing: every row base (x[src], w[e], y[e], g[dst]) is wave-uniform (scalar registers); the per-lane part is a
+    # loop-invariant 32-bit element offset computed once from the *clamped* channel uc = min(u, mul-1), so loads need
+    # no predication (lanes with u >= mul read channel mul-1 and never store).
+    def lane_offsets(indent, want_x=True, want_g=False):
+        out = [f"{indent}const unsigned ucb = (unsigned)(u < mul ? u : mul - 1) * (unsigned)sizeof(T);"]
+        if want_x:
+            for b in used_blocks:
+                out.append(f"{indent}const unsigned xo{b} = (unsigned)(mul * {xpre[b]}) * (unsigned)sizeof(T) + ucb * {2 * st.in1_ls[b] + 1}u;")
+        if want_g:
+            for sl in sorted({s_ for _, _, s_ in st.instr}):
+                out.append(f"{indent}const unsigned go{sl} = (unsigned)(mul * {opre[sl]}) * (unsigned)sizeof(T) + ucb * {2 * st.out_ls[sl] + 1}u;")
+        return out
+
     def load_x(indent, row, sfx="", decl=True):
         out = decl_x(indent, sfx) if decl else []
         for b in used_blocks:
             d = 2 * st.in1_ls[b] + 1
-            out.append(f"{indent}{{ const T* __restrict__ p = {row} + (int64_t)mul * {xpre[b]} + (int64_t)u * {d};")
             for i in range(d):
-                out.append(f"{indent}  xb{b}{sfx}[{i}] = act ? p[{i}] : T(0);")
-            out.append(f"{indent}}}")
+                out.append(f"{indent}xb{b}{sfx}[{i}] = spec_at({row}, xo{b})[{i}];")
         return out
 
     def load_y(indent, row, sfx="", decl=True):
@@ -158,7 +169,7 @@ def _emit(st: Structure) -> str:
         out = [f"{indent}T wv{sfx}[kNP];"] if decl else []
         for p in range(NP):
             c = f"T({coeff[p]!r}) * " if scale else ""
-            out.append(f"{indent}wv{sfx}[{p}] = act ? {c}{row}[(int64_t)mul * {p}] : T(0);")
+            out.append(f"{indent}wv{sfx}[{p}] = {c}*spec_at({row} + (unsigned)(mul * {p}), ucb);")
         return out
 
     # ------------------------------------------------------------------ forward
@@ -173,10 +184,11 @@ def _emit(st: Structure) -> str:
     A("  if (WPN == 1) { item = (int64_t)bid * 4 + wid; wsub = 0; } else { item = bid; wsub = wid; }")
     A("  const bool valid = item < (int64_t)a.N * nchunk;")
     A("  if (WPN == 1 && !valid) return;")
-    A("  const int node = valid ? (int)(item / nchunk) : 0;")
+    A("  const int node = spec_uniform(valid ? (int)(item / nchunk) : 0);")
     A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
     A("  const int u = chunk * 64 + lane;")
     A("  const bool act = valid && (u < mul);")
+    L.extend(lane_offsets("  "))
     A(f"  T acc[kOD];")
     A("#pragma unroll")
     A("  for (int k = 0; k < kOD; ++k) acc[k] = T(0);")
@@ -187,7 +199,7 @@ def _emit(st: Structure) -> str:
 
     def fwd_loads(sfx, e, sv):
         out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
-               f"      const T* __restrict__ wr = a.w + (int64_t){e} * a.wn + u;",
+               f"      const T* __restrict__ wr = a.w + (int64_t){e} * a.wn;",
                f"      const T* __restrict__ yr = a.y + (int64_t){e} * kS;"]
         out += load_w("      ", "wr", sfx=sfx, decl=False)
         out += load_x("      ", "xr", sfx=sfx, decl=False)
@@ -209,17 +221,17 @@ def _emit(st: Structure) -> str:
     A("  int idx = beg + wsub;")
     A("  int nidx = idx + WPN;")
     A("  int e0 = 0, s0 = 0, e1 = 0, s1 = 0;")
-    A("  if (idx < end) { e0 = a.eid[idx]; s0 = a.nbr[idx]; }")
+    A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); }")
     A("  if (idx < end) {")
     L.extend(fwd_loads("A", "e0", "s0"))
     A("  }")
-    A("  if (nidx < end) { e1 = a.eid[nidx]; s1 = a.nbr[nidx]; }")
+    A("  if (nidx < end) { e1 = spec_uniform(a.eid[nidx]); s1 = spec_uniform(a.nbr[nidx]); }")
     A("  while (idx < end) {")
     A("    if (nidx < end) {")
     L.extend(fwd_loads("B", "e1", "s1"))
     A("    }")
     A("    int nn = nidx + WPN;")
-    A("    if (nn < end) { e0 = a.eid[nn]; s0 = a.nbr[nn]; }")
+    A("    if (nn < end) { e0 = spec_uniform(a.eid[nn]); s0 = spec_uniform(a.nbr[nn]); }")
     L.extend(fwd_compute("A"))
     A("    idx = nidx; nidx = nn;")
     A("    if (idx >= end) break;")
@@ -227,7 +239,7 @@ def _emit(st: Structure) -> str:
     L.extend(fwd_loads("A", "e0", "s0"))
     A("    }")
     A("    nn = nidx + WPN;")
-    A("    if (nn < end) { e1 = a.eid[nn]; s1 = a.nbr[nn]; }")
+    A("    if (nn < end) { e1 = spec_uniform(a.eid[nn]); s1 = spec_uniform(a.nbr[nn]); }")
     L.extend(fwd_compute("B"))
     A("    idx = nidx; nidx = nn;")
     A("  }")
@@ -264,7 +276,10 @@ def _emit(st: Structure) -> str:
     A("}")
 
     # ------------------------------------------------------------------ backward (edge operands)
-    A("template <typename T, int WPN>")
+    # One contraction serves both edge gradients:  B^p_j = sum_ik C^p_ijk x_i g_k  gives  gw_p = sum_j y_j B^p_j  and
+    # gy_j += w_p B^p_j.  FUSED additionally forms A^p_i = sum_jk C^p_ijk y_j g_k and emits the edge's contribution
+    # w_p A^p_i to grad_x[src] (grad_out[dst] is already in registers), summed per source node afterwards.
+    A("template <typename T, int WPN, bool FUSED, bool GW, bool GY>")
     A("__global__ __launch_bounds__(256) void bwd_edge_kernel(const SpecArgs<T> a) {")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -274,7 +289,7 @@ def _emit(st: Structure) -> str:
     A("  const int64_t item = witem / WPN;")
     A("  const int wsub = (int)(witem - item * WPN);")
     A("  if (item >= (int64_t)a.N * nchunk) return;")
-    A("  const int node = (int)(item / nchunk);")
+    A("  const int node = spec_uniform((int)(item / nchunk));")
     A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
     A("  const int u = chunk * 64 + lane;")
     A("  const bool act = u < mul;")
@@ -283,47 +298,71 @@ def _emit(st: Structure) -> str:
     A("  T gv[kOD];")
     A("  {")
     A("    const T* __restrict__ gb = a.g + (int64_t)node * a.dout;")
-    for s in range(NS):
-        d3 = 2 * st.out_ls[s] + 1
-        c = slot_coeff[s] if slot_coeff[s] is not None else 0.0
+    for s_ in range(NS):
+        d3 = 2 * st.out_ls[s_] + 1
+        c = slot_coeff[s_] if slot_coeff[s_] is not None else 0.0
         for k in range(d3):
-            A(f"    gv[{opre[s] + k}] = act ? T({c!r}) * gb[(int64_t)mul * {opre[s]} + (int64_t)u * {d3} + {k}] : T(0);")
+            A(f"    gv[{opre[s_] + k}] = act ? T({c!r}) * gb[(int64_t)mul * {opre[s_]} + (int64_t)u * {d3} + {k}] : T(0);")
     A("  }")
-    A("  const bool need_gw = a.gw != nullptr;")
-    A("  const bool need_gy = a.gy != nullptr;")
+    L.extend(lane_offsets("  "))
     A("  int idx = beg + wsub;")
-    A("  int e = a.eid[idx], s = a.nbr[idx];")
+    A("  int e = spec_uniform(a.eid[idx]), s = spec_uniform(a.nbr[idx]);")
     A("  while (idx < end) {")
     A("    const int nidx = idx + WPN;")
     A("    int e_n = 0, s_n = 0;")
-    A("    if (nidx < end) { e_n = a.eid[nidx]; s_n = a.nbr[nidx]; }")
+    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); }")
     A("    const T* __restrict__ xr = a.x + (int64_t)s * a.din;")
     A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
+    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn;")
     L.extend(load_x("    ", "xr"))
-    A("    if (need_gw) {")
-    L.extend(load_y("      ", "yr"))
-    A("      T* __restrict__ gwr = a.gw + (int64_t)e * a.wn + u;")
-    for p, (b, j, s) in enumerate(st.instr):
-        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
-        d3 = 2 * l3 + 1
-        A(f"      {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}, yb{j}, t);")
-        terms = " + ".join(f"t[{k}] * gv[{opre[s] + k}]" for k in range(d3))
-        A(f"        const T r = {terms};")
-        A(f"        if (act) gwr[(int64_t)mul * {p}] = r; }}")
+    A("    T wv[kNP];")
+    A("    if (GY || FUSED) {")
+    L.extend(load_w("      ", "wr", decl=False))
     A("    }")
-    A("    if (need_gy) {")
-    A("      const T* __restrict__ wr = a.w + (int64_t)e * a.wn + u;")
-    L.extend(load_w("      ", "wr"))
-    A(f"      T q[kS];")
+    L.extend(decl_y("    "))
+    A("    if (GW || FUSED) {")
+    L.extend(load_y("      ", "yr", decl=False))
+    A("    }")
+    A("    T rr[kNP];")
+    A("    T q[kS];")
     A("#pragma unroll")
-    A("      for (int j = 0; j < kS; ++j) q[j] = T(0);")
-    for p, (b, j, s) in enumerate(st.instr):
-        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
+    A("    for (int j = 0; j < kS; ++j) q[j] = T(0);")
+    for p, (b, j, s_) in enumerate(st.instr):
+        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s_]
         d2 = 2 * l2 + 1
-        A(f"      {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b}, gv + {opre[s]}, t);")
+        A(f"    {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b}, gv + {opre[s_]}, t);")
+        terms = " + ".join(f"t[{i}] * yb{j}[{i}]" for i in range(d2))
+        A(f"      if (GW) rr[{p}] = {terms};")
+        A("      if (GY) {")
         for i in range(d2):
             A(f"        q[{ypre[j] + i}] += wv[{p}] * t[{i}];")
         A("      }")
+        A("    }")
+    A("    if (FUSED) {")
+    A("      T gxa[kXD];")
+    A("#pragma unroll")
+    A("      for (int i = 0; i < kXD; ++i) gxa[i] = T(0);")
+    for p, (b, j, s_) in enumerate(st.instr):
+        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s_]
+        d1 = 2 * l1 + 1
+        A(f"      {{ T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}, gv + {opre[s_]}, t);")
+        for i in range(d1):
+            A(f"        gxa[{xpre[b] + i}] += wv[{p}] * t[{i}];")
+        A("      }")
+    A("      if (act) {")
+    A("        T* __restrict__ gxr = a.gxe + (int64_t)e * a.din;")
+    for i in range(XD):
+        A(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = gxa[{i}];")
+    A("      }")
+    A("    }")
+    A("    if (GW) {")
+    A("      if (act) {")
+    A("        T* __restrict__ gwr = a.gw + (int64_t)e * a.wn;")
+    for p in range(NP):
+        A(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
+    A("      }")
+    A("    }")
+    A("    if (GY) {")
     A("      T* __restrict__ gyr = a.gy + (int64_t)e * a.gy_stride + chunk * kS;")
     A("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")
     A("    }")
@@ -343,33 +382,32 @@ def _emit(st: Structure) -> str:
     A("  if (WPN == 1) { item = (int64_t)bid * 4 + wid; wsub = 0; } else { item = bid; wsub = wid; }")
     A("  const bool valid = item < (int64_t)a.N * nchunk;")
     A("  if (WPN == 1 && !valid) return;")
-    A("  const int node = valid ? (int)(item / nchunk) : 0;")
+    A("  const int node = spec_uniform(valid ? (int)(item / nchunk) : 0);")
     A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
     A("  const int u = chunk * 64 + lane;")
     A("  const bool act = valid && (u < mul);")
+    L.extend(lane_offsets("  ", want_x=False, want_g=True))
     A("  T acc[kXD];")
     A("#pragma unroll")
     A("  for (int i = 0; i < kXD; ++i) acc[i] = T(0);")
     A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
     A("  int idx = beg + wsub;")
     A("  int e = 0, d = 0;")
-    A("  if (idx < end) { e = a.eid[idx]; d = a.nbr[idx]; }")
+    A("  if (idx < end) { e = spec_uniform(a.eid[idx]); d = spec_uniform(a.nbr[idx]); }")
     A("  while (idx < end) {")
     A("    const int nidx = idx + WPN;")
     A("    int e_n = 0, d_n = 0;")
-    A("    if (nidx < end) { e_n = a.eid[nidx]; d_n = a.nbr[nidx]; }")
+    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); d_n = spec_uniform(a.nbr[nidx]); }")
     A("    const T* __restrict__ gr = a.g + (int64_t)d * a.dout;")
-    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn + u;")
+    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn;")
     A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
     L.extend(load_w("    ", "wr", scale=True))
     used_slots = sorted({s for _, _, s in st.instr})
     for s in used_slots:
         d3 = 2 * st.out_ls[s] + 1
         A(f"    T gs{s}[{d3}];")
-        A(f"    {{ const T* __restrict__ p = gr + (int64_t)mul * {opre[s]} + (int64_t)u * {d3};")
         for k in range(d3):
-            A(f"      gs{s}[{k}] = act ? p[{k}] : T(0);")
-        A("    }")
+            A(f"    gs{s}[{k}] = spec_at(gr, go{s})[{k}];")
     L.extend(load_y("    ", "yr"))
     for p, (b, j, s) in enumerate(st.instr):
         l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
@@ -404,6 +442,52 @@ def _emit(st: Structure) -> str:
     A("  }")
     A("}")
 
+    # ------------------------------------------------------------------ per-source-node sum of the fused rows
+    A("template <typename T>")
+    A("__global__ __launch_bounds__(256) void gx_rows_sum_kernel(const SpecArgs<T> a) {")
+    A("  const int lane = threadIdx.x & 63;")
+    A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+    A("  const int mul = a.mul;")
+    A("  const int nchunk = (mul + 63) >> 6;")
+    A("  const int64_t item = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+    A("  if (item >= (int64_t)a.N * nchunk) return;")
+    A("  const int node = spec_uniform((int)(item / nchunk));")
+    A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
+    A("  const int u = chunk * 64 + lane;")
+    A("  const bool act = u < mul;")
+    A("  T acc[kXD];")
+    A("#pragma unroll")
+    A("  for (int i = 0; i < kXD; ++i) acc[i] = T(0);")
+    A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
+    A("  const T* __restrict__ base = a.gxe + (act ? u : 0);")
+    A("  int idx = beg;")
+    A("  for (; idx + 4 <= end; idx += 4) {")
+    A("    const int e0 = a.eid[idx], e1 = a.eid[idx + 1], e2 = a.eid[idx + 2], e3 = a.eid[idx + 3];")
+    A("    T r0[kXD], r1[kXD], r2[kXD], r3[kXD];")
+    A("#pragma unroll")
+    A("    for (int i = 0; i < kXD; ++i) {")
+    A("      r0[i] = base[(int64_t)e0 * a.din + (int64_t)mul * i];")
+    A("      r1[i] = base[(int64_t)e1 * a.din + (int64_t)mul * i];")
+    A("      r2[i] = base[(int64_t)e2 * a.din + (int64_t)mul * i];")
+    A("      r3[i] = base[(int64_t)e3 * a.din + (int64_t)mul * i];")
+    A("    }")
+    A("#pragma unroll")
+    A("    for (int i = 0; i < kXD; ++i) acc[i] += (r0[i] + r1[i]) + (r2[i] + r3[i]);")
+    A("  }")
+    A("  for (; idx < end; ++idx) {")
+    A("    const int e0 = a.eid[idx];")
+    A("#pragma unroll")
+    A("    for (int i = 0; i < kXD; ++i) acc[i] += base[(int64_t)e0 * a.din + (int64_t)mul * i];")
+    A("  }")
+    A("  if (act) {")
+    A("    T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+    for b in range(NB):
+        d = 2 * st.in1_ls[b] + 1
+        for i in range(d):
+            A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = acc[{xpre[b] + i}];")
+    A("  }")
+    A("}")
+
     # ------------------------------------------------------------------ launchers + registration
     A("template <int WPN>")
     A("static int launch(int which, const SpecArgs<float>& a, hipStream_t stream) {")
@@ -412,7 +496,21 @@ def _emit(st: Structure) -> str:
     A("  if (items == 0) return 0;")
     A("  if (which == 1) {")
     A("    const int64_t blocks = (items * WPN + 3) / 4;")
-    A("    hipLaunchKernelGGL((bwd_edge_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);")
+    A("    const dim3 grid((unsigned)blocks), blk(256);")
+    A("    if (a.gxe != nullptr) {")
+    A("      if (a.gw == nullptr || a.gy == nullptr) return 1;")
+    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, true, true, true>), grid, blk, 0, stream, a);")
+    A("    } else if (a.gw != nullptr && a.gy != nullptr) {")
+    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, true>), grid, blk, 0, stream, a);")
+    A("    } else if (a.gw != nullptr) {")
+    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, false>), grid, blk, 0, stream, a);")
+    A("    } else if (a.gy != nullptr) {")
+    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, false, true>), grid, blk, 0, stream, a);")
+    A("    }")
+    A("    return 0;")
+    A("  }")
+    A("  if (which == 3) {")
+    A("    hipLaunchKernelGGL((gx_rows_sum_kernel<float>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);")
     A("    return 0;")
     A("  }")
     A("  const int64_t blocks = WPN == 1 ? (items + 3) / 4 : items;")

@@ -572,6 +572,83 @@ int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_
                                                     src_sorted, grad_w, grad_y, workspace, num_nodes, num_edges, s);
 }
 
+int64_t nqa_tp_bwd_fused_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges) {
+  if (plan == nullptr || num_edges < 0 || !use_spec(plan, dtype)) return -1;
+  const int nchunk = (plan->uniform_mul + 63) / 64;
+  const int64_t ypart = nchunk > 1 ? num_edges * (int64_t)plan->dim_in2 * nchunk * 4 : 0;
+  return ((ypart + 255) & ~(int64_t)255) + num_edges * (int64_t)plan->dim_in1 * 4;
+}
+
+int nqa_tp_scatter_bwd_fused(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                             const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                             const int32_t* edge_id_dst, const int32_t* src_sorted, const int32_t* rowptr_src,
+                             const int32_t* edge_id_src, void* grad_w, void* grad_y, void* grad_x, void* workspace,
+                             int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, nqa_stream stream) {
+  int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_fused");
+  if (rc != NQA_OK) return rc;
+  if (!use_spec(plan, dtype)) {
+    set_error("nqa_tp_scatter_bwd_fused: no structure-specialised float32 kernel for this plan");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if ((num_nodes > 0 && (!grad_x || !rowptr_dst || !rowptr_src)) ||
+      (num_edges > 0 &&
+       (!x || !y || !w || !grad_out || !edge_id_dst || !src_sorted || !edge_id_src || !grad_w || !grad_y))) {
+    set_error("nqa_tp_scatter_bwd_fused: NULL operand");
+    return NQA_ERR_INVALID;
+  }
+  if (num_edges > 0 &&
+      (workspace == nullptr || workspace_bytes < nqa_tp_bwd_fused_workspace_bytes(plan, dtype, num_edges))) {
+    set_error("nqa_tp_scatter_bwd_fused: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  if (num_nodes == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SpecArgs<float> a{};
+  spec_fill(a, plan, num_nodes);
+  const int nchunk = (plan->uniform_mul + 63) / 64;
+  const int64_t ypart = nchunk > 1 ? num_edges * (int64_t)plan->dim_in2 * nchunk * 4 : 0;
+  float* gxe = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((ypart + 255) & ~(int64_t)255));
+  if (num_edges > 0) {
+    a.x = static_cast<const float*>(x);
+    a.y = static_cast<const float*>(y);
+    a.w = static_cast<const float*>(w);
+    a.g = static_cast<const float*>(grad_out);
+    a.gw = static_cast<float*>(grad_w);
+    a.gxe = gxe;
+    a.rowptr = rowptr_dst;
+    a.eid = edge_id_dst;
+    a.nbr = src_sorted;
+    if (grad_y != nullptr) {
+      if (nchunk == 1) {
+        a.gy = static_cast<float*>(grad_y);
+        a.gy_stride = plan->dim_in2;
+      } else {
+        a.gy = static_cast<float*>(workspace);
+        a.gy_stride = plan->dim_in2 * nchunk;
+      }
+    }
+    plan->spec->launch(1, spec_wpn(plan, num_nodes), a, s);
+    rc = check_launch("nqa_tp_scatter_bwd_fused(edge)");
+    if (rc != NQA_OK) return rc;
+    if (grad_y != nullptr && nchunk > 1) {
+      const int64_t total = num_edges * (int64_t)plan->dim_in2;
+      hipLaunchKernelGGL(spec_gy_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                         static_cast<const float*>(workspace), static_cast<float*>(grad_y), plan->dim_in2, nchunk,
+                         total);
+      rc = check_launch("nqa_tp_scatter_bwd_fused(reduce)");
+      if (rc != NQA_OK) return rc;
+    }
+  }
+  SpecArgs<float> b{};
+  spec_fill(b, plan, num_nodes);
+  b.gxe = gxe;
+  b.out = static_cast<float*>(grad_x);
+  b.rowptr = rowptr_src;
+  b.eid = edge_id_src;
+  plan->spec->launch(3, 1, b, s);
+  return check_launch("nqa_tp_scatter_bwd_fused(sum)");
+}
+
 int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
                          const void* grad_out, const int32_t* rowptr_src, const int32_t* edge_id_src,
                          const int32_t* dst_sorted, void* grad_x, int64_t num_nodes, int64_t num_edges,

@@ -17,6 +17,7 @@ struct SpecArgs {
   T* __restrict__ out;       // fwd: [N, dout]; bwd_x: [N, din]
   T* __restrict__ gw;        // [E, wn] or null
   T* __restrict__ gy;        // [E, gy_stride] or null (gy itself when mul <= 64, else per-chunk partials)
+  T* __restrict__ gxe;       // fused backward: per-edge grad_x contributions [E, xd, mul] (bwd_edge writes, sum reads)
   const int32_t* __restrict__ rowptr;
   const int32_t* __restrict__ eid;
   const int32_t* __restrict__ nbr;
@@ -26,7 +27,7 @@ struct SpecArgs {
   int32_t gy_stride;
 };
 
-// which: 0 = fwd, 1 = bwd_edge, 2 = bwd_x;  wpn: requested wavefronts per (node, chunk)
+// which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows;  wpn: requested wavefronts per (node, chunk)
 using SpecLaunchFn = int (*)(int which, int wpn, const SpecArgs<float>& a, hipStream_t stream);
 
 struct SpecEntry {
@@ -63,6 +64,18 @@ __device__ __forceinline__ unsigned spec_xcd_remap(unsigned b, unsigned nblk) {
   return base + idx;
 }
 
+// Address = wave-uniform row base (scalar registers) + per-lane 32-bit byte offset: lets the compiler use the
+// `global_load/store v, v_off, s[base:base+1] offset:imm` form (no 64-bit vector address arithmetic per access).
+template <typename T>
+__device__ __forceinline__ T* spec_at(T* uniform_base, unsigned lane_bytes) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(uniform_base) + lane_bytes);
+}
+template <typename T>
+__device__ __forceinline__ const T* spec_at(const T* uniform_base, unsigned lane_bytes) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) + lane_bytes);
+}
+__device__ __forceinline__ int spec_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // ---- wave64 reductions -------------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wavefront with DPP row operations (no LDS traffic):
 //   quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8  -> every lane holds its 16-lane row sum
@@ -95,10 +108,10 @@ __device__ __forceinline__ double spec_wave_sum(double v) {
   return v;
 }
 
-// Reduce K per-lane values over the wavefront and store the K sums to dst[0..K) (one store per value by the
-// lane whose index equals the value index, so the K stores coalesce into one transaction for K <= 64).
+// Reduce K per-lane values over the wavefront and store the K sums to dst[0..K).
+// Generic form: one full wave reduction per value (K * ~13 VALU instructions).
 template <typename T, int K>
-__device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, T* __restrict__ dst, int lane) {
+__device__ __forceinline__ void spec_wave_reduce_store_each(const T* __restrict__ q, T* __restrict__ dst, int lane) {
   T mine = T(0);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
@@ -106,6 +119,57 @@ __device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, 
     if (lane == j) mine = r;
   }
   if (lane < K) dst[lane] = mine;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float spec_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// One halving step of the transposing reduction: NIN values per lane -> (NIN+1)/2.  Lanes whose `bit` is clear keep
+// the even member of each pair and hand the odd one to their partner (lane ^ stride), and vice versa.
+template <int NIN, int STEP>
+__device__ __forceinline__ void spec_halve(const float* in, float* out, bool bit) {
+#pragma unroll
+  for (int m = 0; m < (NIN + 1) / 2; ++m) {
+    const float lo = in[2 * m];
+    const float hi = (2 * m + 1 < NIN) ? in[2 * m + 1] : 0.f;
+    const float keep = bit ? hi : lo;
+    const float send = bit ? lo : hi;
+    float got;
+    if (STEP == 0) got = spec_dpp<0xB1>(send);                       // quad_perm [1,0,3,2]: lane ^ 1
+    else if (STEP == 1) got = spec_dpp<0x4E>(send);                  // quad_perm [2,3,0,1]: lane ^ 2
+    else if (STEP == 2) got = spec_dpp<0x1B>(spec_dpp<0x141>(send));  // row_half_mirror . quad reverse: lane ^ 4
+    else got = spec_dpp<0x128>(send);                                // row_ror:8: lane ^ 8
+    out[m] = keep + got;
+  }
+}
+
+// float, K <= 16: transposing butterfly.  Four halving steps inside each 16-lane row leave lane r of every row with
+// the row-partial sum of value r; two gfx950 half-exchanges (v_permlane16_swap / v_permlane32_swap) then all-reduce
+// the four rows.  ~(3K + 10) VALU instructions instead of ~13K, and a single coalesced store.
+template <typename T, int K>
+__device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, T* __restrict__ dst, int lane) {
+  if constexpr (sizeof(T) != 4 || (K > 16)) {
+    spec_wave_reduce_store_each<T, K>(q, dst, lane);
+  } else {
+    constexpr int KA = (K + 1) / 2, KB = (KA + 1) / 2, KC = (KB + 1) / 2;
+    float a[KA], b[KB], c[KC], d[1];
+    spec_halve<K, 0>(q, a, (lane & 1) != 0);
+    spec_halve<KA, 1>(a, b, (lane & 2) != 0);
+    spec_halve<KB, 2>(b, c, (lane & 4) != 0);
+    spec_halve<KC, 3>(c, d, (lane & 8) != 0);
+    // all-reduce over the four rows.  v_permlane16_swap: odd rows of vdst <-> even rows of src; v_permlane32_swap: upper
+    // half of vdst <-> lower half of src; with vdst = src = r the two results hold complementary rows in every lane.
+    // (inline asm: two wait states are required between a VALU write of an operand and the swap.)
+    float r = d[0], r2 = d[0];
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r), "+v"(r2));
+    r += r2;
+    r2 = r;
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r), "+v"(r2));
+    r += r2;
+    if (lane < K) dst[lane] = r;
+  }
 }
 
 }  // namespace nqa

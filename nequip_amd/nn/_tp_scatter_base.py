@@ -18,6 +18,7 @@ three kernels.
 
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -48,6 +49,9 @@ class _Kernels:
         self.dim_out = plan.query(_lib.NQA_PLAN_DIM_OUT)
         self.weight_numel = plan.query(_lib.NQA_PLAN_WEIGHT_NUMEL)
         self.out_needs_zero = bool(plan.query(_lib.NQA_PLAN_OUT_NEEDS_ZERO))
+        # The fused backward trades the per-edge gather of grad_out rows (dim_out) and a second read of the weights for
+        # a per-edge row of grad_x contributions written and read once (2 * dim_in1): worth it for wide outputs only.
+        self.prefer_fused_bwd = (self.weight_numel + self.dim_out) >= 3 * self.dim_in1
 
     def _check(self, x, y, w, topo: EdgeTopology):
         N, E = topo.num_nodes, topo.num_edges
@@ -106,6 +110,36 @@ class _Kernels:
         _lib.check(rc, "nqa_tp_scatter_bwd_edge")
         return gw, gy
 
+    def bwd_fused(self, x, y, w, g, topo: EdgeTopology, need_gw: bool = True, need_gy: bool = True):
+        """(gx, gw, gy) in one pass over ``g`` (``nqa_tp_scatter_bwd_fused``), or None when the plan has no
+        structure-specialised float32 kernel (the caller then uses bwd_x + bwd_edge)."""
+        lib = _lib.load()
+        E, N = topo.num_edges, topo.num_nodes
+        ws_bytes = lib.nqa_tp_bwd_fused_workspace_bytes(self.plan.handle, _nqa_dtype(x.dtype), E)
+        if ws_bytes < 0:
+            return None
+        self._check(x, y, w, topo)
+        gx = torch.empty((N, self.dim_in1), dtype=x.dtype, device=x.device)
+        gw = torch.empty((E, self.weight_numel), dtype=x.dtype, device=x.device) if need_gw else None
+        gy = torch.empty((E, self.dim_in2), dtype=x.dtype, device=x.device) if need_gy else None
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        rowptr, eid, nbr = topo.by_dst
+        rowptr_s, eid_s, _ = topo.by_src
+        es = x.element_size()
+        # algorithmic bytes: w (+ gw, gy) once per edge, the per-edge grad_x rows written and read once, node rows once
+        nbytes = E * (es * (self.weight_numel + self.dim_in2 + 2 * self.dim_in1) + 24) + N * es * (
+            2 * self.dim_in1 + self.dim_out
+        )
+        nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused", nbytes):
+            rc = lib.nqa_tp_scatter_bwd_fused(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(rowptr_s), _ptr(eid_s), _ptr(gw), _ptr(gy), _ptr(gx),
+                _ptr(ws), ws_bytes, N, E, current_stream_ptr(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_bwd_fused")
+        return gx, gw, gy
+
     def bwd_x(self, y, w, g, topo: EdgeTopology) -> torch.Tensor:
         self._check(None, y, w, topo)
         lib = _lib.load()
@@ -148,8 +182,14 @@ class _TPScatterBwdFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, x, y, w, k: _Kernels, topo: EdgeTopology, need: Tuple[bool, bool, bool]):
         g = g.contiguous()
-        gx = k.bwd_x(y, w, g, topo) if need[0] else None
-        gw, gy = k.bwd_edge(x, y, w, g, topo, need_gw=need[2], need_gy=need[1])
+        fused = None
+        if need[0] and need[1] and need[2] and k.prefer_fused_bwd and os.environ.get("NQA_NO_FUSED_BWD", "") in ("", "0"):
+            fused = k.bwd_fused(x, y, w, g, topo, need_gw=need[2], need_gy=need[1])
+        if fused is not None:
+            gx, gw, gy = fused
+        else:
+            gx = k.bwd_x(y, w, g, topo) if need[0] else None
+            gw, gy = k.bwd_edge(x, y, w, g, topo, need_gw=need[2], need_gy=need[1])
         ctx.save_for_backward(g, x, y, w)
         ctx.k, ctx.topo = k, topo
         ctx.mark_non_differentiable(*[t for t, n in zip((gx, gy, gw), need) if not n and t is not None])

@@ -22,10 +22,13 @@ class NodeTypeEmbed(GraphModuleMixin, torch.nn.Module):
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         atom_types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)
-        embedding = self.embed_module(atom_types)
+        # eval mode: parameters are constants (same convention as o3.Linear) -- keeps autograd from carrying the
+        # position-independent embedding through every backward kernel when only forces are requested
+        table = self.embed_module.weight if self.training else self.embed_module.weight.detach()
+        embedding = torch.nn.functional.embedding(atom_types, table)
         data[AtomicDataDict.NODE_ATTRS_KEY] = embedding
         # node_attrs == table[types]: lets the self-connection contract its weights per type first
-        data["_nqa_node_attrs_table"] = self.embed_module.weight
+        data["_nqa_node_attrs_table"] = table
         if self.set_features:
             data[AtomicDataDict.NODE_FEATURES_KEY] = embedding
         return data

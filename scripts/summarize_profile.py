@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (kernel stats + PMC counter passes) into small files for profiles/."""
+"""Condense rocprofv3 output (kernel stats + separate PMC counter passes) into the small files kept under profiles/.
+
+usage: summarize_profile.py <gpurun_out/prof_TAG> <TAG>
+writes <dir>/<TAG>_kernel_stats_top40.csv and <dir>/<TAG>_pmc_summary.json:
+  "kernels":       per GPU kernel: dispatches, FETCH_SIZE_KB, WRITE_SIZE_KB (per dispatch) and corrected HBM bytes
+  "bench_kernels": the same bytes keyed by bench.py's HIP-event region names (what `roofline.traffic` reads)
+"""
 import csv
 import glob
 import json
@@ -9,30 +15,77 @@ import sys
 from collections import defaultdict
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-res = {}
+
+# bench.py region name -> substrings identifying the GPU kernels launched inside that region
+REGIONS = {  # region: (main kernel family, helper kernels that run once per launch)
+    "tp_fwd": (["::fwd_kernel<", "tp_fwd_kernel"], []),
+    "tp_bwd_edge": (["::bwd_edge_kernel<", "tp_bwd_edge_kernel"], ["spec_gy_reduce_kernel", "tp_ypart_reduce_kernel"]),
+    "tp_bwd_x": (["::bwd_x_kernel<", "tp_bwd_x_kernel"], []),
+    "tp_bwd_fused": (["::bwd_fused_kernel<"], ["edge_rows_sum_kernel", "spec_gy_reduce_kernel"]),
+    "radial_mlp_fwd": (["radial_mlp_fwd_kernel"], []),
+    "radial_mlp_bwd": (["radial_mlp_bwd_kernel"], ["radial_mlp_transpose_w1_kernel"]),
+    "node_linear": (["node_linear_kernel", "node_linear_mfma_kernel"], []),
+    "gate": (["gate_fwd_kernel", "gate_bwd_kernel"], []),
+    "edge_embed_fwd": (["edge_embed_fwd_kernel"], []),
+    "edge_embed_bwd": (["edge_embed_bwd_kernel"], []),
+    "edge_vectors": (["edge_vectors_fwd_kernel", "edge_vectors_bwd_kernel"], []),
+}
+
 stats = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    keep = []
-    for r in rows[:40]:
-        keep.append({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    keep = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+            for r in rows[:40]]
     with open(os.path.join(out_dir, f"{tag}_kernel_stats_top40.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
         w.writeheader()
         w.writerows(keep)
-for name in ("fetch", "write"):
+
+per = defaultdict(lambda: {"dispatches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
+for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     files = glob.glob(os.path.join(out_dir, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
-    agg = defaultdict(lambda: [0, 0.0])
+    n = defaultdict(int)
     for r in csv.DictReader(open(files[0])):
-        k = re.sub(r"\(.*", "", r["Kernel_Name"])[:80]
-        agg[(k, r["Counter_Name"])][0] += 1
-        agg[(k, r["Counter_Name"])][1] += float(r["Counter_Value"])
-    res[name] = [
-        {"kernel": k, "counter": c, "dispatches": n, "sum": v, "per_dispatch": v / n}
-        for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]
-    ]
+        if r["Counter_Name"] != counter:
+            continue
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:90]
+        if "nqa::" not in k:
+            continue
+        n[k] += 1
+        per[k][counter + "_KB"] += float(r["Counter_Value"])
+    for k, c in n.items():
+        per[k][counter + "_KB"] /= c
+        per[k]["dispatches"] = c
+for k, v in per.items():
+    # gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads (x2); WRITE_SIZE is exact, both in KB
+    v["hbm_bytes_corrected"] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
+
+bench = {}
+for region, (main_pats, helper_pats) in REGIONS.items():
+    ks = [k for k in per if any(p in k for p in main_pats + helper_pats)]
+    if not ks:
+        continue
+    # bytes per *region launch*: dispatch-weighted mean over the kernels of the region's main kernel family, plus
+    # helper kernels (reductions / prepasses) that run once per launch
+    main = [k for k in ks if any(p in k for p in main_pats)]
+    helpers = [k for k in ks if k not in main]
+    nd = sum(per[k]["dispatches"] for k in main)
+    if nd == 0:
+        continue
+    b = sum(per[k]["hbm_bytes_corrected"] * per[k]["dispatches"] for k in main) / nd
+    for k in helpers:
+        b += per[k]["hbm_bytes_corrected"] * per[k]["dispatches"] / nd
+    bench[region] = {"hbm_bytes_per_launch": b, "dispatches": nd, "kernels": sorted(ks)}
+
+res = {
+    "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE collected in separate passes over bench.py's cfg-3 workload "
+            "(scripts/profile.sh). Units: KB per dispatch, averaged over that kernel's dispatches (all layers). "
+            "gfx950 correction per MI355X_MICROARCH.md: hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.",
+    "kernels": dict(sorted(per.items())),
+    "bench_kernels": bench,
+}
 with open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w") as f:
     json.dump(res, f, indent=1)
-print(json.dumps({k: v[:8] for k, v in res.items()}, indent=1)[:3000])
+print(json.dumps(bench, indent=1)[:3000])
