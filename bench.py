@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), same guide
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")  # HBM bytes per launch from rocprofv3 --pmc
 
@@ -302,36 +303,46 @@ def main():
         if kernels:
             dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
             name, s = dom
-            traffic = None
+            traffic, pmc = None, {}
             try:  # per-launch HBM bytes of this kernel from the committed PMC passes (scripts/profile.sh), if present
                 pmc = json.load(open(PMC_SUMMARY))["bench_kernels"]
                 traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
-            if s.get("flops_per_call", 0) > 0 and name.startswith("radial_mlp"):
-                roofline = {
-                    "bound": "mfma", "kernel": name, "achieved": s["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": s["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                    "avg_launch_ms": s["avg_ms"], "algorithmic_flops_per_launch": s["flops_per_call"],
-                    "algorithmic_bytes_per_launch": s["bytes_per_call"],
-                    "launches_per_step": s["calls"] / max(args.kernel_steps, 1),
+                traffic, pmc = None, {}
+
+            def kernel_roofline(kname, ks):
+                launches = ks["calls"] / max(args.kernel_steps, 1)
+                if ks.get("flops_per_call", 0) > 0 and kname.startswith("radial_mlp"):
+                    # GEMM on the matrix cores.  `achieved` = algorithmic fp32 FLOP/s against the dense fp32-MFMA peak
+                    # (the path's arithmetic type); the default kernels execute 6 bf16 MFMA partial products per
+                    # fp32 product (split operands, fp32-accurate), reported against the bf16 peak as well.
+                    split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
+                    r = {
+                        "bound": "mfma", "kernel": kname, "achieved": ks["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
+                        "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],
+                        "algorithmic_bytes_per_launch": ks["bytes_per_call"], "hbm_gbps": ks["gbps"],
+                        "launches_per_step": launches,
+                    }
+                    if split:
+                        r["executed_bf16_tflops"] = 6.0 * ks["tflops"]
+                        r["frac_of_bf16_peak"] = 6.0 * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS
+                    return r
+                return {
+                    "bound": "hbm", "kernel": kname, "achieved": ks["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ks["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ks["avg_ms"],
+                    "algorithmic_bytes_per_launch": ks["bytes_per_call"], "launches_per_step": launches,
                 }
-            else:
-                roofline = {
-                    "bound": "hbm", "kernel": name, "achieved": s["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": s["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": s["avg_ms"],
-                    "algorithmic_bytes_per_launch": s["bytes_per_call"],
-                    "launches_per_step": s["calls"] / max(args.kernel_steps, 1),
-                }
-            # the hottest HBM-bound hand-written kernel as well (the tensor-product/scatter family)
-            tp = {k: v for k, v in kernels.items() if k.startswith("tp_")}
-            if tp:
-                tname, ts = max(tp.items(), key=lambda kv: kv[1]["total_ms"])
-                roofline["tp_scatter"] = {
-                    "bound": "hbm", "kernel": tname, "achieved": ts["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": ts["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ts["avg_ms"],
-                    "algorithmic_bytes_per_launch": ts["bytes_per_call"],
-                }
+
+            roofline = kernel_roofline(name, s)
+            roofline["traffic"] = traffic
+            # the other hot hand-written kernels, same definition (algorithmic bytes or flops / measured duration)
+            others = {}
+            for kname, ks in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])[:8]:
+                if kname != name:
+                    others[kname] = kernel_roofline(kname, ks)
+                    others[kname]["traffic"] = pmc.get(kname, {}).get("hbm_bytes_per_launch")
+            roofline["other_kernels"] = others
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

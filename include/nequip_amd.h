@@ -217,23 +217,31 @@ int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, 
  *   (nequip/nn/interaction_block.py:119-127,196; nequip/nn/mlp.py:141-156,194-196,262-268) for the
  *   standard one-hidden-layer, bias-free, SiLU radial MLP:
  *     edge_weight[E, W] = silu(edge_embedding[E, nb] @ (w0[nb, H] * alpha0)) @ (w1[H, W] * alpha1)
- *   computed in exact float32 on v_mfma_f32_32x32x2_f32; the hidden layer never leaves the chip.
+ *   The hidden layer never leaves the chip.  `mode` selects how the big GEMM ([E,H] x [H,W]) runs on the matrix
+ *   cores: NQA_MLP_FP32 = v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain); NQA_MLP_BF16X6 = every fp32 operand
+ *   split exactly into three bf16 terms and the six partial products >= 2^-16 accumulated in fp32 on
+ *   v_mfma_f32_32x32x16_bf16 (dropped terms < 2^-24 relative: fp32 accuracy, 2.7x the fp32-MFMA ceiling).  The
+ *   small first layer (K = nb) and all element-wise maths are fp32 in both modes.
  * nqa_radial_mlp_bwd is its vector-Jacobian product w.r.t. the edge embedding (inference forces:
  *   nequip/nn/grad_output.py:217-221); pre-activations are recomputed, not stored.  Parameter gradients
  *   (training) are not produced by these entry points -- the host side keeps the reference's mm/SiLU
  *   formulation in training mode.
  * nqa_radial_mlp_supported returns 1 when (dtype, nb, H, W) can run on the fused kernels
- *   (float32, nb <= 8, H in {64, 128}, W % 4 == 0).
+ *   (float32, nb <= 8, H in {64, 128}, W % 4 == 0).  `workspace` (>= nqa_radial_mlp_workspace_bytes(mode,
+ *   backward, H, W); 0 for the fp32 forward) receives the re-laid-out / split second-layer weights.
  * ------------------------------------------------------------------------------------------- */
+#define NQA_MLP_FP32 0
+#define NQA_MLP_BF16X6 1
 int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, int32_t out_features);
-int nqa_radial_mlp_fwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
-                       double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features, int64_t num_edges,
-                       void* edge_weight, nqa_stream stream);
-int64_t nqa_radial_mlp_bwd_workspace_bytes(int32_t hidden, int32_t out_features);
-int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
-                       double alpha1, const void* grad_edge_weight, int32_t num_basis, int32_t hidden,
-                       int32_t out_features, int64_t num_edges, void* grad_edge_embedding, void* workspace,
-                       int64_t workspace_bytes, nqa_stream stream);
+int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features);
+int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                       const void* w1, double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features,
+                       int64_t num_edges, void* edge_weight, void* workspace, int64_t workspace_bytes,
+                       nqa_stream stream);
+int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                       const void* w1, double alpha1, const void* grad_edge_weight, int32_t num_basis,
+                       int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
+                       void* workspace, int64_t workspace_bytes, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Node-side channel mixing in one launch: replaces e3nn o3.Linear (linear_1 / linear_2,

@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libnequip_amd.so")
 NQA_OK = 0
 NQA_F32 = 0
 NQA_F64 = 1
+NQA_MLP_FP32 = 0  # radial MLP GEMM on exact-fp32 MFMA
+NQA_MLP_BF16X6 = 1  # ... on bf16 MFMA with 3-way split operands (fp32-accurate)
 NQA_LAYOUT_MUL_IR = 0
 NQA_LAYOUT_IR_MUL = 1
 
@@ -99,15 +101,16 @@ SIGNATURES = {
         + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "nqa_radial_mlp_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "nqa_radial_mlp_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "nqa_radial_mlp_fwd": (
         c_int32,
-        [c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p],
+        [c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_int32, c_int32, c_int32, c_int64]
+        + [c_void_p, c_void_p, c_int64, c_void_p],
     ),
-    "nqa_radial_mlp_bwd_workspace_bytes": (c_int64, [c_int32, c_int32]),
     "nqa_radial_mlp_bwd": (
         c_int32,
-        [c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_void_p, c_int32, c_int32, c_int32, c_int64]
-        + [c_void_p, c_void_p, c_int64, c_void_p],
+        [c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_void_p, c_int32, c_int32, c_int32]
+        + [c_int64, c_void_p, c_void_p, c_int64, c_void_p],
     ),
     "nqa_node_linear": (
         c_int32,

@@ -358,6 +358,411 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float* __rest
   }
 }
 
+// ============================================================================================================
+// Split-bf16 ("bf16x6") variants: fp32-accurate GEMMs on the bf16 matrix cores.
+// ============================================================================================================
+// Every fp32 operand is written as the exact sum of three bf16 numbers, x = hi + mid + lo (8 + 8 + 8 significand
+// bits; the residuals are formed exactly in fp32), and a product is accumulated in fp32 from the six partial
+// products whose weight is >= 2^-16:  hi.hi + hi.mid + mid.hi + (mid.mid + hi.lo + lo.hi).  The dropped terms
+// (mid.lo, lo.mid, lo.lo) are below 2^-24 relative -- the rounding level of an fp32 fma chain -- so the result
+// carries fp32 accuracy (tests/test_radial_mlp.py measures both variants against float64), while
+// v_mfma_f32_32x32x16_bf16 retires 16x the MACs per cycle of v_mfma_f32_32x32x2_f32: 6 instructions of 16384 MACs
+// replace 8 of 2048 for the same tile, i.e. 2.7x the fp32-MFMA ceiling, which moves both kernels from MFMA-bound to
+// HBM-bound (the forward writes, the backward reads, 4*W bytes per edge).
+//
+// v_mfma_f32_32x32x16_bf16 register maps: A: lane l holds A[i = l&31][k = 8*(l>>5) + t], t = 0..7 (4 VGPRs);
+// B: B[k = 8*(l>>5) + t][j = l&31]; D as the 32x32 fp32 form.  Weights are split once per call by a small prepass
+// kernel that also lays them out in fragment order (one contiguous 1 KiB wave read per fragment, conflict-free
+// ds_read_b128), so staging a tile into LDS is a plain copy.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));  // round-to-nearest-even, lo -> bits [15:0]
+  return r;
+}
+
+// two floats -> three packed bf16 pairs with x == hi + mid + lo (+ O(2^-25))
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = cvt_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(h << 16);
+  float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(m << 16);
+  r1 -= __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(r0, r1);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+// hidden index held by lane-half `half`, element t of bf16 k-step s, when the hidden layer is produced by the
+// transposed fp32 MFMA of step 1 (accumulator register r = 8*(s&1) + t of 32-row block s>>1)
+__device__ __forceinline__ constexpr int mlp_hmap(int s, int half, int t) {
+  return 32 * (s >> 1) + (t & 3) + 8 * (2 * (s & 1) + (t >> 2)) + 4 * half;
+}
+
+// Forward weight fragments: Wf[tile][s][split][lane] (uint4) = A[i = column 32*tile + (lane&31)][k-step s, half, t]
+// of W1s^T with the hidden order of mlp_hmap; split 0/1/2 = hi/mid/lo.
+__global__ __launch_bounds__(256) void radial_mlp_split_w1_fwd_kernel(const float* __restrict__ W1, float a1, int H,
+                                                                      int W, u32x4* __restrict__ Wf) {
+  const int KS = H / 16;
+  const int ntiles = (W + 31) / 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (tile, s, lane)
+  if (idx >= ntiles * KS * 64) return;
+  const int lane = idx & 63, s = (idx >> 6) % KS, tile = idx / (64 * KS);
+  const int n = 32 * tile + (lane & 31), half = lane >> 5;
+  u32x4 h, m, l;
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) {
+    const float v0 = n < W ? W1[(int64_t)mlp_hmap(s, half, 2 * tp) * W + n] * a1 : 0.f;
+    const float v1 = n < W ? W1[(int64_t)mlp_hmap(s, half, 2 * tp + 1) * W + n] * a1 : 0.f;
+    uint32_t a, b, c;
+    split_pair(v0, v1, a, b, c);
+    h[tp] = a; m[tp] = b; l[tp] = c;
+  }
+  u32x4* __restrict__ o = Wf + ((int64_t)(tile * KS + s) * 3) * 64 + lane;
+  o[0] = h; o[64] = m; o[128] = l;
+}
+
+// Backward weight fragments: Wb[chunk][s][split][nt][lane] = B[k = 32*chunk + 16*half + 8*s + t][j = 32*nt + (lane&31)]
+// of W1s^T, i.e. 8 consecutive floats of row j of W1s.
+__global__ __launch_bounds__(256) void radial_mlp_split_w1_bwd_kernel(const float* __restrict__ W1, float a1, int H,
+                                                                      int W, u32x4* __restrict__ Wb) {
+  const int NT = H / 32;
+  const int nchunks = (W + 31) / 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (chunk, s, nt, lane)
+  if (idx >= nchunks * 2 * NT * 64) return;
+  const int lane = idx & 63, nt = (idx >> 6) % NT, s = (idx / (64 * NT)) & 1, chunk = idx / (128 * NT);
+  const int j = 32 * nt + (lane & 31), half = lane >> 5;
+  const int k0 = 32 * chunk + 16 * half + 8 * s;
+  u32x4 h, m, l;
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) {
+    const int k = k0 + 2 * tp;
+    const float v0 = k < W ? W1[(int64_t)j * W + k] * a1 : 0.f;
+    const float v1 = k + 1 < W ? W1[(int64_t)j * W + k + 1] * a1 : 0.f;
+    uint32_t a, b, c;
+    split_pair(v0, v1, a, b, c);
+    h[tp] = a; m[tp] = b; l[tp] = c;
+  }
+  u32x4* __restrict__ o = Wb + ((int64_t)((chunk * 2 + s) * 3) * NT + nt) * 64 + lane;
+  o[0] = h; o[(int64_t)NT * 64] = m; o[(int64_t)2 * NT * 64] = l;
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_kernel(const float* __restrict__ emb,
+                                                                    const float* __restrict__ W0,
+                                                                    const u32x4* __restrict__ Wf, float a0, int nb,
+                                                                    int W, int64_t E, float* __restrict__ out,
+                                                                    int dbg) {
+  constexpr int KS = H / 16;            // bf16 k-steps
+  constexpr int TILE = KS * 3 * 64;     // uint4 per 32-column weight tile (24 KiB for H = 128)
+  constexpr int NV = TILE / 256;        // uint4 per thread per tile
+  constexpr int kTS = 36;               // padded row stride (floats) of the per-wave output transpose tile
+  __shared__ float w0s[H * kMaxNb];     // [k][c]
+  __shared__ u32x4 as[2][TILE];
+  __shared__ __align__(16) float tbuf[4 * 32 * kTS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int64_t myrow = (int64_t)blockIdx.x * kMlpRows + wv * 32 + l31;
+  const bool row_ok = myrow < E;
+
+  for (int i = tid; i < H * kMaxNb; i += 256) {
+    const int k = i / kMaxNb, c = i - k * kMaxNb;
+    w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
+  }
+  const int ntiles = (W + 31) / 32;
+  u32x4 pre[NV];
+  auto stage_load = [&](int tile) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) pre[v] = Wf[(int64_t)tile * TILE + tid + v * 256];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) as[buf][tid + v * 256] = pre[v];
+  };
+  // Weight tiles are fetched two tiles ahead (global -> registers during tile t-1, registers -> LDS at the start of
+  // tile t, consumed in tile t+1): vmcnt retires in order and also counts the output stores, so waiting for a
+  // prefetch issued only one tile ago would wait for the previous tile's HBM stores as well.
+  stage_load(0);
+  stage_store(0);
+  if (ntiles > 1) stage_load(1);
+  __syncthreads();
+
+  // ---- step 1: hidden layer (K = nb <= 8) in exact fp32 on MFMA, SiLU, split into bf16 B fragments ---------------
+  u32x4 bh[KS], bm[KS], bl[KS];
+  {
+    float ev[kMaxNb];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) ev[c] = (c < nb && row_ok) ? emb[myrow * nb + c] : 0.f;
+#pragma unroll
+    for (int kb = 0; kb < H / 32; ++kb) {
+      f32x16 hacc = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];
+        const float bv = half ? ev[2 * s2 + 1] : ev[2 * s2];
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float h0 = row_ok ? silu_f(hacc[r]) : 0.f;
+        const float h1 = row_ok ? silu_f(hacc[r + 1]) : 0.f;
+        uint32_t a, b, c;
+        split_pair(h0, h1, a, b, c);
+        const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
+        bh[s][tp] = a; bm[s][tp] = b; bl[s][tp] = c;
+      }
+    }
+  }
+
+  // ---- step 2: out^T tiles of 32 columns -----------------------------------------------------------------------
+  // Two accumulator sets alternate between tiles: the epilogue of tile t-1 (accumulator read-out, 4 float4 stores)
+  // is emitted after the first k-steps of tile t have been queued on the matrix pipe, so it overlaps with them
+  // instead of draining the pipe at every tile boundary.
+  // The accumulator layout gives every lane 16 B pieces of 32 different rows; stored directly, each store
+  // instruction would touch 32 lines with 32 B each.  A wave-private LDS transpose (4 KiB) turns the tile into
+  // row-major order so that each store instruction writes 8 complete 128 B row segments.
+  float* __restrict__ tb = tbuf + wv * (32 * kTS);
+  const int64_t wrow0 = (int64_t)((dbg & 8) ? (blockIdx.x & 15) : blockIdx.x) * kMlpRows + wv * 32;
+  auto emit = [&](const f32x16& pa, const f32x16& pb, int tile) {
+    if (dbg & 1) {
+      if (pa[0] == 12345.f && pb[3] == 777.f) out[0] = 1.f;  // ablation: keep the MFMAs live, skip the stores
+      return;
+    }
+    // lane (edge, half) holds columns 8*g + 4*half + (0..3) of its row in registers 4g..4g+3
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(tb + l31 * kTS + 8 * g + 4 * half) =
+          make_float4(pa[4 * g] + pb[4 * g], pa[4 * g + 1] + pb[4 * g + 1], pa[4 * g + 2] + pb[4 * g + 2],
+                      pa[4 * g + 3] + pb[4 * g + 3]);
+    const int n0 = tile * 32;
+    const int c4 = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * i + rsub;
+      const float4 v = *reinterpret_cast<const float4*>(tb + r * kTS + 4 * c4);
+      if (wrow0 + r < E && n0 + 4 * c4 + 3 < W) *reinterpret_cast<float4*>(out + (wrow0 + r) * W + n0 + 4 * c4) = v;
+    }
+  };
+  auto tile_body = [&](int tile, f32x16& accA, f32x16& accB, const f32x16& prevA, const f32x16& prevB) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles && !(dbg & 2)) stage_store(buf ^ 1);
+    if (tile + 2 < ntiles && !(dbg & 2)) stage_load(tile + 2);
+    const u32x4* __restrict__ a = as[buf] + lane;
+    accA = (f32x16){0};  // large partial products
+    accB = (f32x16){0};  // small partial products, summed with accA at the end
+    u32x4 fa[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fa[0][q] = a[q * 64];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[(s + 1) & 1][q] = a[((s + 1) * 3 + q) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
+      accA = mfma_bf16(ah, bh[s], accA);
+      accB = mfma_bf16(am, bm[s], accB);
+      accA = mfma_bf16(ah, bm[s], accA);
+      accB = mfma_bf16(ah, bl[s], accB);
+      accA = mfma_bf16(am, bh[s], accA);
+      accB = mfma_bf16(al, bh[s], accB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 1 && tile > 0) {
+        emit(prevA, prevB, tile - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!(dbg & 4)) lds_barrier();
+  };
+  f32x16 a0A, a0B, a1A, a1B;
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    tile_body(tile, a0A, a0B, a1A, a1B);
+    if (tile + 1 < ntiles) tile_body(tile + 1, a1A, a1B, a0A, a0B);
+  }
+  if (ntiles & 1)
+    emit(a0A, a0B, ntiles - 1);
+  else
+    emit(a1A, a1B, ntiles - 1);
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const float* __restrict__ emb,
+                                                                    const float* __restrict__ W0,
+                                                                    const u32x4* __restrict__ Wb,
+                                                                    const float* __restrict__ gw, float a0, int nb,
+                                                                    int W, int64_t E, float* __restrict__ g_emb) {
+  // K (= W) is consumed in chunks of 32 columns = two bf16 k-steps; lane (row, half) owns the 16 contiguous floats
+  // 32*chunk + 16*half + [0, 16) of its g_w row per chunk: HBM -> registers directly, split in registers.
+  constexpr int NT = H / 32;
+  constexpr int CH = 2 * 3 * NT * 64;   // uint4 per chunk of B fragments (24 KiB for H = 128)
+  constexpr int NV = CH / 256;
+  constexpr int GS = H + 1;
+  constexpr int kMainBytes = 2 * CH * 16;
+  constexpr int kEpiBytes = kMlpRows * GS * 4;
+  constexpr int kBufBytes = kMainBytes > kEpiBytes ? kMainBytes : kEpiBytes;
+  __shared__ __align__(16) unsigned char smem_raw[kBufBytes];
+  __shared__ float w0s[H * kMaxNb];        // [k][c]
+  __shared__ float w0t[kMaxNb * H];        // [c][k]
+  __shared__ float es[kMlpRows * kMaxNb];  // embedding tile [row][c]
+  u32x4* __restrict__ bsm = reinterpret_cast<u32x4*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int64_t blk0 = (int64_t)blockIdx.x * kMlpRows;
+  const int64_t myrow = blk0 + wv * 32 + l31;
+  const bool row_ok = myrow < E;
+
+  for (int i = tid; i < H * kMaxNb; i += 256) {
+    const int k = i / kMaxNb, c = i - k * kMaxNb;
+    const float v = c < nb ? W0[c * H + k] * a0 : 0.f;
+    w0s[i] = v;
+    w0t[c * H + k] = v;
+  }
+  for (int i = tid; i < kMlpRows * kMaxNb; i += 256) {
+    const int r = i / kMaxNb, c = i - r * kMaxNb;
+    es[i] = (c < nb && blk0 + r < E) ? emb[(blk0 + r) * nb + c] : 0.f;
+  }
+
+  const int nchunks = (W + 31) / 32;
+  u32x4 pb[NV];
+  const float* __restrict__ grow = gw + (row_ok ? myrow : 0) * W + 16 * half;
+  auto load_a = [&](int ch, float4 (&pa)[4]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = 32 * ch + 16 * half + 4 * v;
+      pa[v] = (row_ok && k + 3 < W) ? *reinterpret_cast<const float4*>(grow + 32 * ch + 4 * v)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);  // W % 4 == 0
+    }
+  };
+  auto load_b = [&](int ch) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) pb[v] = Wb[(int64_t)ch * CH + tid + v * 256];
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) bsm[buf * CH + tid + v * 256] = pb[v];
+  };
+  // g_w (HBM) is fetched two chunks ahead into alternating register sets, the weight fragments (L2) one chunk ahead
+  // and *before* the g_w request of the same iteration: vmcnt retires in order, so the wait for the fragments then
+  // leaves the younger HBM loads in flight.
+  float4 paA[4], paB[4];
+  load_b(0);
+  load_a(0, paA);
+  store_b(0);
+  if (nchunks > 1) load_a(1, paB);
+  __syncthreads();
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+
+  auto body = [&](int ch, float4 (&pa)[4]) {
+    const int buf = ch & 1;
+    // split this chunk's 16 floats into the A fragments of its two k-steps
+    u32x4 ah[2], am[2], al[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint32_t a, b, c;
+      split_pair(pa[2 * s].x, pa[2 * s].y, a, b, c);
+      ah[s][0] = a; am[s][0] = b; al[s][0] = c;
+      split_pair(pa[2 * s].z, pa[2 * s].w, a, b, c);
+      ah[s][1] = a; am[s][1] = b; al[s][1] = c;
+      split_pair(pa[2 * s + 1].x, pa[2 * s + 1].y, a, b, c);
+      ah[s][2] = a; am[s][2] = b; al[s][2] = c;
+      split_pair(pa[2 * s + 1].z, pa[2 * s + 1].w, a, b, c);
+      ah[s][3] = a; am[s][3] = b; al[s][3] = c;
+    }
+    if (ch + 1 < nchunks) load_b(ch + 1);
+    if (ch + 2 < nchunks) load_a(ch + 2, pa);
+    const u32x4* __restrict__ bs = bsm + buf * CH + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fb[3][NT];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[q][t] = bs[((s * 3 + q) * NT + t) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(am[s], fb[1][t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(ah[s], fb[2][t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(al[s], fb[0][t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(ah[s], fb[1][t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(am[s], fb[0][t], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(ah[s], fb[0][t], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch + 1 < nchunks) store_b(buf ^ 1);
+    lds_barrier();
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    body(ch, paA);
+    if (ch + 1 < nchunks) body(ch + 1, paB);
+  }
+
+  // epilogue (exact fp32): pre-activations recomputed on MFMA in the accumulator layout, g_pre = g_h * silu'(pre),
+  // one pass through LDS for the NB-wide GEMV -- identical to the fp32 kernel
+  float* __restrict__ gp = reinterpret_cast<float*>(smem_raw);
+  {
+    const float* __restrict__ erow = es + (wv * 32 + l31) * kMaxNb;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 pacc = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const float av = erow[2 * s2 + half];
+        const float bv = w0t[(2 * s2 + half) * H + t * 32 + l31];
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, pacc, 0, 0, 0);
+      }
+      const int col = t * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        gp[lr * GS + col] = acc[t][r] * silu_grad_f(pacc[r]);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 1, kh = tid & 1;
+    float sacc[kMaxNb];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) sacc[c] = 0.f;
+    const float* __restrict__ gr = gp + r * GS + kh * (H / 2);
+    const float* __restrict__ wr = w0s + kh * (H / 2) * kMaxNb;
+#pragma unroll 4
+    for (int k = 0; k < H / 2; ++k) {
+      const float gv = gr[k];
+      const float4 w0 = *reinterpret_cast<const float4*>(wr + k * kMaxNb);
+      const float4 w1 = *reinterpret_cast<const float4*>(wr + k * kMaxNb + 4);
+      sacc[0] += gv * w0.x; sacc[1] += gv * w0.y; sacc[2] += gv * w0.z; sacc[3] += gv * w0.w;
+      sacc[4] += gv * w1.x; sacc[5] += gv * w1.y; sacc[6] += gv * w1.z; sacc[7] += gv * w1.w;
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) sacc[c] += __shfl_xor(sacc[c], 1, 64);
+    if (kh == 0 && blk0 + r < E) {
+      for (int c = 0; c < nb; ++c) g_emb[(blk0 + r) * nb + c] = sacc[c];
+    }
+  }
+}
+
 static int check_args(const void* emb, const void* W0, const void* W1, int nb, int H, int W, int64_t E,
                       const char* fn) {
   if (E < 0 || nb <= 0 || nb > kMaxNb || W <= 0 || (E > 0 && (!emb || !W0 || !W1))) {
@@ -384,19 +789,55 @@ int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, i
              : 0;
 }
 
-int nqa_radial_mlp_fwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
-                       double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features, int64_t num_edges,
-                       void* edge_weight, nqa_stream stream) {
+int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features) {
+  if (hidden <= 0 || out_features <= 0) return -1;
+  if (mode == NQA_MLP_BF16X6) {
+    // weight fragments: ceil(W/32) tiles x (H/16) k-steps x 3 splits x 1 KiB (same size for both directions)
+    return (int64_t)((out_features + 31) / 32) * (hidden / 16) * 3 * 1024;
+  }
+  if (mode != NQA_MLP_FP32) return -1;
+  if (!backward) return 0;
+  return (int64_t)hidden * out_features * (int64_t)sizeof(float) + 4 * 64 * hidden * (int64_t)sizeof(float);
+}
+
+static int check_mode(int32_t dtype, int32_t mode, const char* fn) {
   if (dtype != NQA_F32) {
-    set_error("nqa_radial_mlp_fwd: only float32 is implemented on MFMA");
+    set_error(std::string(fn) + ": only float32 is implemented on MFMA");
     return NQA_ERR_UNSUPPORTED;
   }
-  int rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_fwd");
+  if (mode != NQA_MLP_FP32 && mode != NQA_MLP_BF16X6) {
+    set_error(std::string(fn) + ": unknown mode");
+    return NQA_ERR_INVALID;
+  }
+  return NQA_OK;
+}
+
+static int launch_status(const char* fn) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string(fn) + ": " + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                       const void* w1, double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features,
+                       int64_t num_edges, void* edge_weight, void* workspace, int64_t workspace_bytes,
+                       nqa_stream stream) {
+  int rc = check_mode(dtype, mode, "nqa_radial_mlp_fwd");
+  if (rc != NQA_OK) return rc;
+  rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_fwd");
   if (rc != NQA_OK) return rc;
   if (num_edges == 0) return NQA_OK;
   if (edge_weight == nullptr || out_features % 4 != 0) {
     set_error("nqa_radial_mlp_fwd: invalid output (needs out_features % 4 == 0)");
     return NQA_ERR_INVALID;
+  }
+  const int64_t need = nqa_radial_mlp_workspace_bytes(mode, 0, hidden, out_features);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("nqa_radial_mlp_fwd: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = (unsigned)((num_edges + kMlpRows - 1) / kMlpRows);
@@ -408,40 +849,42 @@ int nqa_radial_mlp_fwd(int32_t dtype, const void* edge_embedding, const void* w0
     const char* v = std::getenv("NQA_MLP_DBG");
     return v ? std::atoi(v) : 0;
   }();
+  if (mode == NQA_MLP_BF16X6) {
+    u32x4* wf = static_cast<u32x4*>(workspace);
+    const int nfrag = ((out_features + 31) / 32) * (hidden / 16) * 64;
+    hipLaunchKernelGGL(radial_mlp_split_w1_fwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
+                       (float)alpha1, hidden, out_features, wf);
+    if (hidden == 128)
+      hipLaunchKernelGGL(radial_mlp_fwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
+                         num_basis, out_features, num_edges, o, dbg);
+    else
+      hipLaunchKernelGGL(radial_mlp_fwd_bf16x6_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
+                         num_basis, out_features, num_edges, o, dbg);
+    return launch_status("nqa_radial_mlp_fwd");
+  }
   if (hidden == 128)
     hipLaunchKernelGGL(radial_mlp_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, b, (float)alpha0,
                        (float)alpha1, num_basis, out_features, num_edges, o, dbg);
   else
     hipLaunchKernelGGL(radial_mlp_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, b, (float)alpha0,
                        (float)alpha1, num_basis, out_features, num_edges, o, dbg);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) {
-    set_error(std::string("nqa_radial_mlp_fwd: ") + hipGetErrorString(err));
-    return NQA_ERR_LAUNCH;
-  }
-  return NQA_OK;
+  return launch_status("nqa_radial_mlp_fwd");
 }
 
-int64_t nqa_radial_mlp_bwd_workspace_bytes(int32_t hidden, int32_t out_features) {
-  return (int64_t)hidden * out_features * (int64_t)sizeof(float) + 4 * 64 * hidden * (int64_t)sizeof(float);
-}
-
-int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0, double alpha0, const void* w1,
-                       double alpha1, const void* grad_edge_weight, int32_t num_basis, int32_t hidden,
-                       int32_t out_features, int64_t num_edges, void* grad_edge_embedding, void* workspace,
-                       int64_t workspace_bytes, nqa_stream stream) {
-  if (dtype != NQA_F32) {
-    set_error("nqa_radial_mlp_bwd: only float32 is implemented on MFMA");
-    return NQA_ERR_UNSUPPORTED;
-  }
-  int rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
+int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                       const void* w1, double alpha1, const void* grad_edge_weight, int32_t num_basis,
+                       int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
+                       void* workspace, int64_t workspace_bytes, nqa_stream stream) {
+  int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
+  if (rc != NQA_OK) return rc;
+  rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   if (num_edges == 0) return NQA_OK;
   if (grad_edge_weight == nullptr || grad_edge_embedding == nullptr || out_features % 4 != 0) {
     set_error("nqa_radial_mlp_bwd: invalid argument (needs out_features % 4 == 0)");
     return NQA_ERR_INVALID;
   }
-  if (workspace == nullptr || workspace_bytes < nqa_radial_mlp_bwd_workspace_bytes(hidden, out_features)) {
+  if (workspace == nullptr || workspace_bytes < nqa_radial_mlp_workspace_bytes(mode, 1, hidden, out_features)) {
     set_error("nqa_radial_mlp_bwd: workspace missing or too small");
     return NQA_ERR_WORKSPACE;
   }
@@ -452,6 +895,19 @@ int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0
   const float* b = static_cast<const float*>(w1);
   const float* g = static_cast<const float*>(grad_edge_weight);
   float* o = static_cast<float*>(grad_edge_embedding);
+  if (mode == NQA_MLP_BF16X6) {
+    u32x4* wb = static_cast<u32x4*>(workspace);
+    const int nfrag = ((out_features + 31) / 32) * 2 * (hidden / 32) * 64;
+    hipLaunchKernelGGL(radial_mlp_split_w1_bwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
+                       (float)alpha1, hidden, out_features, wb);
+    if (hidden == 128)
+      hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
+                         num_basis, out_features, num_edges, o);
+    else
+      hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
+                         num_basis, out_features, num_edges, o);
+    return launch_status("nqa_radial_mlp_bwd");
+  }
   float* w1t = static_cast<float*>(workspace);  // [W (+ padding rows read by the last chunk)][H]
   hipLaunchKernelGGL(radial_mlp_transpose_w1_kernel, dim3((unsigned)((hidden * out_features + 255) / 256)), dim3(256),
                      0, s, b, (float)alpha1, hidden, out_features, w1t);
@@ -461,12 +917,7 @@ int nqa_radial_mlp_bwd(int32_t dtype, const void* edge_embedding, const void* w0
   else
     hipLaunchKernelGGL(radial_mlp_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, w1t, g, (float)alpha0,
                        num_basis, out_features, num_edges, o);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) {
-    set_error(std::string("nqa_radial_mlp_bwd: ") + hipGetErrorString(err));
-    return NQA_ERR_LAUNCH;
-  }
-  return NQA_OK;
+  return launch_status("nqa_radial_mlp_bwd");
 }
 
 }  // extern "C"

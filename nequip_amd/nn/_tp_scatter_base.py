@@ -126,10 +126,9 @@ class _Kernels:
         rowptr, eid, nbr = topo.by_dst
         rowptr_s, eid_s, _ = topo.by_src
         es = x.element_size()
-        # algorithmic bytes: w (+ gw, gy) once per edge, the per-edge grad_x rows written and read once, node rows once
-        nbytes = E * (es * (self.weight_numel + self.dim_in2 + 2 * self.dim_in1) + 24) + N * es * (
-            2 * self.dim_in1 + self.dim_out
-        )
+        # algorithmic bytes: operands and results once (w, y, gw, gy per edge; x, g, gx per node) -- the intermediate
+        # per-edge grad_x rows (written and read once, 2 * dim_in1 per edge) are traffic, not algorithm
+        nbytes = E * (es * (self.weight_numel + self.dim_in2) + 24) + N * es * (2 * self.dim_in1 + self.dim_out)
         nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
         with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused", nbytes):
             rc = lib.nqa_tp_scatter_bwd_fused(

@@ -16,12 +16,20 @@ from ..utils import ktimer
 from ._graph_mixin import GraphModuleMixin
 
 
+def radial_mlp_mode() -> int:
+    """GEMM mode of the fused radial MLP: split-bf16 (fp32-accurate, default) or exact fp32 MFMA
+    (``NQA_MLP_EXACT_FP32=1``)."""
+    import os
+
+    return _lib.NQA_MLP_FP32 if os.environ.get("NQA_MLP_EXACT_FP32", "") not in ("", "0") else _lib.NQA_MLP_BF16X6
+
+
 class _RadialMLPFn(torch.autograd.Function):
-    """Fused two-layer radial MLP on fp32 MFMA (``nqa_radial_mlp_fwd/bwd``); inference path: differentiable w.r.t.
-    the edge embedding only (that is what the force backward needs)."""
+    """Fused two-layer radial MLP on the matrix cores (``nqa_radial_mlp_fwd/bwd``); inference path: differentiable
+    w.r.t. the edge embedding only (that is what the force backward needs)."""
 
     @staticmethod
-    def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float):
+    def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float, mode: int):
         from ._topology import _ptr, current_stream_ptr
 
         lib = _lib.load()
@@ -30,12 +38,15 @@ class _RadialMLPFn(torch.autograd.Function):
         H, W = w1.shape
         out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
         flops = 2.0 * E * (nb * H + H * W)
+        ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=emb.device)
         with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):
-            rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
-                                        _ptr(out), current_stream_ptr(emb.device))
+            rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
+                                        _ptr(out), _ptr(ws), ws_bytes, current_stream_ptr(emb.device))
         _lib.check(rc, "nqa_radial_mlp_fwd")
         ctx.save_for_backward(emb, w0, w1)
         ctx.alphas = (alpha0, alpha1)
+        ctx.mode = mode
         return out
 
     @staticmethod
@@ -50,14 +61,14 @@ class _RadialMLPFn(torch.autograd.Function):
         H, W = w1.shape
         g_emb = torch.empty_like(emb)
         flops = 2.0 * E * (nb * H * 2 + H * W)
-        ws_bytes = lib.nqa_radial_mlp_bwd_workspace_bytes(H, W)
+        ws_bytes = lib.nqa_radial_mlp_workspace_bytes(ctx.mode, 1, H, W)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
         with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
-            rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, _ptr(emb), _ptr(w0), ctx.alphas[0], _ptr(w1), ctx.alphas[1],
-                                        _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes,
+            rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, ctx.mode, _ptr(emb), _ptr(w0), ctx.alphas[0], _ptr(w1),
+                                        ctx.alphas[1], _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes,
                                         current_stream_ptr(emb.device))
         _lib.check(rc, "nqa_radial_mlp_bwd")
-        return g_emb, None, None, None, None
+        return g_emb, None, None, None, None, None
 
 
 class ScalarLinearLayer(torch.nn.Module):
@@ -119,7 +130,8 @@ class ScalarMLPFunction(torch.nn.Module):
         # inference on the GPU: one fused MFMA kernel (hidden layer stays on chip); training keeps the
         # mm/SiLU formulation so that parameter gradients and double backward come from autograd
         if self._fused_ok(x):
-            return _RadialMLPFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0], self._alphas[1])
+            return _RadialMLPFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0], self._alphas[1],
+                                      radial_mlp_mode())
         return self.mlp(x)
 
 

@@ -1,6 +1,7 @@
 """Fused MFMA radial MLP (nqa_radial_mlp_fwd/bwd) against the oracle's ScalarMLPFunction restatement
 (oracle/nn.py::scalar_mlp following nequip/nn/mlp.py:141-156,262-268).  float32, tolerance 1e-5 relative to
-the output scale (exact-fp32 MFMA: only the summation order differs from the CPU mm)."""
+the output scale, for both GEMM modes: exact-fp32 MFMA (only the summation order differs from the CPU mm) and the
+default split-bf16 mode (three exact bf16 terms per operand, six partial products, fp32 accumulation)."""
 
 import math
 
@@ -10,10 +11,16 @@ import torch
 from oracle import nn as onn
 
 
+@pytest.fixture(params=["bf16x6", "fp32"])
+def mlp_mode(request, monkeypatch):
+    monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if request.param == "fp32" else "0")
+    return request.param
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("E", [1, 127, 128, 1000, 4133])
-@pytest.mark.parametrize("H,W", [(128, 704), (128, 192), (64, 64), (64, 160), (128, 2944)])
-def test_radial_mlp_fwd_bwd(device, E, H, W):
+@pytest.mark.parametrize("H,W", [(128, 704), (128, 192), (64, 64), (64, 160), (128, 2944), (128, 36)])
+def test_radial_mlp_fwd_bwd(device, mlp_mode, E, H, W):
     from nequip_amd.nn.mlp import ScalarMLPFunction
 
     torch.manual_seed(E + H + W)
@@ -33,6 +40,46 @@ def test_radial_mlp_fwd_bwd(device, E, H, W):
     (ge,) = torch.autograd.grad(out, e_dev, g.to(device))
     torch.testing.assert_close(ref.detach(), out.detach().cpu(), atol=1e-5 * float(ref.abs().max()), rtol=1e-5)
     torch.testing.assert_close(ge_ref, ge.cpu(), atol=2e-5 * float(ge_ref.abs().max()), rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_radial_mlp_split_bf16_has_fp32_accuracy(device, monkeypatch):
+    """Error against a float64 evaluation: the split-bf16 GEMM must be as accurate as the exact-fp32 MFMA one (and as
+    a float32 CPU mm) -- i.e. at the fp32 rounding level, orders of magnitude below bf16/tf32 arithmetic."""
+    from nequip_amd.nn.mlp import ScalarMLPFunction
+
+    torch.manual_seed(7)
+    E, H, W = 2048, 128, 704
+    mlp = ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=1, hidden_layers_width=H).eval()
+    emb = torch.randn(E, 8) * 0.7
+    g = torch.randn(E, W)
+    w0, w1 = mlp.mlp[0].weight.detach(), mlp.mlp[2].weight.detach()
+    e64 = emb.double().requires_grad_(True)
+    ref64 = onn.scalar_mlp(e64, [w0.double(), w1.double()], "silu")
+    (ge64,) = torch.autograd.grad(ref64, e64, g.double())
+    e32 = emb.clone().requires_grad_(True)
+    ref32 = onn.scalar_mlp(e32, [w0, w1], "silu")
+    (ge32,) = torch.autograd.grad(ref32, e32, g)
+    err_cpu = float((ref32.detach().double() - ref64.detach()).abs().max() / ref64.abs().max())
+    gerr_cpu = float((ge32.double() - ge64).abs().max() / ge64.abs().max())
+
+    mlp = mlp.to(device)
+    errs = {}
+    for mode in ("fp32", "bf16x6"):
+        monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if mode == "fp32" else "0")
+        e_dev = emb.to(device).requires_grad_(True)
+        out = mlp(e_dev)
+        (ge,) = torch.autograd.grad(out, e_dev, g.to(device))
+        errs[mode] = (
+            float((out.detach().cpu().double() - ref64.detach()).abs().max() / ref64.abs().max()),
+            float((ge.cpu().double() - ge64).abs().max() / ge64.abs().max()),
+        )
+    print("max error / max|ref| vs float64: cpu fp32", (err_cpu, gerr_cpu), errs)
+    for mode, (ef, eb) in errs.items():
+        assert ef < 2e-6 and eb < 4e-6, (mode, ef, eb)
+    # split-bf16 within 3x of the exact-fp32 kernels' own rounding error
+    assert errs["bf16x6"][0] < 3 * max(errs["fp32"][0], err_cpu)
+    assert errs["bf16x6"][1] < 3 * max(errs["fp32"][1], gerr_cpu)
 
 
 @pytest.mark.gpu
