@@ -256,17 +256,19 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  *   atom_types (int64 [N]) is required iff n_types > 1.  The backward w.r.t. x is the same call with transposed
  *   tables/weights.  All tables are device pointers.
  * nqa_gate: e3nn Gate (nequip/nn/convnetlayer.py:104-112,162-164): in = scalars (+) gates (+) gated ->
- *   out = act(scalars) (+) act(gates)[u] * gated[u, :]; seg_table: {begin, end, act, pad, double cst} per scalar/gate
- *   segment (act 0 = identity, 1 = silu, 2 = tanh; cst = e3nn normalize2mom constant); blk_table: int32
- *   {in_off, out_off, mul, d, gate_off, 0, 0, 0} per gated block.  backward != 0 computes grad_in from grad_out.
+ *   out = act(scalars) (+) act(gates)[u] * gated[u, :] (act 0 = identity, 1 = silu, 2 = tanh, each times its e3nn
+ *   normalize2mom constant `cst`).  col_table: one 32-byte record {int32 a, b, c, d; double cst; int32 e, f} per
+ *   column -- forward (backward == 0), per OUTPUT column: {src, gate (-1 for scalars), act, 0, cst, 0, 0}:
+ *   out[z,c] = gate < 0 ? act(in[z,src]) : act(in[z,gate]) * in[z,src]; backward, per INPUT column:
+ *   {kind, act, o, i, cst, len, gate}: kind 0 (scalar) gin = g[z,o] act'(in[z,c]); kind 1 (gate) gin = act'(in[z,c])
+ *   sum_{m<len} g[z,o+m] in[z,i+m]; kind 2 (gated) gin = act(in[z,gate]) g[z,o]; kind 3: zero.
  * ------------------------------------------------------------------------------------------- */
 int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
                     int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
                     double scale, int32_t chunk_width, nqa_stream stream);
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
-             const void* seg_table, int32_t n_segs, const void* blk_table, int32_t n_blks, int32_t num_scalars,
-             int32_t num_gates, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
+             const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
 #ifdef __cplusplus
 }

@@ -119,8 +119,7 @@ SIGNATURES = {
     ),
     "nqa_gate": (
         c_int32,
-        [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32]
-        + [c_int32, c_int32, c_int64, c_void_p],
+        [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],
     ),
 }
 

@@ -258,14 +258,6 @@ __global__ __launch_bounds__(256) void node_linear_mfma_kernel(const NodeLinearA
 // ---- Gate ----------------------------------------------------------------------------------------------------
 // in  = [scalars (ns) | gates (ng) | gated blocks (mul_b x d_b)...],  out = [act(scalars) | act(gates)[u] * gated[u, :]]
 // activation id per scalar / gate segment: 0 = identity, 1 = silu * cst, 2 = tanh * cst.
-struct GateSeg {
-  int32_t begin, end, act, pad;
-  double cst;
-};
-struct GateBlk {
-  int32_t in_off, out_off, mul, d, gate_off, pad0, pad1, pad2;  // gate_off: offset of this block's gates inside `gates`
-};
-
 template <typename T>
 __device__ __forceinline__ T act_eval(int act, T x, T cst) {
   if (act == 1) return cst * x / (T(1) + exp(-x));
@@ -285,27 +277,30 @@ __device__ __forceinline__ T act_grad(int act, T x, T cst) {
   return T(1);
 }
 
+// Column tables (built by the host from the irreps bookkeeping, one 32-byte record per column):
+//   forward,  per OUTPUT column c: {a = src, b = gate (-1: scalar), c = act, cst}
+//       out[z,c] = gate < 0 ? act(in[z,src]) : act(in[z,gate]) * in[z,src]
+//   backward, per INPUT column c:  {a = kind, b = act, c = o, d = i, cst, e = len, f = gate}
+//       kind 0 scalar: gin = g[z,o] * act'(in[z,c])
+//       kind 1 gate  : gin = act'(in[z,c]) * sum_{m<len} g[z,o+m] * in[z,i+m]
+//       kind 2 gated : gin = act(in[z,gate]) * g[z,o]
+// One thread per (atom, column), columns fastest: every global access is coalesced and the kernels are pure streams.
+struct GateCol {
+  int32_t a, b, c, d;
+  double cst;  // e3nn normalize2mom constant of the activation
+  int32_t e, f;
+};
+static_assert(sizeof(GateCol) == 32, "GateCol layout is part of the C ABI");
+
 template <typename T>
 struct GateArgs {
   const T* __restrict__ in;
   const T* __restrict__ gout;  // backward only
   T* __restrict__ out;         // fwd: out [N, dout]; bwd: gin [N, din]
-  const GateSeg* __restrict__ segs;
-  const GateBlk* __restrict__ blks;
-  int32_t n_segs, n_blks, ns, ng, din, dout;
+  const GateCol* __restrict__ cols;
+  int32_t din, dout;
   int64_t N;
 };
-
-template <typename T>
-__device__ __forceinline__ void gate_seg_of(const GateArgs<T>& a, int col, int& act, T& cst) {
-  act = 0;
-  cst = T(1);
-  for (int s = 0; s < a.n_segs; ++s)
-    if (col >= a.segs[s].begin && col < a.segs[s].end) {
-      act = a.segs[s].act;
-      cst = (T)a.segs[s].cst;
-    }
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateArgs<T> a) {
@@ -313,26 +308,11 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateArgs<T> a) {
   if (i >= a.N * a.dout) return;
   const int64_t z = i / a.dout;
   const int c = (int)(i - z * a.dout);
+  const GateCol t = a.cols[c];
   const T* __restrict__ row = a.in + z * a.din;
-  if (c < a.ns) {
-    int act;
-    T cst;
-    gate_seg_of(a, c, act, cst);
-    a.out[i] = act_eval(act, row[c], cst);
-    return;
-  }
-  for (int b = 0; b < a.n_blks; ++b) {
-    const GateBlk bl = a.blks[b];
-    if (c >= bl.out_off && c < bl.out_off + bl.mul * bl.d) {
-      const int u = (c - bl.out_off) / bl.d;
-      const int gcol = a.ns + bl.gate_off + u;
-      int act;
-      T cst;
-      gate_seg_of(a, gcol, act, cst);
-      a.out[i] = act_eval(act, row[gcol], cst) * row[bl.in_off + (c - bl.out_off)];
-      return;
-    }
-  }
+  const T cst = (T)t.cst;
+  const T xs = row[t.a];
+  a.out[i] = t.b < 0 ? act_eval(t.c, xs, cst) : act_eval(t.c, row[t.b], cst) * xs;
 }
 
 template <typename T>
@@ -341,47 +321,21 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateArgs<T> a) {
   if (i >= a.N * a.din) return;
   const int64_t z = i / a.din;
   const int c = (int)(i - z * a.din);
+  const GateCol t = a.cols[c];
   const T* __restrict__ row = a.in + z * a.din;
   const T* __restrict__ g = a.gout + z * a.dout;
-  if (c < a.ns) {
-    int act;
-    T cst;
-    gate_seg_of(a, c, act, cst);
-    a.out[i] = g[c] * act_grad(act, row[c], cst);
-    return;
-  }
-  if (c < a.ns + a.ng) {
-    // gate u of some block: sum over the block's 2l+1 components
-    const int gl = c - a.ns;
-    for (int b = 0; b < a.n_blks; ++b) {
-      const GateBlk bl = a.blks[b];
-      if (gl >= bl.gate_off && gl < bl.gate_off + bl.mul) {
-        const int u = gl - bl.gate_off;
-        T s = T(0);
-        for (int m = 0; m < bl.d; ++m) s += g[bl.out_off + u * bl.d + m] * row[bl.in_off + u * bl.d + m];
-        int act;
-        T cst;
-        gate_seg_of(a, c, act, cst);
-        a.out[i] = s * act_grad(act, row[c], cst);
-        return;
-      }
-    }
+  const T cst = (T)t.cst;
+  if (t.a == 0) {
+    a.out[i] = g[t.c] * act_grad(t.b, row[c], cst);
+  } else if (t.a == 1) {
+    T s = T(0);
+    for (int m = 0; m < t.e; ++m) s += g[t.c + m] * row[t.d + m];
+    a.out[i] = s * act_grad(t.b, row[c], cst);
+  } else if (t.a == 2) {
+    a.out[i] = act_eval(t.b, row[t.f], cst) * g[t.c];
+  } else {
     a.out[i] = T(0);
-    return;
   }
-  for (int b = 0; b < a.n_blks; ++b) {
-    const GateBlk bl = a.blks[b];
-    if (c >= bl.in_off && c < bl.in_off + bl.mul * bl.d) {
-      const int u = (c - bl.in_off) / bl.d;
-      const int gcol = a.ns + bl.gate_off + u;
-      int act;
-      T cst;
-      gate_seg_of(a, gcol, act, cst);
-      a.out[i] = act_eval(act, row[gcol], cst) * g[bl.out_off + (c - bl.in_off)];
-      return;
-    }
-  }
-  a.out[i] = T(0);
 }
 
 }  // namespace nqa
@@ -478,13 +432,13 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
 }
 
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
-             const void* seg_table, int32_t n_segs, const void* blk_table, int32_t n_blks, int32_t num_scalars,
-             int32_t num_gates, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream) {
+             const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream) {
   if (dtype != NQA_F32 && dtype != NQA_F64) {
     set_error("nqa_gate: unsupported dtype");
     return NQA_ERR_UNSUPPORTED;
   }
-  if (num_nodes < 0 || (num_nodes > 0 && (!input || !out || (backward && !grad_out))) || dim_in <= 0 || dim_out <= 0) {
+  if (num_nodes < 0 || (num_nodes > 0 && (!input || !out || !col_table || (backward && !grad_out))) || dim_in <= 0 ||
+      dim_out <= 0) {
     set_error("nqa_gate: invalid argument");
     return NQA_ERR_INVALID;
   }
@@ -498,12 +452,7 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
     a.in = static_cast<const T*>(input);                                                          \
     a.gout = static_cast<const T*>(grad_out);                                                     \
     a.out = static_cast<T*>(out);                                                                 \
-    a.segs = static_cast<const GateSeg*>(seg_table);                                              \
-    a.blks = static_cast<const GateBlk*>(blk_table);                                              \
-    a.n_segs = n_segs;                                                                            \
-    a.n_blks = n_blks;                                                                            \
-    a.ns = num_scalars;                                                                           \
-    a.ng = num_gates;                                                                             \
+    a.cols = static_cast<const GateCol*>(col_table);                                              \
     a.din = dim_in;                                                                               \
     a.dout = dim_out;                                                                             \
     a.N = num_nodes;                                                                              \

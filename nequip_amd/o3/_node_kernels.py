@@ -150,7 +150,14 @@ def _transposed(meta: NodeLinearMeta) -> NodeLinearMeta:
 
 
 def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Tensor:
-    return meta.transpose_weights(wp)
+    if wp.requires_grad:
+        return meta.transpose_weights(wp)
+    # constant weights (eval mode): the modules keep `wp` alive across steps, so the transposed copy rides on it
+    cached = getattr(wp, "_nqa_transposed", None)
+    if cached is None or cached[0] != wp._version:
+        cached = (wp._version, meta.transpose_weights(wp))
+        wp._nqa_transposed = cached
+    return cached[1]
 
 
 def _weight_grad(x, g, types, meta: NodeLinearMeta, T: int):
@@ -183,48 +190,59 @@ _ACT_IDS = {"identity": 0, "silu": 1, "tanh": 2}
 
 
 class GateMeta:
+    """Column tables of ``nqa_gate`` (see include/nequip_amd.h): one 32-byte record per output (forward) / input
+    (backward) column."""
+
     def __init__(self, irreps_scalars: Irreps, act_scalars: Sequence[Tuple[str, float]], irreps_gates: Irreps,
                  act_gates: Sequence[Tuple[str, float]], irreps_gated: Irreps):
         self.ns, self.ng = irreps_scalars.dim, irreps_gates.dim
         self.din = self.ns + self.ng + irreps_gated.dim
         self.dout = self.ns + irreps_gated.dim
-        segs = b""
-        off = 0
-        n = 0
+        col_act = []  # (act id, cst) of every scalar / gate column
         for (mul, _), (name, cst) in list(zip(irreps_scalars, act_scalars)) + list(zip(irreps_gates, act_gates)):
-            segs += struct.pack("<iiiid", off, off + mul, _ACT_IDS[name], 0, float(cst))
-            off += mul
-            n += 1
-        self.n_segs = n
-        self._segs = segs
-        blks = []
+            col_act += [(_ACT_IDS[name], float(cst))] * mul
+        fwd = [None] * self.dout
+        bwd = [None] * self.din
+        rec = struct.Struct("<iiiidii")
+        for c in range(self.ns):
+            act, cst = col_act[c]
+            fwd[c] = rec.pack(c, -1, act, 0, cst, 0, 0)
+            bwd[c] = rec.pack(0, act, c, 0, cst, 0, 0)
         in_off, out_off, goff = self.ns + self.ng, self.ns, 0
         for mul, ir in irreps_gated:
-            blks.append((in_off, out_off, mul, ir.dim, goff, 0, 0, 0))
-            in_off += mul * ir.dim
-            out_off += mul * ir.dim
+            d = ir.dim
+            for u in range(mul):
+                gcol = self.ns + goff + u
+                act, cst = col_act[gcol]
+                bwd[gcol] = rec.pack(1, act, out_off + u * d, in_off + u * d, cst, d, 0)
+                for m in range(d):
+                    fwd[out_off + u * d + m] = rec.pack(in_off + u * d + m, gcol, act, 0, cst, 0, 0)
+                    bwd[in_off + u * d + m] = rec.pack(2, act, out_off + u * d + m, 0, cst, 0, gcol)
+            in_off += mul * d
+            out_off += mul * d
             goff += mul
-        self.n_blks = len(blks)
-        self._blks = blks
+        zero = rec.pack(3, 0, 0, 0, 1.0, 0, 0)
+        self._fwd = b"".join(r if r is not None else rec.pack(0, -1, 0, 0, 1.0, 0, 0) for r in fwd)
+        self._bwd = b"".join(r if r is not None else zero for r in bwd)
         self._dev = {}
 
     def device_tables(self, device):
         key = str(device)
         if key not in self._dev:
-            st = torch.frombuffer(bytearray(self._segs if self._segs else b"\0" * 24), dtype=torch.uint8).clone().to(device)
-            bt = torch.tensor(self._blks if self._blks else [(0,) * 8], dtype=torch.int32).reshape(-1, 8).to(device)
-            self._dev[key] = (st, bt)
+            ft = torch.frombuffer(bytearray(self._fwd), dtype=torch.uint8).clone().to(device)
+            bt = torch.frombuffer(bytearray(self._bwd), dtype=torch.uint8).clone().to(device)
+            self._dev[key] = (ft, bt)
         return self._dev[key]
 
 
 def _launch_gate(x, gout, meta: GateMeta, backward: bool):
     lib = _lib.load()
-    st, bt = meta.device_tables(x.device)
+    ft, bt = meta.device_tables(x.device)
     N = x.shape[0]
     out = torch.empty((N, meta.din if backward else meta.dout), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device), ktimer.region("gate", x.element_size() * N * (meta.din + meta.dout)):
-        rc = lib.nqa_gate(_dt(x.dtype), 1 if backward else 0, _ptr(x), _ptr(gout), _ptr(out), _ptr(st), meta.n_segs,
-                          _ptr(bt), meta.n_blks, meta.ns, meta.ng, meta.din, meta.dout, N, _stream(x.device))
+        rc = lib.nqa_gate(_dt(x.dtype), 1 if backward else 0, _ptr(x), _ptr(gout), _ptr(out),
+                          _ptr(bt if backward else ft), meta.din, meta.dout, N, _stream(x.device))
     _lib.check(rc, "nqa_gate")
     return out
 

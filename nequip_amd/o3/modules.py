@@ -59,8 +59,17 @@ class Linear(torch.nn.Module):
     def forward(self, x: torch.Tensor, addend: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
         if x.is_cuda and x.dtype in (torch.float32, torch.float64) and self.weight_numel > 0:
             # eval mode: parameter gradients are not produced (inference fast path, as for the radial MLP)
-            w = self.weight if self.training else self.weight.detach()
-            wp = (w * self._scale_vec).unsqueeze(0)
+            if self.training:
+                wp = (self.weight * self._scale_vec).unsqueeze(0)
+            else:
+                # constants in eval mode: the packed (and, on first backward, transposed) weights are built once per
+                # parameter version instead of with a handful of tiny kernels every step
+                key = (id(self.weight), self.weight.data_ptr(), self.weight._version, x.device, x.dtype)
+                cached = getattr(self, "_eval_wp", None)
+                if cached is None or cached[0] != key:
+                    cached = (key, (self.weight.detach() * self._scale_vec).unsqueeze(0).contiguous())
+                    self._eval_wp = cached
+                wp = cached[1]
             return _node_linear(x, wp, None, self._meta, addend=addend, scale=scale)
         out = self._forward_reference(x)
         if scale != 1.0:
@@ -168,13 +177,23 @@ class FullyConnectedTensorProduct(torch.nn.Module):
     def forward_typed(self, x: torch.Tensor, types: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
         if x.is_cuda and self._meta is not None and x.dtype in (torch.float32, torch.float64):
             # per-type pre-contraction W_t[u, w] = sum_v table[t, v] W[u, v, w] (tiny), then ONE fused launch
-            parts = []
-            weight = self.weight if self.training else self.weight.detach()
-            table = table if self.training else table.detach()
-            for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
-                Wt = torch.einsum("tv,uvw->tuw", table, weight[sl].view(shape)) * self._scale[io]
-                parts.append(Wt.reshape(table.shape[0], -1))
-            wp = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+            def contract(weight, table):
+                parts = []
+                for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+                    Wt = torch.einsum("tv,uvw->tuw", table, weight[sl].view(shape)) * self._scale[io]
+                    parts.append(Wt.reshape(table.shape[0], -1))
+                return (torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]).contiguous()
+
+            if self.training:
+                wp = contract(self.weight, table)
+            else:  # constants in eval mode: contracted once per (weight, table) version
+                key = (id(self.weight), self.weight.data_ptr(), self.weight._version, table._version, table.data_ptr(),
+                       x.device, x.dtype)
+                cached = getattr(self, "_eval_wp", None)
+                if cached is None or cached[0] != key:
+                    cached = (key, contract(self.weight.detach(), table.detach()))
+                    self._eval_wp = cached
+                wp = cached[1]
             return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)
         Z = x.shape[0]
         T = table.shape[0]
