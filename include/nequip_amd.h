@@ -250,11 +250,13 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  *   pre-contracted per atom type by the caller) and the residual add `x + sc` (:203-204):
  *     out[z, ob, w, m] = scale * sum_{(ib->ob)} sum_u x[z, ib, u, m] * W[type(z)][ib->ob][u, w]  (+ addend[z,...])
  *   mul_ir layout.  chunk_table: int32 records {o_off, d, mul_out, c0, instr_begin, instr_end, width, 0} (one per
- *   `chunk_width`-channel chunk of an output irrep block, every output element covered exactly once; chunk_width
- *   128 + float32 runs on fp32 MFMA, 64 on the VALU kernel that also serves float64); instr_table: int32
+ *   64-channel chunk of an output irrep block, every output element covered exactly once); instr_table: int32
  *   records {x_off, mul_in, w_off, 0} ([mul_in, mul_out] row-major matrix at weights + type*weight_stride + w_off).
+ *   chunk_width = 64: float32 runs on fp32 MFMA with LDS-staged operands, float64 on the VALU kernel;
+ *   chunk_width = -64 forces the VALU kernel for float32 as well.
  *   atom_types (int64 [N]) is required iff n_types > 1.  The backward w.r.t. x is the same call with transposed
- *   tables/weights.  All tables are device pointers.
+ *   tables/weights.  chunk_table / instr_table are HOST pointers (<= 40 chunks, <= 64 instructions): they are
+ *   copied into the kernel arguments at call time.  x, weights, addend, out, atom_types are device pointers.
  * nqa_gate: e3nn Gate (nequip/nn/convnetlayer.py:104-112,162-164): in = scalars (+) gates (+) gated ->
  *   out = act(scalars) (+) act(gates)[u] * gated[u, :] (act 0 = identity, 1 = silu, 2 = tanh, each times its e3nn
  *   normalize2mom constant `cst`).  col_table: one 32-byte record {int32 a, b, c, d; double cst; int32 e, f} per
@@ -265,8 +267,8 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  * ------------------------------------------------------------------------------------------- */
 int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
-                    int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
-                    double scale, int32_t chunk_width, nqa_stream stream);
+                    int32_t n_instr, int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out,
+                    int64_t num_nodes, double scale, int32_t chunk_width, nqa_stream stream);
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
              const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 

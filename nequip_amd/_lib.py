@@ -114,8 +114,8 @@ SIGNATURES = {
     ),
     "nqa_node_linear": (
         c_int32,
-        [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64]
-        + [c_int32, c_int32, c_int64, c_double, c_int32, c_void_p],
+        [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32]
+        + [c_int64, c_int32, c_int32, c_int64, c_double, c_int32, c_void_p],
     ),
     "nqa_gate": (
         c_int32,

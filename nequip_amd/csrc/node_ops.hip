@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
+#include <cstdlib>
 #include <string>
 
 #include "plan.h"
@@ -32,6 +34,9 @@ struct NodeInstr {  // one (input block -> output block) weight matrix [mul_in, 
   int32_t x_off, mul_in, w_off, pad;
 };
 
+constexpr int kMaxNodeChunks = 40;  // 64-channel chunks of the output irreps per launch
+constexpr int kMaxNodeInstr = 64;   // (input block -> output block) matrices per launch
+
 template <typename T>
 struct NodeLinearArgs {
   const T* __restrict__ x;
@@ -39,12 +44,15 @@ struct NodeLinearArgs {
   const T* __restrict__ addend;  // optional [N, dout]
   T* __restrict__ out;
   const int64_t* __restrict__ types;  // optional [N]
-  const NodeChunk* __restrict__ chunks;
-  const NodeInstr* __restrict__ instr;
   int32_t n_chunks, n_types, din, dout;
   int64_t wstride;
   int64_t N;
   T scale;
+  // The chunk / instruction tables travel in the kernel-argument segment (scalar loads, no dependent global round
+  // trips before the first operand request).
+  NodeChunk chunks[kMaxNodeChunks];
+  NodeInstr instr[kMaxNodeInstr];
+  int32_t blk_begin[kMaxNodeChunks + 1];  // MFMA kernel: first workgroup of every chunk (exact 1-D grid, no idle blocks)
 };
 
 // One u-block: UB consecutive input channels.  The UB weight values are loaded first (independent, coalesced L2
@@ -168,89 +176,242 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs<T
 
 // ---- float32 on the matrix cores ---------------------------------------------------------------------------------
 // Transposed product  D[i = w][j = (z, m)] = sum_u A[i][u] B[u][j]  on v_mfma_f32_32x32x2_f32 (exact fp32):
-//   A[i = w][k = u]   = W[u][w]               weight rows, coalesced global loads (L2 resident), one value per lane
-//   B[k = u][j = z,m] = x[z, x_off + u*d + m]  node rows straight from global/L1 (each lane walks its own row)
-// A wavefront owns floor(32/d) atoms (their d components fill the 32 columns) and up to four 32-channel row tiles of
-// one output block, so every B value feeds up to four MFMAs.  No LDS, no barriers; masks handle ragged edges
-// (odd mul, mul_out not a multiple of 32, partial atom groups) and, for the per-type self-connection, columns whose
-// atom type differs from the weight set being applied.  (A register-double-buffered variant of the batch loop was
-// measured slower -- 0.85 vs 0.69 ms per cfg-3 step -- and is not used.)
+//   A[i = w][k = u]   = W_t[u][c0 + w]          weight slab, staged once per workgroup in LDS
+//   B[k = u][j = z,m] = x[z, x_off + u*d + m]    node-row slab, staged per wavefront in LDS
+// A workgroup owns one 64-channel chunk of one output irrep block; each of its 4 wavefronts owns floor(32/d) atoms
+// (their d components fill the 32 MFMA columns).  The loop runs over "stages" = (instruction, atom type, 64-channel
+// K slab): a stage's weight slab [64][64] is fetched coalesced by the whole workgroup (double-buffered in LDS,
+// requested one stage ahead into registers), its x slab -- for every atom one *contiguous* run of 64*d floats --
+// coalesced by the owning wavefront.  All MFMA operands then come from LDS with conflict-free strides, so HBM/L2
+// only ever sees full-line requests (the first version read x and wrote out as scattered dwords: 3-4x off the
+// roofline).  The result tile goes back through the wavefront's LDS slab and leaves as contiguous 64*d-float runs
+// per atom, fused with the scale and the optional addend (self-connection / residual).  Ragged edges (odd mul,
+// partial atom groups) are handled by zero-filled slabs and masked stores; for the per-type self-connection the
+// columns of atoms whose type differs from the staged weight set are zeroed in the B operand.
 using f32x16n = __attribute__((ext_vector_type(16))) float;
 
+constexpr int kNLW = 64;                       // output channels per chunk (two 32-row MFMA tiles)
+constexpr int kNLK = 64;                       // input channels per stage
+constexpr int kNLXS = 32 * (kNLK + 1);         // floats per wavefront slab: NZT atoms x (64+1)*d, NZT*d <= 32
+
 template <int D>
-__device__ __forceinline__ void node_linear_mfma_item(const NodeLinearArgs<float>& a, const NodeChunk& ch, int64_t g,
-                                                      int lane) {
-  constexpr int NZT = 32 / D;
-  constexpr int TB = 8;  // k-pairs per register batch
+__device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<float>& a, const NodeChunk& ch, int bx,
+                                                       float* __restrict__ ws, float* __restrict__ xs_all) {
+  constexpr int NZT = 32 / D;                               // atoms per wavefront
+  // padded slab stride per atom.  Columns (zl, m) of a k-step read xs[zl*S + u*d + m]: conflict-free iff zl*S + m
+  // are distinct mod 32.  d > 1: S = 64*d + P with P the multiple of 4 >= d (also keeps rows 16-byte aligned for
+  // 128-bit LDS access); d = 1 (32 atoms): S = 65.
+  constexpr int P = D == 1 ? 1 : ((D + 3) / 4) * 4;
+  constexpr int S = kNLK * D + P;
+  constexpr bool kVecLds = (S % 4) == 0;
+  constexpr int RUN4 = kNLK * D / 4;                        // float4 per atom run (64*d floats)
+  constexpr int XV4 = (NZT * RUN4 + 63) / 64;               // float4 per lane per slab
+  static_assert(NZT * S <= kNLXS, "slab too small");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, j = lane & 31;
-  const int zl = j / D, m = j - zl * D;
-  const int64_t z = g * NZT + zl;
-  const bool col_ok = (zl < NZT) && (z < a.N);
+  const int zlr = j / D, m = j - zlr * D;
+  const int zl = min(zlr, NZT - 1);                         // clamped for addressing
+  const int64_t zbase = ((int64_t)bx * 4 + wv) * NZT;  // first atom of this wavefront
+  const int64_t z = zbase + zl;
+  const bool col_ok = (zlr < NZT) && (z < a.N);
   const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
-  const int cw = min(ch.width, ch.mul_out - ch.c0);
-  const int nwt = (cw + 31) >> 5;  // 32-channel row tiles in this chunk (<= 4)
-  f32x16n acc[4];
+  const int cw = min(kNLW, ch.mul_out - ch.c0);
+  float* __restrict__ xs = xs_all + wv * kNLXS;
+
+  // per-lane slab coordinates (loop invariant): float4 v of this lane belongs to atom xz[v], offset 4*xo4[v]
+  int xz[XV4], xo[XV4];
 #pragma unroll
-  for (int wt = 0; wt < 4; ++wt) acc[wt] = (f32x16n){0};
-  for (int q = ch.instr_begin; q < ch.instr_end; ++q) {
-    const NodeInstr ins = a.instr[q];
-    const int K = ins.mul_in;
-    const float* __restrict__ xrow = a.x + (col_ok ? z : 0) * a.din + ins.x_off + m;
-    for (int t = 0; t < a.n_types; ++t) {
-      const float* __restrict__ wbase = a.w + (int64_t)t * a.wstride + ins.w_off + ch.c0 + j;
-      const bool bsel = col_ok && (a.n_types == 1 || tzj == t);
-      for (int k0 = 0; k0 < K; k0 += 2 * TB) {
-        float bq[TB], aq[TB][4];
+  for (int v = 0; v < XV4; ++v) {
+    const int idx = lane + v * 64;
+    xz[v] = idx / RUN4;
+    xo[v] = (idx - xz[v] * RUN4) * 4;
+  }
+
+  // stage enumeration: (instruction q, type t, K slab k0)
+  int q = ch.instr_begin, t = 0, k0 = 0;
+  NodeInstr ins = q < ch.instr_end ? a.instr[q] : NodeInstr{0, 0, 0, 0};
+  auto advance = [&]() {  // -> false when exhausted
+    k0 += kNLK;
+    if (k0 >= ins.mul_in) {
+      k0 = 0;
+      if (++t >= a.n_types) {
+        t = 0;
+        if (++q < ch.instr_end) ins = a.instr[q];
+      }
+    }
+    return q < ch.instr_end;
+  };
+
+  float4 wreg[4];
+  float4 xreg[XV4];
+  auto load_stage = [&](const NodeInstr& si, int st, int sk0) {
+    // weight slab rows u = sk0 .. sk0+63, columns c0 .. c0+63 of W_t [mul_in][mul_out]
+    const float* __restrict__ wb = a.w + (int64_t)st * a.wstride + si.w_off + ch.c0;
+    const bool wal = ((ch.mul_out | ch.c0 | si.w_off) & 3) == 0 && (a.wstride & 3) == 0;
 #pragma unroll
-        for (int i = 0; i < TB; ++i) {
-          const int u = k0 + 2 * i + half;
-          const bool uok = u < K;
-          bq[i] = (bsel && uok) ? xrow[(int64_t)u * D] : 0.f;
-#pragma unroll
-          for (int wt = 0; wt < 4; ++wt)
-            aq[i][wt] = (uok && wt < nwt && (wt * 32 + j) < cw) ? wbase[(int64_t)u * ch.mul_out + wt * 32] : 0.f;
+    for (int v = 0; v < 4; ++v) {
+      const int idx = tid + v * 256;      // float4 index in the [64][16] slab
+      const int u = idx >> 4, c4 = (idx & 15) * 4;
+      const int ug = sk0 + u;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ug < si.mul_in) {
+        const float* __restrict__ p = wb + (int64_t)ug * ch.mul_out + c4;
+        if (wal && c4 + 3 < cw) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (c4 + 0 < cw) r.x = p[0];
+          if (c4 + 1 < cw) r.y = p[1];
+          if (c4 + 2 < cw) r.z = p[2];
+          if (c4 + 3 < cw) r.w = p[3];
         }
+      }
+      wreg[v] = r;
+    }
+    // x slab: atom zz contributes the contiguous run x[zz, x_off + sk0*d .. + 64*d) (zero beyond mul_in)
+    const int kk = min(kNLK, si.mul_in - sk0) * D;  // valid floats per atom
+    const bool xal = ((a.din | si.x_off) & 3) == 0;  // (sk0*d is a multiple of 64)
 #pragma unroll
-        for (int i = 0; i < TB; ++i) {
+    for (int v = 0; v < XV4; ++v) {
+      const int64_t zg = zbase + xz[v];
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xz[v] < NZT && zg < a.N && xo[v] < kk) {
+        const float* __restrict__ p = a.x + zg * a.din + si.x_off + sk0 * D + xo[v];
+        if (xal && xo[v] + 3 < kk) {
+          r = *reinterpret_cast<const float4*>(p);
+        } else {
+          r.x = p[0];
+          if (xo[v] + 1 < kk) r.y = p[1];
+          if (xo[v] + 2 < kk) r.z = p[2];
+          if (xo[v] + 3 < kk) r.w = p[3];
+        }
+      }
+      xreg[v] = r;
+    }
+  };
+  auto store_stage = [&](int buf) {
 #pragma unroll
-          for (int wt = 0; wt < 4; ++wt)
-            if (wt < nwt) acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i][wt], bq[i], acc[wt], 0, 0, 0);
+    for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(ws + buf * (kNLK * kNLW) + (tid + v * 256) * 4) = wreg[v];
+#pragma unroll
+    for (int v = 0; v < XV4; ++v) {
+      if (xz[v] < NZT) {
+        float* __restrict__ d = xs + xz[v] * S + xo[v];
+        if constexpr (kVecLds) {
+          *reinterpret_cast<float4*>(d) = xreg[v];
+        } else {
+          d[0] = xreg[v].x; d[1] = xreg[v].y; d[2] = xreg[v].z; d[3] = xreg[v].w;
         }
       }
     }
+  };
+
+  f32x16n acc0 = {0}, acc1 = {0};
+  bool have = q < ch.instr_end;
+  if (have) {
+    load_stage(ins, t, k0);
+    store_stage(0);
   }
-  if (col_ok) {
-    const int64_t obase = z * a.dout + ch.o_off + m;
+  __syncthreads();
+  int buf = 0;
+  while (have) {
+    const int cur_t = t;
+    const bool more = advance();
+    if (more) load_stage(ins, t, k0);  // next stage -> registers, lands behind the MFMAs below
+    const bool bsel = col_ok && (a.n_types == 1 || tzj == cur_t);
+    const float* __restrict__ wsb = ws + buf * (kNLK * kNLW) + j;
+    const float* __restrict__ xb = xs + zl * S + m;
+    // LDS operand reads of the next register batch are issued between the MFMAs of the current one
+    constexpr int TB = 4;
+    float bq[2][TB], a0[2][TB], a1[2][TB];
 #pragma unroll
-    for (int wt = 0; wt < 4; ++wt) {
-      if (wt >= nwt) continue;
+    for (int i = 0; i < TB; ++i) {
+      const int u = 2 * i + half;
+      bq[0][i] = xb[u * D];
+      a0[0][i] = wsb[u * kNLW];
+      a1[0][i] = wsb[u * kNLW + 32];
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int wl = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (wl < cw) {
-          const int64_t o = obase + (int64_t)(ch.c0 + wl) * D;
-          float v = a.scale * acc[wt][r];
-          if (a.addend != nullptr) v += a.addend[o];
-          a.out[o] = v;
+    for (int b = 0; b < kNLK / 2 / TB; ++b) {
+      if (b + 1 < kNLK / 2 / TB) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int u = 2 * ((b + 1) * TB + i) + half;
+          bq[(b + 1) & 1][i] = xb[u * D];
+          a0[(b + 1) & 1][i] = wsb[u * kNLW];
+          a1[(b + 1) & 1][i] = wsb[u * kNLW + 32];
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        const float bv = bsel ? bq[b & 1][i] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[b & 1][i], bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[b & 1][i], bv, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wavefront is done with ws[buf ^ 1]'s previous contents and with its own x slab
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    have = more;
+  }
+
+  // result tile -> this wavefront's slab as [atom][w*d + m] (same padded stride), then contiguous runs per atom
+  if (zlr < NZT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      xs[zl * S + wl * D + m] = acc0[r];
+      xs[zl * S + (wl + 32) * D + m] = acc1[r];
+    }
+  }
+  // (same wavefront wrote what it reads: LDS operations of a wavefront complete in order)
+  const int run = cw * D;  // valid floats per atom
+  const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
+#pragma unroll
+  for (int v = 0; v < XV4; ++v) {
+    const int64_t zg = zbase + xz[v];
+    if (xz[v] < NZT && zg < a.N && xo[v] < run) {
+      const float* __restrict__ sp = xs + xz[v] * S + xo[v];
+      float4 r;
+      if constexpr (kVecLds) {
+        r = *reinterpret_cast<const float4*>(sp);
+      } else {
+        r = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      }
+      const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + xo[v];
+      r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+      if (oal && xo[v] + 3 < run) {
+        if (a.addend != nullptr) {
+          const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+          r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+        }
+        *reinterpret_cast<float4*>(a.out + o) = r;
+      } else {
+        const float rv[4] = {r.x, r.y, r.z, r.w};
+        for (int e = 0; e < 4; ++e)
+          if (xo[v] + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
       }
     }
   }
 }
 
 __global__ __launch_bounds__(256) void node_linear_mfma_kernel(const NodeLinearArgs<float> a) {
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const NodeChunk ch = a.chunks[blockIdx.y];
-  const int64_t g = (int64_t)blockIdx.x * 4 + wv;
-  const int nzt = 32 / ch.d;
-  if (g * nzt >= a.N) return;
+  __shared__ __align__(16) float ws[2 * kNLK * kNLW];  // 32 KiB: double-buffered weight slab
+  __shared__ __align__(16) float xs[4 * kNLXS];        // 4 x 8.1 KiB: per-wavefront x / result slabs
+  // exact 1-D grid: chunk c owns workgroups [blk_begin[c], blk_begin[c+1])
+  int c = 0;
+  while (c + 1 < a.n_chunks && (int)blockIdx.x >= a.blk_begin[c + 1]) ++c;
+  const NodeChunk ch = a.chunks[c];
+  const int bx = (int)blockIdx.x - a.blk_begin[c];
   switch (ch.d) {
-    case 1: node_linear_mfma_item<1>(a, ch, g, lane); break;
-    case 3: node_linear_mfma_item<3>(a, ch, g, lane); break;
-    case 5: node_linear_mfma_item<5>(a, ch, g, lane); break;
-    case 7: node_linear_mfma_item<7>(a, ch, g, lane); break;
-    case 9: node_linear_mfma_item<9>(a, ch, g, lane); break;
+    case 1: node_linear_mfma_block<1>(a, ch, bx, ws, xs); break;
+    case 3: node_linear_mfma_block<3>(a, ch, bx, ws, xs); break;
+    case 5: node_linear_mfma_block<5>(a, ch, bx, ws, xs); break;
+    case 7: node_linear_mfma_block<7>(a, ch, bx, ws, xs); break;
+    case 9: node_linear_mfma_block<9>(a, ch, bx, ws, xs); break;
     default: break;
   }
 }
@@ -346,20 +507,25 @@ extern "C" {
 
 int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
-                    int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
+                    int32_t n_instr, int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
                     double scale, int32_t chunk_width, nqa_stream stream) {
-  // chunk_width 128: float32 tables for the MFMA kernel; 64: tables for the VALU kernel (float64, or float32 by choice)
-  const bool use_mfma = dtype == NQA_F32 && chunk_width == 128;
-  if (chunk_width != 64 && chunk_width != 128) {
-    set_error("nqa_node_linear: chunk_width must be 64 or 128");
+  // 64-channel chunk tables serve both kernels: float32 runs on fp32 MFMA (chunk_width 64) or, on request
+  // (chunk_width -64), on the VALU kernel that also serves float64
+  const bool use_mfma = dtype == NQA_F32 && chunk_width == 64;
+  if (chunk_width != 64 && chunk_width != -64) {
+    set_error("nqa_node_linear: chunk_width must be 64 (or -64: VALU kernel)");
     return NQA_ERR_INVALID;
   }
   if (dtype != NQA_F32 && dtype != NQA_F64) {
     set_error("nqa_node_linear: unsupported dtype");
     return NQA_ERR_UNSUPPORTED;
   }
-  if (num_nodes < 0 || n_chunks < 0 || n_types < 1 || dim_in <= 0 || dim_out <= 0 ||
-      (num_nodes > 0 && (!x || !weights || !out || !chunk_table || !instr_table)) ||
+  if (n_chunks > kMaxNodeChunks || n_instr > kMaxNodeInstr) {
+    set_error("nqa_node_linear: more than 40 output chunks or 64 instructions in one call");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (num_nodes < 0 || n_chunks < 0 || n_instr < 0 || n_types < 1 || dim_in <= 0 || dim_out <= 0 ||
+      (num_nodes > 0 && (!x || !weights || !out || !chunk_table || (n_instr > 0 && !instr_table))) ||
       (n_types > 1 && atom_types == nullptr)) {
     set_error("nqa_node_linear: invalid argument");
     return NQA_ERR_INVALID;
@@ -381,8 +547,8 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     a.addend = static_cast<const float*>(addend);
     a.out = static_cast<float*>(out);
     a.types = n_types > 1 ? atom_types : nullptr;
-    a.chunks = static_cast<const NodeChunk*>(chunk_table);
-    a.instr = static_cast<const NodeInstr*>(instr_table);
+    std::memcpy(a.chunks, chunk_table, sizeof(NodeChunk) * (size_t)n_chunks);
+    if (n_instr > 0) std::memcpy(a.instr, instr_table, sizeof(NodeInstr) * (size_t)n_instr);
     a.n_chunks = n_chunks;
     a.n_types = n_types;
     a.din = dim_in;
@@ -391,10 +557,20 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     a.N = num_nodes;
     a.scale = (float)scale;
     if (use_mfma) {
-      // grid.x is sized for the irrep with the fewest atoms per wavefront (d = 9 -> 3 atoms); surplus wavefronts of
-      // chunks with smaller d exit immediately
-      const int64_t groups = (num_nodes + 2) / 3;
-      const dim3 mgrid((unsigned)((groups + 3) / 4), (unsigned)n_chunks);
+      int64_t nblk = 0;
+      for (int c = 0; c < n_chunks; ++c) {
+        a.blk_begin[c] = (int32_t)nblk;
+        const int d = a.chunks[c].d;
+        if (d != 1 && d != 3 && d != 5 && d != 7 && d != 9) {
+          set_error("nqa_node_linear: irrep dimension above 9 (l > 4)");
+          return NQA_ERR_UNSUPPORTED;
+        }
+        const int per_blk = 4 * (32 / d);  // atoms per workgroup
+        nblk += (num_nodes + per_blk - 1) / per_blk;
+      }
+      a.blk_begin[n_chunks] = (int32_t)nblk;
+      if (nblk == 0) return NQA_OK;
+      const dim3 mgrid((unsigned)nblk);
       hipLaunchKernelGGL(node_linear_mfma_kernel, mgrid, dim3(256), 0, s, a);
     } else {
       if (smem > 64 * 1024)
@@ -409,8 +585,8 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     a.addend = static_cast<const double*>(addend);
     a.out = static_cast<double*>(out);
     a.types = n_types > 1 ? atom_types : nullptr;
-    a.chunks = static_cast<const NodeChunk*>(chunk_table);
-    a.instr = static_cast<const NodeInstr*>(instr_table);
+    std::memcpy(a.chunks, chunk_table, sizeof(NodeChunk) * (size_t)n_chunks);
+    if (n_instr > 0) std::memcpy(a.instr, instr_table, sizeof(NodeInstr) * (size_t)n_instr);
     a.n_chunks = n_chunks;
     a.n_types = n_types;
     a.din = dim_in;

@@ -54,9 +54,7 @@ class NodeLinearMeta:
         # transposed weights: same instruction order, each [mul_out, mul_in]
         self.fwd = self._tables(self.irreps_out, out_off, in_off, self.irreps_in, True, 64)
         self.bwd = self._tables(self.irreps_in, in_off, out_off, self.irreps_out, False, 64)
-        self.fwd128 = self._tables(self.irreps_out, out_off, in_off, self.irreps_in, True, 128)
-        self.bwd128 = self._tables(self.irreps_in, in_off, out_off, self.irreps_out, False, 128)
-        self._dev = {}
+        self._host = {}
 
     def _tables(self, side_out: Irreps, off_out, off_in, side_in: Irreps, by_out: bool, width: int):
         chunks: List[Tuple[int, ...]] = []
@@ -74,14 +72,15 @@ class NodeLinearMeta:
                 chunks.append((off_out[b], ir.dim, mul_o, c0, begin, end, width, 0))
         return chunks, instr
 
-    def device_tables(self, device, which: str, width: int = 64):
-        key = (str(device), which, width)
-        if key not in self._dev:
-            chunks, instr = getattr(self, which + ("128" if width == 128 else ""))
-            ct = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 8).to(device)
-            it = torch.tensor(instr if instr else [(0, 0, 0, 0)], dtype=torch.int32).reshape(-1, 4).to(device)
-            self._dev[key] = (ct, len(chunks), it)
-        return self._dev[key]
+    def host_tables(self, which: str):
+        """(chunk bytes, n_chunks, instr bytes, n_instr): the tables are passed by host pointer (kernel arguments)."""
+        if which not in self._host:
+            chunks, instr = getattr(self, which)
+            cb = b"".join(struct.pack("<8i", *c) for c in chunks)
+            ib = b"".join(struct.pack("<4i", *i) for i in instr)
+            self._host[which] = (ctypes.create_string_buffer(cb, max(len(cb), 1)), len(chunks),
+                                 ctypes.create_string_buffer(ib, max(len(ib), 1)), len(instr))
+        return self._host[which]
 
     def transpose_weights(self, wp: torch.Tensor) -> torch.Tensor:
         """[T, wstride] packed forward weights -> packed transposed weights with the same offsets."""
@@ -95,15 +94,16 @@ class NodeLinearMeta:
 
 def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale: float):
     lib = _lib.load()
-    width = 128 if x.dtype == torch.float32 else 64  # float32: fp32-MFMA kernel; float64: VALU kernel
-    ct, nchunks, it = meta.device_tables(x.device, which, width)
+    width = 64  # 64-channel chunks: float32 on the fp32-MFMA kernel, float64 on the VALU kernel
+    ct, nchunks, it, ninstr = meta.host_tables(which)
     din, dout = (meta.din, meta.dout) if which == "fwd" else (meta.dout, meta.din)
     N = x.shape[0]
     out = torch.empty((N, dout), dtype=x.dtype, device=x.device)
     flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
     with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
         rc = lib.nqa_node_linear(
-            _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types), _ptr(ct), nchunks, _ptr(it),
+            _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types),
+            ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p), ninstr,
             wp.shape[0], wp.shape[1], din, dout, N, float(scale), width, _stream(x.device),
         )  # fmt: skip
     _lib.check(rc, "nqa_node_linear")
