@@ -17,18 +17,20 @@ from collections import defaultdict
 out_dir, tag = sys.argv[1], sys.argv[2]
 
 # bench.py region name -> substrings identifying the GPU kernels launched inside that region
-REGIONS = {  # region: (main kernel family, helper kernels that run once per launch)
-    "tp_fwd": (["::fwd_kernel<", "tp_fwd_kernel"], []),
-    "tp_bwd_edge": (["::bwd_edge_kernel<", "tp_bwd_edge_kernel"], ["spec_gy_reduce_kernel", "tp_ypart_reduce_kernel"]),
-    "tp_bwd_x": (["::bwd_x_kernel<", "tp_bwd_x_kernel"], []),
-    "tp_bwd_fused": (["::bwd_fused_kernel<"], ["edge_rows_sum_kernel", "spec_gy_reduce_kernel"]),
-    "radial_mlp_fwd": (["radial_mlp_fwd_kernel"], []),
-    "radial_mlp_bwd": (["radial_mlp_bwd_kernel"], ["radial_mlp_transpose_w1_kernel"]),
-    "node_linear": (["node_linear_kernel", "node_linear_mfma_kernel"], []),
-    "gate": (["gate_fwd_kernel", "gate_bwd_kernel"], []),
-    "edge_embed_fwd": (["edge_embed_fwd_kernel"], []),
-    "edge_embed_bwd": (["edge_embed_bwd_kernel"], []),
-    "edge_vectors": (["edge_vectors_fwd_kernel", "edge_vectors_bwd_kernel"], []),
+REGIONS = {  # region: (regexes of the main kernel family, regexes of helper kernels that run once per launch)
+    "tp_fwd": ([r"::fwd_kernel<", r"tp_fwd_kernel"], []),
+    "tp_bwd_edge": ([r"::bwd_edge_kernel<float, \d, false", r"tp_bwd_edge_kernel"],
+                    [r"spec_gy_reduce_kernel", r"tp_ypart_reduce_kernel"]),
+    "tp_bwd_x": ([r"::bwd_x_kernel<", r"tp_bwd_x_kernel"], []),
+    "tp_bwd_fused": ([r"::bwd_edge_kernel<float, \d, true"], [r"gx_rows_sum_kernel"]),
+    "radial_mlp_fwd": ([r"radial_mlp_fwd(_bf16x6)?_kernel"], [r"radial_mlp_split_w1_fwd_kernel"]),
+    "radial_mlp_bwd": ([r"radial_mlp_bwd(_bf16x6)?_kernel"],
+                       [r"radial_mlp_transpose_w1_kernel", r"radial_mlp_split_w1_bwd_kernel"]),
+    "node_linear": ([r"node_linear_kernel", r"node_linear_mfma_kernel"], []),
+    "gate": ([r"gate_fwd_kernel", r"gate_bwd_kernel"], []),
+    "edge_embed_fwd": ([r"edge_embed_fwd_kernel"], []),
+    "edge_embed_bwd": ([r"edge_embed_bwd_kernel"], []),
+    "edge_vectors": ([r"edge_vectors_fwd_kernel", r"edge_vectors_bwd_kernel"], []),
 }
 
 stats = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -64,12 +66,12 @@ for k, v in per.items():
 
 bench = {}
 for region, (main_pats, helper_pats) in REGIONS.items():
-    ks = [k for k in per if any(p in k for p in main_pats + helper_pats)]
+    ks = [k for k in per if any(re.search(p, k) for p in main_pats + helper_pats)]
     if not ks:
         continue
     # bytes per *region launch*: dispatch-weighted mean over the kernels of the region's main kernel family, plus
     # helper kernels (reductions / prepasses) that run once per launch
-    main = [k for k in ks if any(p in k for p in main_pats)]
+    main = [k for k in ks if any(re.search(p, k) for p in main_pats)]
     helpers = [k for k in ks if k not in main]
     nd = sum(per[k]["dispatches"] for k in main)
     if nd == 0:
