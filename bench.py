@@ -91,10 +91,21 @@ def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
     cfg = model_cfg(w, n_edges / n_atoms)
     model = build_model(cfg, names, torch.device("cpu"))
     weights = {k.replace("model.func.", ""): v.detach() for k, v in model.state_dict().items()}
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     specs = omodel.build_specs(cfg)
-    omodel.energy_forces(data, cfg, weights, specs)  # warm-up
+    # thread count: the oracle is a chain of small ATen ops -- all host cores (256 on the GPU box) oversubscribe it by
+    # orders of magnitude, so a few moderate settings are tried once each and the fastest is used (and reported)
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nthreads in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+        torch.set_num_threads(nthreads)
+        omodel.energy_forces(data, cfg, weights, specs)  # warm-up
+        t0 = time.perf_counter()
+        omodel.energy_forces(data, cfg, weights, specs)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nthreads)
+    cores = best[1]
+    torch.set_num_threads(cores)
     times = []
     t_start = time.perf_counter()
     while len(times) < 10 and (time.perf_counter() - t_start) < max_seconds:
