@@ -39,6 +39,8 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
             num_batch = 1
         pos = data[K.POSITIONS_KEY]
         has_cell = K.CELL_KEY in data
+        if not self.training and pos.is_cuda and pos.dtype == torch.float64:
+            return self._forward_inference(data, pos, batch, num_batch, has_cell)
         if has_cell:
             orig_cell = data[K.CELL_KEY]
             cell = orig_cell.view(-1, 3, 3).expand(num_batch, 3, 3)
@@ -81,4 +83,58 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         data[K.POSITIONS_KEY] = pos
         if not did_pos_req_grad:
             pos.requires_grad_(False)
+        return data
+
+    def _forward_inference(self, data, pos, batch, num_batch: int, has_cell: bool):
+        """First-order (eval mode) evaluation of the same quantities without the strain bookkeeping.
+
+        With ``edge_vec = (pos_j - pos_i + shift @ cell) (1 + eps_sym)`` the reference's symmetric-displacement gradient is
+        ``dE/d eps = sym(sum_e edge_vec_e (x) g_e)`` with ``g_e = dE/d edge_vec_e``, and ``dE/d pos`` is the adjoint of the
+        edge-vector map applied to ``g``.  So: edge vectors once (HIP kernel, leaf of the autograd graph), one
+        ``autograd.grad`` w.r.t. them, and ONE pass of the atomics-free adjoint kernel that returns both the per-atom
+        position gradient and the per-atom ``sum_e edge_vec_e (x) g_e`` -- instead of ~40 small float64 ATen kernels for
+        building, differentiating and reducing the displaced positions / cell.  Training (second order) keeps the
+        reference formulation above.
+        """
+        from .. import _lib
+        from ._topology import _ptr, current_stream_ptr, topology_cache
+        from .utils import _EdgeVectorsFn
+
+        K = AtomicDataDict
+        lib = _lib.load()
+        edge_index = data[K.EDGE_INDEX_KEY]
+        cell = data[K.CELL_KEY].view(-1, 3, 3).expand(num_batch, 3, 3) if has_cell else None
+        shift = data[K.EDGE_CELL_SHIFT_KEY].contiguous() if has_cell else None
+        ebatch = batch.contiguous() if (has_cell and batch is not None) else None
+        with torch.no_grad():
+            edge_vec = _EdgeVectorsFn.apply(pos.detach(), cell, edge_index, shift, ebatch)
+        edge_vec.requires_grad_(True)
+        data[K.EDGE_VECTORS_KEY] = edge_vec
+        data = self.func(data)
+        g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].contiguous()
+        num_nodes = pos.shape[0]
+        topo = topology_cache.get(edge_index[0], edge_index[1], num_nodes)
+        rp_d, eid_d, _ = topo.by_dst
+        rp_s, eid_s, _ = topo.by_src
+        ev = edge_vec.detach()
+        g_pos = torch.empty((num_nodes, 3), dtype=torch.float64, device=pos.device)
+        part = torch.empty((num_nodes, 9), dtype=torch.float64, device=pos.device)
+        with torch.cuda.device(pos.device):
+            # the kernel's generic per-edge left factor (the cell shift in the autograd adjoint) is the edge vector here:
+            # part[n] = sum_{e: centre(e) = n} edge_vec_e (x) g_e
+            rc = lib.nqa_edge_vectors_bwd(_ptr(g), _ptr(ev), _ptr(rp_d), _ptr(eid_d), _ptr(rp_s), _ptr(eid_s),
+                                          num_nodes, _ptr(g_pos), _ptr(part), current_stream_ptr(pos.device))
+        _lib.check(rc, "nqa_edge_vectors_bwd")
+        data[K.FORCE_KEY] = torch.neg(g_pos)
+        if num_batch > 1:
+            m = torch.zeros((num_batch, 9), dtype=torch.float64, device=pos.device).index_add_(0, batch, part)
+        else:
+            m = part.sum(0, keepdim=True)
+        m = m.view(num_batch, 3, 3)
+        virial = 0.5 * (m + m.transpose(-1, -2))
+        if has_cell:
+            volume = torch.sum(cell[:, 0] * torch.linalg.cross(cell[:, 1], cell[:, 2], dim=-1), dim=-1).abs()
+            data[K.STRESS_KEY] = virial / volume.view(num_batch, 1, 1)
+        data[K.VIRIAL_KEY] = torch.neg(virial)
+        data[K.EDGE_VECTORS_KEY] = ev
         return data

@@ -95,11 +95,15 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             else:
                 sc = self.sc(x, node_attrs)
 
-        x = self.linear_1(x)
-
-        data[AtomicDataDict.NODE_FEATURES_KEY] = x
-        data = self.avg_num_neighbors_norm(data)
-        x = data[AtomicDataDict.NODE_FEATURES_KEY]
+        norm = self.avg_num_neighbors_norm
+        if norm.norm_shortcut and x.is_cuda and norm.norm_key not in data:
+            # one avg_num_neighbors for all types: 1/sqrt(avg) rides on the linear_1 launch (no separate N x D pass)
+            x = self.linear_1(x, scale=norm.norm_scalar)
+        else:
+            x = self.linear_1(x)
+            data[AtomicDataDict.NODE_FEATURES_KEY] = x
+            data = norm(data)
+            x = data[AtomicDataDict.NODE_FEATURES_KEY]
 
         x = self.tp_scatter(
             x=x,

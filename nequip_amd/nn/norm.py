@@ -24,6 +24,8 @@ class AvgNumNeighborsNorm(torch.nn.Module):
         norm_const = torch.tensor([(1.0 / sqrt(N)) for N in avg_num_neighbors]).reshape(-1, 1)
         self.register_buffer("norm_const", norm_const, persistent=False)
         self.norm_shortcut = self.norm_const.numel() == 1
+        # python float for callers that fold the (type-independent) factor into their own kernel launch
+        self.norm_scalar = float(norm_const.reshape(-1)[0]) if self.norm_shortcut else None
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         features = data[self.in_field]
