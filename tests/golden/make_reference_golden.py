@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Golden vectors produced by the REFERENCE's own code (mir-group/nequip under /root/reference), for the rows of the
+hot path whose arithmetic lives in nequip itself rather than in e3nn:
+
+    a1  with_edge_vectors_                          nequip/nn/utils.py:68-118
+    a3  EdgeLengthNormalizer, BesselEdgeLengthEncoding, PolynomialCutoff
+                                                    nequip/nn/embedding/_edge.py:18-151, cutoffs.py:17-27
+    a4  ScalarMLPFunction (the radial MLP)          nequip/nn/mlp.py:81-268
+    a6  AvgNumNeighborsNorm                         nequip/nn/norm.py:7-68
+        PerTypeScaleShift, AtomwiseReduce           nequip/nn/atomwise.py:62-284
+    a12 ForceStressOutput (forces, virial, stress by autograd through a pair-energy stand-in)
+                                                    nequip/nn/grad_output.py:107-298
+
+``e3nn`` (and the training-stack packages nequip imports at package level) are not installed here, so they are
+replaced by inert stand-in modules: every module listed above is plain PyTorch and never calls into them at run time
+(irreps bookkeeping objects are the only thing the stand-ins absorb).  What still cannot be produced this way is
+anything computed BY e3nn: spherical harmonics, Clebsch-Gordan tensor products, o3.Linear, Gate -- for those the oracle
+remains a restatement ("parity unpinned").
+
+    python tests/golden/make_reference_golden.py     # needs /root/reference; rewrites tests/golden/ref_*.npz
+
+The fixtures travel to the GPU box (the reference does not) and are checked by tests/test_reference_golden.py.
+"""
+
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = os.environ.get("NEQUIP_REFERENCE", "/root/reference")
+
+
+# ---- inert stand-ins for packages that are not installed -----------------------------------------------------
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:  # used as a decorator
+            return a[0]
+        return _Any()
+
+    def __getattr__(self, n):
+        if n.startswith("__") and n.endswith("__"):
+            raise AttributeError(n)
+        return _Any()
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+    def __iter__(self):
+        return iter(())
+
+    def __getitem__(self, k):
+        return _Any()
+
+    def __eq__(self, other):  # irreps bookkeeping objects always "match"
+        return True
+
+    def __ne__(self, other):
+        return False
+
+    def __hash__(self):
+        return 0
+
+
+class _Mod(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith("__") and n.endswith("__"):
+            raise AttributeError(n)
+        return _Any()
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    TOPS = {"e3nn", "omegaconf", "hydra", "lightning", "torchmetrics", "ase", "matscipy", "vesin", "tqdm_joblib", "lmdb",
+            "opt_einsum_fx", "pytorch_lightning", "wandb", "torch_ema", "lightning_utilities"}
+
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in self.TOPS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Mod(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def _import_reference():
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, REFERENCE)
+    from nequip.data import AtomicDataDict
+    from nequip.nn import atomwise, grad_output, mlp, norm
+    from nequip.nn import utils as nn_utils
+    from nequip.nn.embedding import _edge, cutoffs
+
+    return AtomicDataDict, atomwise, grad_output, mlp, norm, nn_utils, _edge, cutoffs
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    K, atomwise, grad_output, mlp, norm, nn_utils, _edge, cutoffs = _import_reference()
+    torch.set_default_dtype(torch.float32)
+    g = torch.Generator().manual_seed(20260924)
+
+    # ---- a1: edge vectors (single periodic frame, and a batch of two frames) --------------------------------
+    def frame(n, L):
+        pos = torch.rand(n, 3, generator=g, dtype=torch.float64) * L
+        cell = torch.eye(3, dtype=torch.float64) * L + 0.05 * torch.randn(3, 3, generator=g, dtype=torch.float64)
+        E = 4 * n
+        ei = torch.randint(0, n, (2, E), generator=g)
+        sh = torch.randint(-1, 2, (E, 3), generator=g).to(torch.float64)
+        return pos, cell, ei, sh
+
+    out = {}
+    pos, cell, ei, sh = frame(12, 5.0)
+    pos.requires_grad_(True)
+    cell_r = cell.clone().view(1, 3, 3).requires_grad_(True)
+    data = {K.POSITIONS_KEY: pos, K.CELL_KEY: cell_r, K.EDGE_INDEX_KEY: ei, K.EDGE_CELL_SHIFT_KEY: sh}
+    data = nn_utils.with_edge_vectors_(data, with_lengths=True)
+    coef = torch.randn(ei.shape[1], 3, generator=g, dtype=torch.float64)
+    gp, gc = torch.autograd.grad((data[K.EDGE_VECTORS_KEY] * coef).sum(), [pos, cell_r])
+    out.update(s_pos=_np(pos), s_cell=_np(cell_r), s_edge_index=_np(ei), s_shift=_np(sh), s_coef=_np(coef),
+               s_vec=_np(data[K.EDGE_VECTORS_KEY]), s_len=_np(data[K.EDGE_LENGTH_KEY]), s_gpos=_np(gp), s_gcell=_np(gc))
+    # batch of two frames
+    p1, c1, e1, s1 = frame(7, 4.0)
+    p2, c2, e2, s2 = frame(9, 6.0)
+    pos = torch.cat([p1, p2]).requires_grad_(True)
+    cells = torch.stack([c1, c2]).requires_grad_(True)
+    ei = torch.cat([e1, e2 + 7], dim=1)
+    sh = torch.cat([s1, s2])
+    batch = torch.cat([torch.zeros(7, dtype=torch.long), torch.ones(9, dtype=torch.long)])
+    data = {K.POSITIONS_KEY: pos, K.CELL_KEY: cells, K.EDGE_INDEX_KEY: ei, K.EDGE_CELL_SHIFT_KEY: sh,
+            K.BATCH_KEY: batch, K.NUM_NODES_KEY: torch.tensor([7, 9])}
+    data = nn_utils.with_edge_vectors_(data, with_lengths=True)
+    coef = torch.randn(ei.shape[1], 3, generator=g, dtype=torch.float64)
+    gp, gc = torch.autograd.grad((data[K.EDGE_VECTORS_KEY] * coef).sum(), [pos, cells])
+    out.update(b_pos=_np(pos), b_cell=_np(cells), b_edge_index=_np(ei), b_shift=_np(sh), b_batch=_np(batch),
+               b_coef=_np(coef), b_vec=_np(data[K.EDGE_VECTORS_KEY]), b_gpos=_np(gp), b_gcell=_np(gc))
+    np.savez_compressed(os.path.join(HERE, "ref_edge_vectors.npz"), **out)
+
+    # ---- a3: length normaliser + Bessel x polynomial cutoff ---------------------------------------------------
+    out = {}
+    r_max = 4.5
+    vec = torch.randn(96, 3, generator=g, dtype=torch.float64) * 2.0
+    vec[0] = torch.tensor([0.0, 5.0, 0.0])      # beyond the cutoff
+    vec[1] = torch.tensor([0.0, 0.0, 4.5])      # exactly at the cutoff
+    vec[2] = torch.tensor([1e-3, 0.0, 0.0])     # very short
+    for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dt)  # the reference modules take their output dtype from the default dtype
+        normalizer = _edge.EdgeLengthNormalizer(r_max=r_max, type_names=["A", "B"])
+        bessel = _edge.BesselEdgeLengthEncoding(cutoff=cutoffs.PolynomialCutoff(6), num_bessels=8, trainable=False)
+        v = vec.clone().requires_grad_(True)
+        data = {K.EDGE_VECTORS_KEY: v}
+        data = bessel(normalizer(data))
+        emb = data[K.EDGE_EMBEDDING_KEY]
+        cot = torch.randn(emb.shape, generator=g, dtype=torch.float64).to(emb.dtype)
+        (gv,) = torch.autograd.grad((emb * cot).sum(), [v])
+        out.update({f"emb_{dt_name}": _np(emb), f"cutoff_{dt_name}": _np(data[K.EDGE_CUTOFF_KEY]),
+                    f"normed_{dt_name}": _np(data["normed_edge_lengths"]), f"cot_{dt_name}": _np(cot),
+                    f"gvec_{dt_name}": _np(gv)})
+    torch.set_default_dtype(torch.float32)
+    out.update(vec=_np(vec), r_max=np.float64(r_max), bessel_weights=_np(bessel.bessel_weights))
+    np.savez_compressed(os.path.join(HERE, "ref_radial_basis.npz"), **out)
+
+    # ---- a4: ScalarMLPFunction as the radial MLP ---------------------------------------------------------------
+    out = {}
+    for tag, (din, width, depth, dout) in {"d1": (8, 64, 1, 96), "d2": (8, 32, 2, 40), "d0": (8, None, 0, 24)}.items():
+        torch.manual_seed(hash(tag) % 1000)
+        m = mlp.ScalarMLPFunction(input_dim=din, output_dim=dout, hidden_layers_depth=depth, hidden_layers_width=width,
+                                  nonlinearity="silu", bias=False)
+        x = (torch.randn(50, din, generator=g) * 0.7).requires_grad_(True)
+        y = m(x)
+        cot = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad((y * cot).sum(), [x] + list(m.parameters()))
+        out[f"{tag}_x"], out[f"{tag}_y"], out[f"{tag}_cot"], out[f"{tag}_gx"] = _np(x), _np(y), _np(cot), _np(grads[0])
+        for i, (p, gp_) in enumerate(zip(m.parameters(), grads[1:])):
+            out[f"{tag}_w{i}"], out[f"{tag}_gw{i}"] = _np(p), _np(gp_)
+    np.savez_compressed(os.path.join(HERE, "ref_scalar_mlp.npz"), **out)
+
+    # ---- a6 + readout helpers ------------------------------------------------------------------------------------
+    out = {}
+    names = ["H", "O"]
+    types = torch.randint(0, 2, (20,), generator=g)
+    feats = torch.randn(20, 24, generator=g)
+    n1 = norm.AvgNumNeighborsNorm(type_names=names, avg_num_neighbors=39.5)
+    n2 = norm.AvgNumNeighborsNorm(type_names=names, avg_num_neighbors={"H": 31.0, "O": 47.0})
+    d1 = n1({K.NODE_FEATURES_KEY: feats.clone(), K.ATOM_TYPE_KEY: types})
+    d2 = n2({K.NODE_FEATURES_KEY: feats.clone(), K.ATOM_TYPE_KEY: types})
+    e_atom = torch.randn(20, 1, generator=g)
+    pts = atomwise.PerTypeScaleShift(type_names=names, field=K.PER_ATOM_ENERGY_KEY, out_field=K.PER_ATOM_ENERGY_KEY,
+                                     scales={"H": 1.7, "O": 0.6}, shifts={"H": -3.1, "O": 5.5},
+                                     irreps_in={K.PER_ATOM_ENERGY_KEY: "0e"})
+    d3 = pts({K.PER_ATOM_ENERGY_KEY: e_atom.clone(), K.ATOM_TYPE_KEY: types})
+    batch = torch.sort(torch.randint(0, 3, (20,), generator=g)).values
+    red = atomwise.AtomwiseReduce(field=K.PER_ATOM_ENERGY_KEY, out_field=K.TOTAL_ENERGY_KEY, reduce="sum",
+                                  irreps_in={K.PER_ATOM_ENERGY_KEY: "0e"})
+    d4 = red({K.PER_ATOM_ENERGY_KEY: d3[K.PER_ATOM_ENERGY_KEY], K.BATCH_KEY: batch,
+              K.NUM_NODES_KEY: torch.bincount(batch, minlength=3)})
+    out.update(types=_np(types), feats=_np(feats), norm_scalar=_np(d1[K.NODE_FEATURES_KEY]),
+               norm_per_type=_np(d2[K.NODE_FEATURES_KEY]), e_atom=_np(e_atom), e_scaled=_np(d3[K.PER_ATOM_ENERGY_KEY]),
+               batch=_np(batch), e_total=_np(d4[K.TOTAL_ENERGY_KEY]))
+    np.savez_compressed(os.path.join(HERE, "ref_atomwise.npz"), **out)
+
+    # ---- a12: ForceStressOutput around a pair-energy stand-in (E = sum_e w_e * |r_e|^2 * exp(-|r_e|)) ------------
+    from nequip.nn._graph_mixin import GraphModuleMixin
+
+    class PairEnergy(GraphModuleMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._init_irreps(irreps_in={K.POSITIONS_KEY: "1o"}, irreps_out={K.TOTAL_ENERGY_KEY: "0e"})
+
+        def forward(self, data):
+            data = nn_utils.with_edge_vectors_(data, with_lengths=True)
+            r = data[K.EDGE_LENGTH_KEY].view(-1)
+            e_edge = data["edge_w"] * r * r * torch.exp(-r)
+            per_atom = torch.zeros(data[K.POSITIONS_KEY].shape[0], dtype=r.dtype).index_add_(0, data[K.EDGE_INDEX_KEY][0], e_edge)
+            if K.BATCH_KEY in data:
+                nb = int(data[K.BATCH_KEY].max()) + 1
+                tot = torch.zeros(nb, dtype=r.dtype).index_add_(0, data[K.BATCH_KEY], per_atom)
+            else:
+                tot = per_atom.sum().view(1)
+            data[K.TOTAL_ENERGY_KEY] = tot.view(-1, 1)
+            return data
+
+    out = {}
+    try:
+        fso = grad_output.ForceStressOutput(func=PairEnergy())
+        fso.eval()
+        for tag, with_batch in (("s", False), ("b", True)):
+            if not with_batch:
+                pos_s, cell_s, ei_s, sh_s = frame(10, 5.0)
+                w_e = torch.rand(ei_s.shape[1], generator=g, dtype=torch.float64)
+                data = {K.POSITIONS_KEY: pos_s.clone(), K.CELL_KEY: cell_s.clone().view(1, 3, 3), K.EDGE_INDEX_KEY: ei_s,
+                        K.EDGE_CELL_SHIFT_KEY: sh_s, "edge_w": w_e}
+                res = fso(data)
+                out.update(s_pos=_np(pos_s), s_cell=_np(cell_s), s_edge_index=_np(ei_s), s_shift=_np(sh_s), s_w=_np(w_e),
+                           s_energy=_np(res[K.TOTAL_ENERGY_KEY]), s_forces=_np(res[K.FORCE_KEY]),
+                           s_virial=_np(res[K.VIRIAL_KEY]), s_stress=_np(res[K.STRESS_KEY]))
+            else:
+                pos_b = torch.cat([p1, p2]).detach().clone()
+                cells_b = torch.stack([c1, c2]).detach().clone()
+                ei_b = torch.cat([e1, e2 + 7], dim=1)
+                sh_b = torch.cat([s1, s2])
+                batch_b = torch.cat([torch.zeros(7, dtype=torch.long), torch.ones(9, dtype=torch.long)])
+                w_e = torch.rand(ei_b.shape[1], generator=g, dtype=torch.float64)
+                data = {K.POSITIONS_KEY: pos_b.clone(), K.CELL_KEY: cells_b.clone(), K.EDGE_INDEX_KEY: ei_b,
+                        K.EDGE_CELL_SHIFT_KEY: sh_b, K.BATCH_KEY: batch_b, K.NUM_NODES_KEY: torch.tensor([7, 9]),
+                        "edge_w": w_e}
+                res = fso(data)
+                out.update(b_pos=_np(pos_b), b_cell=_np(cells_b), b_edge_index=_np(ei_b), b_shift=_np(sh_b),
+                           b_batch=_np(batch_b), b_w=_np(w_e), b_energy=_np(res[K.TOTAL_ENERGY_KEY]),
+                           b_forces=_np(res[K.FORCE_KEY]), b_virial=_np(res[K.VIRIAL_KEY]), b_stress=_np(res[K.STRESS_KEY]))
+        np.savez_compressed(os.path.join(HERE, "ref_force_stress.npz"), **out)
+    except Exception as exc:  # pragma: no cover
+        print("ForceStressOutput fixture skipped:", type(exc).__name__, exc)
+        raise
+
+    for f in sorted(os.listdir(HERE)):
+        if f.startswith("ref_"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
