@@ -272,6 +272,28 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
              const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Neighbour list on the device: replaces _compute_neighborlist_single_frame
+ *   (nequip/data/_nl.py:63-165), i.e. the CPU library call `neighbour_list("ijS", pbc, cell, positions, cutoff)`:
+ *   all ordered pairs (i, j, S) with |pos[j] - pos[i] + S @ cell| < r_max except i == j with S == 0;
+ *   edge_index[0] = i (convolution centre), edge_index[1] = j, S = integer lattice shifts (0 along non-periodic
+ *   directions).  pos [N,3] float64 (anywhere in space), cell [3,3] float64 rows = lattice vectors (NULL or all-zero:
+ *   no cell, only valid without periodicity), pbc int32[3] (device; NULL = none).  Triclinic cells, cells thinner than
+ *   the cutoff (several images of one atom) and mixed periodicity are supported.
+ * Two calls because the number of edges is data dependent:
+ *   nqa_neighbor_list_count builds the cell grid in `workspace` (>= nqa_neighbor_list_workspace_bytes(N)) and writes
+ *     rowptr [N+1] int32 (device): rowptr[i]..rowptr[i+1] = the edge range of centre atom i, rowptr[N] = E;
+ *   the caller reads rowptr[N], allocates edge_index [2,E] int64 and edge_cell_shift [E,3] float64, and calls
+ *   nqa_neighbor_list_fill with the same workspace.  Edges come out grouped by centre atom in ascending order
+ *   (dst-sorted: rowptr IS the dst-CSR row pointer of the tensor-product kernels) and in a deterministic order
+ *   within each atom.
+ * ------------------------------------------------------------------------------------------- */
+int64_t nqa_neighbor_list_workspace_bytes(int64_t num_atoms);
+int nqa_neighbor_list_count(const double* pos, const double* cell, const int32_t* pbc, double r_max, int64_t num_atoms,
+                            void* workspace, int64_t workspace_bytes, int32_t* rowptr, nqa_stream stream);
+int nqa_neighbor_list_fill(const void* workspace, const int32_t* rowptr, int64_t num_atoms, int64_t num_edges,
+                           int64_t* edge_index, double* edge_cell_shift, nqa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,12 @@ SIGNATURES = {
         [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32]
         + [c_int64, c_int32, c_int32, c_int64, c_double, c_int32, c_void_p],
     ),
+    "nqa_neighbor_list_workspace_bytes": (c_int64, [c_int64]),
+    "nqa_neighbor_list_count": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
+    ),
+    "nqa_neighbor_list_fill": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "nqa_gate": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],

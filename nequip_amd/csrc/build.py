@@ -25,7 +25,8 @@ OBJ_DIR = os.path.join(HERE, "build")
 GEN_DIR = os.path.join(HERE, "generated")
 SPEC_DIR = os.path.join(HERE, "generated_spec")
 
-SOURCES = ["plan.cpp", "csr.hip", "tp_generic.hip", "edge_embed.hip", "edge_vectors.hip", "radial_mlp.hip", "node_ops.hip", "tp_fused.hip"]
+SOURCES = ["plan.cpp", "csr.hip", "tp_generic.hip", "edge_embed.hip", "edge_vectors.hip", "radial_mlp.hip", "node_ops.hip",
+           "neighbor_list.hip"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,116 @@
+"""Neighbour lists on the device (mirror of ``nequip/data/_nl.py:63-381`` for one backend, ``"nequip_amd"``).
+
+``compute_neighborlist_(data, r_max)`` keeps the reference's contract (``_nl.py:364-381``): it adds ``edge_index``
+(int64 ``[2, E]``, row 0 = convolution centre, row 1 = neighbour) and -- iff the data has a cell -- ``edge_cell_shift``
+(``[E, 3]``, dtype of the positions) to ``data`` in place; batched input gives batched output, unbatched gives
+unbatched, everything stays on the device of the positions.  Where the reference moves the positions to the host and
+calls matscipy / ASE / vesin, this backend runs a cell-list search on the GPU (``nqa_neighbor_list_count/fill``,
+``nequip_amd/csrc/neighbor_list.hip``) with the same pair semantics (``|r| < r_max``, no self pair with zero shift,
+mixed periodicity, cells thinner than the cutoff).  Edges come out grouped by centre atom, so the dst-CSR of the
+tensor-product kernels needs no sort for them.
+"""
+
+import ctypes
+from typing import Dict, Final, Optional, Tuple, Union
+
+import torch
+
+from .. import _lib
+from . import AtomicDataDict
+
+NEIGHBORLIST_BACKEND_NEQUIP_AMD: Final[str] = "nequip_amd"
+DEFAULT_NEIGHBORLIST_BACKEND: Final[str] = NEIGHBORLIST_BACKEND_NEQUIP_AMD
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
+
+
+def _compute_neighborlist_single_frame(
+    pos: torch.Tensor,
+    r_max: float,
+    cell: Optional[torch.Tensor] = None,
+    pbc: Union[bool, Tuple[bool, bool, bool], torch.Tensor] = False,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(edge_index [2, E] int64, edge_cell_shift [E, 3])`` of one frame (``nequip/data/_nl.py:63-165``)."""
+    if not pos.is_cuda:
+        raise RuntimeError("the `nequip_amd` neighbour list runs on the GPU: positions must be a CUDA/HIP tensor")
+    if isinstance(pbc, bool):
+        pbc = (pbc,) * 3
+    elif isinstance(pbc, torch.Tensor):
+        pbc = tuple(bool(b) for b in pbc.detach().cpu().view(-1).tolist())
+    if cell is None and any(pbc):
+        raise ValueError("Periodic boundary conditions requested but no cell was provided.")
+    lib = _lib.load()
+    device = pos.device
+    out_dtype = pos.dtype
+    N = pos.shape[0]
+    pos64 = pos.detach().to(torch.float64).contiguous()
+    cell64 = cell.detach().to(torch.float64).reshape(3, 3).contiguous() if cell is not None else None
+    pbc_dev = torch.tensor([int(b) for b in pbc], dtype=torch.int32, device=device)
+    ws_bytes = lib.nqa_neighbor_list_workspace_bytes(N)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    with torch.cuda.device(device):
+        rc = lib.nqa_neighbor_list_count(_ptr(pos64), _ptr(cell64), _ptr(pbc_dev), float(r_max), N, _ptr(ws), ws_bytes,
+                                         _ptr(rowptr), stream)
+        _lib.check(rc, "nqa_neighbor_list_count")
+        E = int(rowptr[N].item())  # the one synchronisation: the edge count is data dependent
+        if E < 0:
+            raise RuntimeError("neighbour list has more than 2^31 - 1 edges")
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=device)
+        shifts = torch.empty((E, 3), dtype=torch.float64, device=device)
+        rc = lib.nqa_neighbor_list_fill(_ptr(ws), _ptr(rowptr), N, E, _ptr(edge_index), _ptr(shifts), stream)
+        _lib.check(rc, "nqa_neighbor_list_fill")
+    return edge_index, shifts.to(out_dtype)
+
+
+def _frame_from_batched(data: AtomicDataDict.Type, idx: int, node_offsets) -> AtomicDataDict.Type:
+    K = AtomicDataDict
+    lo, hi = int(node_offsets[idx]), int(node_offsets[idx + 1])
+    out = {K.POSITIONS_KEY: data[K.POSITIONS_KEY][lo:hi]}
+    if K.ATOM_TYPE_KEY in data:
+        out[K.ATOM_TYPE_KEY] = data[K.ATOM_TYPE_KEY].view(-1)[lo:hi]
+    if K.CELL_KEY in data:
+        out[K.CELL_KEY] = data[K.CELL_KEY].view(-1, 3, 3)[idx]
+    if K.PBC_KEY in data:
+        out[K.PBC_KEY] = data[K.PBC_KEY].view(-1, 3)[idx]
+    return out
+
+
+def compute_neighborlist_(data: AtomicDataDict.Type, r_max: float,
+                          backend: str = DEFAULT_NEIGHBORLIST_BACKEND) -> AtomicDataDict.Type:
+    """Add a neighbour list to ``data`` in place (contract of ``nequip/data/_nl.py:364-381``)."""
+    if backend not in NEIGHBORLIST_BACKEND_OPTIONS:
+        supported = ", ".join(f"`{b}`" for b in NEIGHBORLIST_BACKEND_OPTIONS)
+        raise ValueError(f"Unknown neighborlist backend = `{backend}`. Supported backends: {supported}")
+    K = AtomicDataDict
+    batched = K.BATCH_KEY in data
+    nframes = K.num_frames(data)
+    if batched:
+        counts = data[K.NUM_NODES_KEY].view(-1).cpu().tolist() if K.NUM_NODES_KEY in data else torch.bincount(
+            data[K.BATCH_KEY], minlength=nframes).cpu().tolist()
+    else:
+        counts = [data[K.POSITIONS_KEY].shape[0]]
+    offsets = [0]
+    for c in counts:
+        offsets.append(offsets[-1] + int(c))
+    has_cell = data.get(K.CELL_KEY, None) is not None
+    eidx, shifts = [], []
+    for f in range(nframes):
+        frame = _frame_from_batched(data, f, offsets)
+        cell = frame.get(K.CELL_KEY, None)
+        pbc = frame.get(K.PBC_KEY, None)
+        if pbc is None:
+            pbc = False
+        ei, sh = _compute_neighborlist_single_frame(frame[K.POSITIONS_KEY], r_max, cell=cell, pbc=pbc)
+        eidx.append(ei + offsets[f])
+        shifts.append(sh)
+    data[K.EDGE_INDEX_KEY] = torch.cat(eidx, dim=1) if len(eidx) > 1 else eidx[0]
+    if has_cell:
+        data[K.EDGE_CELL_SHIFT_KEY] = torch.cat(shifts, dim=0) if len(shifts) > 1 else shifts[0]
+    return data
+
+
+NEIGHBORLIST_BACKEND_OPTIONS: Final[Dict[str, object]] = {NEIGHBORLIST_BACKEND_NEQUIP_AMD: compute_neighborlist_}
