@@ -228,7 +228,9 @@ int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, 
  *   formulation in training mode.
  * nqa_radial_mlp_supported returns 1 when (dtype, nb, H, W) can run on the fused kernels
  *   (float32, nb <= 8, H in {64, 128}, W % 4 == 0).  `workspace` (>= nqa_radial_mlp_workspace_bytes(mode,
- *   backward, H, W); 0 for the fp32 forward) receives the re-laid-out / split second-layer weights.
+ *   backward, H, W); 0 for the fp32 forward) receives the re-laid-out / split second-layer weights (a function of
+ *   w1, alpha1, mode and direction only): a caller whose weights are constant may keep it and pass
+ *   workspace_ready != 0 on later calls to skip the prepass kernel.
  * ------------------------------------------------------------------------------------------- */
 #define NQA_MLP_FP32 0
 #define NQA_MLP_BF16X6 1
@@ -237,11 +239,11 @@ int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t h
 int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
                        const void* w1, double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features,
                        int64_t num_edges, void* edge_weight, void* workspace, int64_t workspace_bytes,
-                       nqa_stream stream);
+                       int32_t workspace_ready, nqa_stream stream);
 int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
                        const void* w1, double alpha1, const void* grad_edge_weight, int32_t num_basis,
                        int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
-                       void* workspace, int64_t workspace_bytes, nqa_stream stream);
+                       void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Node-side channel mixing in one launch: replaces e3nn o3.Linear (linear_1 / linear_2,

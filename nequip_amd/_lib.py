@@ -105,12 +105,12 @@ SIGNATURES = {
     "nqa_radial_mlp_fwd": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_int32, c_int32, c_int32, c_int64]
-        + [c_void_p, c_void_p, c_int64, c_void_p],
+        + [c_void_p, c_void_p, c_int64, c_int32, c_void_p],
     ),
     "nqa_radial_mlp_bwd": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_void_p, c_int32, c_int32, c_int32]
-        + [c_int64, c_void_p, c_void_p, c_int64, c_void_p],
+        + [c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p],
     ),
     "nqa_node_linear": (
         c_int32,

@@ -824,7 +824,7 @@ static int launch_status(const char* fn) {
 int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
                        const void* w1, double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features,
                        int64_t num_edges, void* edge_weight, void* workspace, int64_t workspace_bytes,
-                       nqa_stream stream) {
+                       int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_fwd");
   if (rc != NQA_OK) return rc;
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_fwd");
@@ -852,8 +852,9 @@ int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
   if (mode == NQA_MLP_BF16X6) {
     u32x4* wf = static_cast<u32x4*>(workspace);
     const int nfrag = ((out_features + 31) / 32) * (hidden / 16) * 64;
-    hipLaunchKernelGGL(radial_mlp_split_w1_fwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
-                       (float)alpha1, hidden, out_features, wf);
+    if (!workspace_ready)
+      hipLaunchKernelGGL(radial_mlp_split_w1_fwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
+                         (float)alpha1, hidden, out_features, wf);
     if (hidden == 128)
       hipLaunchKernelGGL(radial_mlp_fwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
                          num_basis, out_features, num_edges, o, dbg);
@@ -874,7 +875,7 @@ int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
 int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
                        const void* w1, double alpha1, const void* grad_edge_weight, int32_t num_basis,
                        int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
-                       void* workspace, int64_t workspace_bytes, nqa_stream stream) {
+                       void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
@@ -898,8 +899,9 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
   if (mode == NQA_MLP_BF16X6) {
     u32x4* wb = static_cast<u32x4*>(workspace);
     const int nfrag = ((out_features + 31) / 32) * 2 * (hidden / 32) * 64;
-    hipLaunchKernelGGL(radial_mlp_split_w1_bwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
-                       (float)alpha1, hidden, out_features, wb);
+    if (!workspace_ready)
+      hipLaunchKernelGGL(radial_mlp_split_w1_bwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
+                         (float)alpha1, hidden, out_features, wb);
     if (hidden == 128)
       hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
                          num_basis, out_features, num_edges, o);
@@ -909,8 +911,9 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
     return launch_status("nqa_radial_mlp_bwd");
   }
   float* w1t = static_cast<float*>(workspace);  // [W (+ padding rows read by the last chunk)][H]
-  hipLaunchKernelGGL(radial_mlp_transpose_w1_kernel, dim3((unsigned)((hidden * out_features + 255) / 256)), dim3(256),
-                     0, s, b, (float)alpha1, hidden, out_features, w1t);
+  if (!workspace_ready)
+    hipLaunchKernelGGL(radial_mlp_transpose_w1_kernel, dim3((unsigned)((hidden * out_features + 255) / 256)),
+                       dim3(256), 0, s, b, (float)alpha1, hidden, out_features, w1t);
   if (hidden == 128)
     hipLaunchKernelGGL(radial_mlp_bwd_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, w1t, g, (float)alpha0,
                        num_basis, out_features, num_edges, o);

@@ -24,12 +24,33 @@ def radial_mlp_mode() -> int:
     return _lib.NQA_MLP_FP32 if os.environ.get("NQA_MLP_EXACT_FP32", "") not in ("", "0") else _lib.NQA_MLP_BF16X6
 
 
+class _WeightImages:
+    """Per-module cache of the split / re-laid-out second-layer weights (``workspace`` of ``nqa_radial_mlp_fwd/bwd``):
+    in eval mode the weights are constants, so the prepass kernel runs once per parameter version, not per call."""
+
+    def __init__(self):
+        self.key = None
+        self.images = {}
+
+    def validate(self, param: torch.Tensor) -> None:
+        """Drop the images if the parameter they were made from changed (new object, storage, version or device)."""
+        key = (id(param), param.data_ptr(), param._version, param.device)
+        if key != self.key:
+            self.key, self.images = key, {}
+
+    def get(self, w1: torch.Tensor, mode: int, backward: int, nbytes: int):
+        hit = (mode, backward) in self.images
+        if not hit:
+            self.images[(mode, backward)] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=w1.device)
+        return self.images[(mode, backward)], hit
+
+
 class _RadialMLPFn(torch.autograd.Function):
     """Fused two-layer radial MLP on the matrix cores (``nqa_radial_mlp_fwd/bwd``); inference path: differentiable
     w.r.t. the edge embedding only (that is what the force backward needs)."""
 
     @staticmethod
-    def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float, mode: int):
+    def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
         from ._topology import _ptr, current_stream_ptr
 
         lib = _lib.load()
@@ -39,14 +60,14 @@ class _RadialMLPFn(torch.autograd.Function):
         out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
         flops = 2.0 * E * (nb * H + H * W)
         ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=emb.device)
+        ws, ready = cache.get(w1, mode, 0, ws_bytes)
         with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):
             rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
-                                        _ptr(out), _ptr(ws), ws_bytes, current_stream_ptr(emb.device))
+                                        _ptr(out), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
         _lib.check(rc, "nqa_radial_mlp_fwd")
         ctx.save_for_backward(emb, w0, w1)
         ctx.alphas = (alpha0, alpha1)
-        ctx.mode = mode
+        ctx.mode, ctx.cache = mode, cache
         return out
 
     @staticmethod
@@ -62,13 +83,13 @@ class _RadialMLPFn(torch.autograd.Function):
         g_emb = torch.empty_like(emb)
         flops = 2.0 * E * (nb * H * 2 + H * W)
         ws_bytes = lib.nqa_radial_mlp_workspace_bytes(ctx.mode, 1, H, W)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
+        ws, ready = ctx.cache.get(w1, ctx.mode, 1, ws_bytes)
         with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
             rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, ctx.mode, _ptr(emb), _ptr(w0), ctx.alphas[0], _ptr(w1),
                                         ctx.alphas[1], _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes,
-                                        current_stream_ptr(emb.device))
+                                        int(ready), current_stream_ptr(emb.device))
         _lib.check(rc, "nqa_radial_mlp_bwd")
-        return g_emb, None, None, None, None, None
+        return g_emb, None, None, None, None, None, None
 
 
 class ScalarLinearLayer(torch.nn.Module):
@@ -130,8 +151,13 @@ class ScalarMLPFunction(torch.nn.Module):
         # inference on the GPU: one fused MFMA kernel (hidden layer stays on chip); training keeps the
         # mm/SiLU formulation so that parameter gradients and double backward come from autograd
         if self._fused_ok(x):
-            return _RadialMLPFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0], self._alphas[1],
-                                      radial_mlp_mode())
+            cache = getattr(self, "_weight_images", None)
+            if cache is None:
+                cache = self._weight_images = _WeightImages()
+            # (the fused path only runs in eval mode: weights are constants there, as for o3.Linear)
+            cache.validate(self.mlp[2].weight)
+            return _RadialMLPFn.apply(x, self.mlp[0].weight.detach(), self.mlp[2].weight.detach(), self._alphas[0],
+                                      self._alphas[1], radial_mlp_mode(), cache)
         return self.mlp(x)
 
 
