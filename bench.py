@@ -43,6 +43,9 @@ WORKLOADS = {
     "water10k": dict(box="water", n_side=15, l_max=2, num_features=64, num_layers=3),
     "si1k": dict(box="si", reps=5, l_max=2, num_features=64, num_layers=3),
     "water_small": dict(box="water", n_side=5, l_max=2, num_features=64, num_layers=3),
+    # BASELINE config 5: 100k-atom fcc Cu, l_max=3, 128 features (cu20k: same model on a fifth of the box)
+    "cu100k": dict(box="cu", reps=(25, 25, 40), l_max=3, num_features=128, num_layers=3),
+    "cu20k": dict(box="cu", reps=(25, 25, 8), l_max=3, num_features=128, num_layers=3),
 }
 
 
@@ -61,6 +64,8 @@ def build_box(w, seed=0):
         pos, types, cell, names = syn.water_box(n_side=w["n_side"], seed=seed)
     elif w["box"] == "si":
         pos, types, cell, names = syn.silicon_box(reps=w["reps"], seed=seed)
+    elif w["box"] == "cu":
+        pos, types, cell, names = syn.copper_box(reps=tuple(w["reps"]), seed=seed)
     else:
         raise ValueError(w["box"])
     data = syn.make_data(pos, types, 4.5, cell, spatial_sort=os.environ.get("NQA_BENCH_SORT", "0") != "0")

@@ -257,8 +257,8 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  *   chunk_width = 64: float32 runs on fp32 MFMA with LDS-staged operands, float64 on the VALU kernel;
  *   chunk_width = -64 forces the VALU kernel for float32 as well.
  *   atom_types (int64 [N]) is required iff n_types > 1.  The backward w.r.t. x is the same call with transposed
- *   tables/weights.  chunk_table / instr_table are HOST pointers (<= 40 chunks, <= 64 instructions): they are
- *   copied into the kernel arguments at call time.  x, weights, addend, out, atom_types are device pointers.
+ *   tables/weights.  chunk_table / instr_table are HOST pointers (<= 64 instructions; more than 40 chunks are
+ *   processed in several launches): they are copied into the kernel arguments at call time.  x, weights, addend, out, atom_types are device pointers.
  * nqa_gate: e3nn Gate (nequip/nn/convnetlayer.py:104-112,162-164): in = scalars (+) gates (+) gated ->
  *   out = act(scalars) (+) act(gates)[u] * gated[u, :] (act 0 = identity, 1 = silu, 2 = tanh, each times its e3nn
  *   normalize2mom constant `cst`).  col_table: one 32-byte record {int32 a, b, c, d; double cst; int32 e, f} per

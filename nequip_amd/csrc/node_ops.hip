@@ -520,9 +520,21 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     set_error("nqa_node_linear: unsupported dtype");
     return NQA_ERR_UNSUPPORTED;
   }
-  if (n_chunks > kMaxNodeChunks || n_instr > kMaxNodeInstr) {
-    set_error("nqa_node_linear: more than 40 output chunks or 64 instructions in one call");
+  if (n_instr > kMaxNodeInstr) {
+    set_error("nqa_node_linear: more than 64 instructions in one call");
     return NQA_ERR_UNSUPPORTED;
+  }
+  if (n_chunks > kMaxNodeChunks && chunk_table != nullptr) {
+    // wide layers (e.g. l_max = 3 with 128 features: > 40 output chunks): one launch per group of chunks -- chunk
+    // records are self-contained (absolute offsets / instruction ranges)
+    for (int32_t c0 = 0; c0 < n_chunks; c0 += kMaxNodeChunks) {
+      const int32_t nc = n_chunks - c0 < kMaxNodeChunks ? n_chunks - c0 : kMaxNodeChunks;
+      const int rc = nqa_node_linear(dtype, x, weights, addend, out, atom_types,
+                                     static_cast<const NodeChunk*>(chunk_table) + c0, nc, instr_table, n_instr, n_types,
+                                     weight_stride, dim_in, dim_out, num_nodes, scale, chunk_width, stream);
+      if (rc != NQA_OK) return rc;
+    }
+    return NQA_OK;
   }
   if (num_nodes < 0 || n_chunks < 0 || n_instr < 0 || n_types < 1 || dim_in <= 0 || dim_out <= 0 ||
       (num_nodes > 0 && (!x || !weights || !out || !chunk_table || (n_instr > 0 && !instr_table))) ||
@@ -533,8 +545,8 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
   if (num_nodes == 0) return NQA_OK;
   const size_t es = dtype == NQA_F32 ? 4 : 8;
   const size_t smem = (size_t)kNZ * dim_in * es;
-  if (smem > 160 * 1024 - 1024) {
-    set_error("nqa_node_linear: feature rows too wide for the LDS tile");
+  if (!use_mfma && smem > 160 * 1024 - 1024) {  // (the MFMA kernel stages 64-channel slabs, not whole rows)
+    set_error("nqa_node_linear: feature rows too wide for the LDS tile of the VALU kernel");
     return NQA_ERR_UNSUPPORTED;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
