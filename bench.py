@@ -390,7 +390,7 @@ def main():
             "kernels_gbps": {k: v["gbps"] for k, v in kernels.items()},
             "kernels_tflops": {k: v["tflops"] for k, v in kernels.items() if v.get("tflops", 0) > 0},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.workload)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result))
