@@ -45,6 +45,7 @@ struct NodeLinearArgs {
   T* __restrict__ out;
   const int64_t* __restrict__ types;  // optional [N]
   int32_t n_chunks, n_types, din, dout;
+  int32_t dbg;  // ablation switches (NQA_NODE_DBG), 0 in production
   int64_t wstride;
   int64_t N;
   T scale;
@@ -190,13 +191,15 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs<T
 // columns of atoms whose type differs from the staged weight set are zeroed in the B operand.
 using f32x16n = __attribute__((ext_vector_type(16))) float;
 
+__device__ __forceinline__ void nl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kNLW = 64;                       // output channels per chunk (two 32-row MFMA tiles)
 constexpr int kNLK = 64;                       // input channels per stage
 constexpr int kNLXS = 32 * (kNLK + 1);         // floats per wavefront slab: NZT atoms x (64+1)*d, NZT*d <= 32
 
 template <int D>
 __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<float>& a, const NodeChunk& ch, int bx,
-                                                       float* __restrict__ ws, float* __restrict__ xs_all) {
+                                                       int nblk, float* __restrict__ ws, float* __restrict__ xs_all) {
   constexpr int NZT = 32 / D;                               // atoms per wavefront
   // padded slab stride per atom.  Columns (zl, m) of a k-step read xs[zl*S + u*d + m]: conflict-free iff zl*S + m
   // are distinct mod 32.  d > 1: S = 64*d + P with P the multiple of 4 >= d (also keeps rows 16-byte aligned for
@@ -213,11 +216,11 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
   const int half = lane >> 5, j = lane & 31;
   const int zlr = j / D, m = j - zlr * D;
   const int zl = min(zlr, NZT - 1);                         // clamped for addressing
-  const int64_t zbase = ((int64_t)bx * 4 + wv) * NZT;  // first atom of this wavefront
-  const int64_t z = zbase + zl;
-  const bool col_ok = (zlr < NZT) && (z < a.N);
-  const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
   const int cw = min(kNLW, ch.mul_out - ch.c0);
+  // atom groups (4 wavefronts x NZT atoms) of this chunk are dealt round-robin to its nblk workgroups: a workgroup
+  // that owns several groups requests the first slab of the next group before the last MFMAs of the current one, so
+  // only its very first operand fetch is exposed
+  const int64_t ngroups = (a.N + 4 * NZT - 1) / (4 * NZT);
   float* __restrict__ xs = xs_all + wv * kNLXS;
 
   // per-lane slab coordinates (loop invariant): float4 v of this lane belongs to atom xz[v], offset 4*xo4[v]
@@ -232,7 +235,7 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
   // stage enumeration: (instruction q, type t, K slab k0)
   int q = ch.instr_begin, t = 0, k0 = 0;
   NodeInstr ins = q < ch.instr_end ? a.instr[q] : NodeInstr{0, 0, 0, 0};
-  auto advance = [&]() {  // -> false when exhausted
+  auto advance = [&]() {  // -> false when the stages of one atom group are exhausted
     k0 += kNLK;
     if (k0 >= ins.mul_in) {
       k0 = 0;
@@ -246,7 +249,7 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
 
   float4 wreg[4];
   float4 xreg[XV4];
-  auto load_stage = [&](const NodeInstr& si, int st, int sk0) {
+  auto load_stage = [&](const NodeInstr& si, int st, int sk0, int64_t zbase) {
     // weight slab rows u = sk0 .. sk0+63, columns c0 .. c0+63 of W_t [mul_in][mul_out]
     const float* __restrict__ wb = a.w + (int64_t)st * a.wstride + si.w_off + ch.c0;
     const bool wal = ((ch.mul_out | ch.c0 | si.w_off) & 3) == 0 && (a.wstride & 3) == 0;
@@ -307,98 +310,127 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
   };
 
   f32x16n acc0 = {0}, acc1 = {0};
-  bool have = q < ch.instr_end;
-  if (have) {
-    load_stage(ins, t, k0);
+  const bool any_stage = q < ch.instr_end;
+  int64_t g = bx;
+  int64_t zbase = (g * 4 + wv) * NZT;  // first atom of this wavefront in the current group
+  bool have = true;
+  if (any_stage) {
+    if (!(a.dbg & 1)) load_stage(ins, t, k0, zbase);
     store_stage(0);
   }
   __syncthreads();
   int buf = 0;
   while (have) {
+    const int64_t z = zbase + zl;
+    const bool col_ok = (zlr < NZT) && (z < a.N);
+    const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
     const int cur_t = t;
-    const bool more = advance();
-    if (more) load_stage(ins, t, k0);  // next stage -> registers, lands behind the MFMAs below
-    const bool bsel = col_ok && (a.n_types == 1 || tzj == cur_t);
-    const float* __restrict__ wsb = ws + buf * (kNLK * kNLW) + j;
-    const float* __restrict__ xb = xs + zl * S + m;
-    // LDS operand reads of the next register batch are issued between the MFMAs of the current one
-    constexpr int TB = 4;
-    float bq[2][TB], a0[2][TB], a1[2][TB];
-#pragma unroll
-    for (int i = 0; i < TB; ++i) {
-      const int u = 2 * i + half;
-      bq[0][i] = xb[u * D];
-      a0[0][i] = wsb[u * kNLW];
-      a1[0][i] = wsb[u * kNLW + 32];
-    }
-#pragma unroll
-    for (int b = 0; b < kNLK / 2 / TB; ++b) {
-      if (b + 1 < kNLK / 2 / TB) {
-#pragma unroll
-        for (int i = 0; i < TB; ++i) {
-          const int u = 2 * ((b + 1) * TB + i) + half;
-          bq[(b + 1) & 1][i] = xb[u * D];
-          a0[(b + 1) & 1][i] = wsb[u * kNLW];
-          a1[(b + 1) & 1][i] = wsb[u * kNLW + 32];
-        }
+    // what comes next: the following stage of this group, else the first stage of this workgroup's next group
+    bool last_of_group = !any_stage || !advance();
+    int64_t zbase_next = zbase;
+    bool next_valid = !last_of_group;
+    if (last_of_group) {
+      const int64_t gn = g + nblk;
+      if (gn < ngroups) {
+        g = gn;
+        zbase_next = (gn * 4 + wv) * NZT;
+        q = ch.instr_begin; t = 0; k0 = 0;
+        if (any_stage) ins = a.instr[q];
+        next_valid = true;
       }
-      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (next_valid && any_stage && !(a.dbg & 1)) load_stage(ins, t, k0, zbase_next);  // lands behind the MFMAs below
+    if (any_stage) {
+      const bool bsel = col_ok && (a.n_types == 1 || tzj == cur_t);
+      const float* __restrict__ wsb = ws + buf * (kNLK * kNLW) + j;
+      const float* __restrict__ xb = xs + zl * S + m;
+      // LDS operand reads of the next register batch are issued between the MFMAs of the current one
+      constexpr int TB = 4;
+      float bq[2][TB], a0[2][TB], a1[2][TB];
 #pragma unroll
       for (int i = 0; i < TB; ++i) {
-        const float bv = bsel ? bq[b & 1][i] : 0.f;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[b & 1][i], bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[b & 1][i], bv, acc1, 0, 0, 0);
+        const int u = 2 * i + half;
+        bq[0][i] = xb[u * D];
+        a0[0][i] = wsb[u * kNLW];
+        a1[0][i] = wsb[u * kNLW + 32];
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();  // every wavefront is done with ws[buf ^ 1]'s previous contents and with its own x slab
-    if (more) store_stage(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-    have = more;
-  }
-
-  // result tile -> this wavefront's slab as [atom][w*d + m] (same padded stride), then contiguous runs per atom
-  if (zlr < NZT) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
-      xs[zl * S + wl * D + m] = acc0[r];
-      xs[zl * S + (wl + 32) * D + m] = acc1[r];
-    }
-  }
-  // (same wavefront wrote what it reads: LDS operations of a wavefront complete in order)
-  const int run = cw * D;  // valid floats per atom
-  const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
+      for (int b = 0; b < ((a.dbg & 2) ? 1 : kNLK / 2 / TB); ++b) {
+        if (b + 1 < kNLK / 2 / TB) {
 #pragma unroll
-  for (int v = 0; v < XV4; ++v) {
-    const int64_t zg = zbase + xz[v];
-    if (xz[v] < NZT && zg < a.N && xo[v] < run) {
-      const float* __restrict__ sp = xs + xz[v] * S + xo[v];
-      float4 r;
-      if constexpr (kVecLds) {
-        r = *reinterpret_cast<const float4*>(sp);
-      } else {
-        r = make_float4(sp[0], sp[1], sp[2], sp[3]);
-      }
-      const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + xo[v];
-      r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
-      if (oal && xo[v] + 3 < run) {
-        if (a.addend != nullptr) {
-          const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
-          r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+          for (int i = 0; i < TB; ++i) {
+            const int u = 2 * ((b + 1) * TB + i) + half;
+            bq[(b + 1) & 1][i] = xb[u * D];
+            a0[(b + 1) & 1][i] = wsb[u * kNLW];
+            a1[(b + 1) & 1][i] = wsb[u * kNLW + 32];
+          }
         }
-        *reinterpret_cast<float4*>(a.out + o) = r;
-      } else {
-        const float rv[4] = {r.x, r.y, r.z, r.w};
-        for (int e = 0; e < 4; ++e)
-          if (xo[v] + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const float bv = bsel ? bq[b & 1][i] : 0.f;
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[b & 1][i], bv, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[b & 1][i], bv, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (last_of_group) {
+      // result tile -> this wavefront's slab as [atom][w*d + m] (same padded stride), then contiguous runs per atom
+      // (the x slab is free: all MFMAs of the group are issued; same wavefront, LDS operations complete in order)
+      if (zlr < NZT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
+          xs[zl * S + wl * D + m] = acc0[r];
+          xs[zl * S + (wl + 32) * D + m] = acc1[r];
+        }
+      }
+      acc0 = (f32x16n){0};
+      acc1 = (f32x16n){0};
+      const int run = cw * D;  // valid floats per atom
+      const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
+#pragma unroll
+      for (int v = 0; v < XV4; ++v) {
+        const int64_t zg = zbase + xz[v];
+        if (xz[v] < NZT && zg < a.N && xo[v] < run) {
+          const float* __restrict__ sp = xs + xz[v] * S + xo[v];
+          float4 r;
+          if constexpr (kVecLds) {
+            r = *reinterpret_cast<const float4*>(sp);
+          } else {
+            r = make_float4(sp[0], sp[1], sp[2], sp[3]);
+          }
+          const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + xo[v];
+          r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+          if (oal && xo[v] + 3 < run) {
+            if (a.addend != nullptr) {
+              const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+              r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+            }
+            if (!(a.dbg & 4) || r.x == 12345.f) *reinterpret_cast<float4*>(a.out + o) = r;
+          } else {
+            const float rv[4] = {r.x, r.y, r.z, r.w};
+            for (int e = 0; e < 4; ++e)
+              if (xo[v] + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
+          }
+        }
+      }
+    }
+    if (next_valid && any_stage) {
+      // LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain vmcnt, i.e. wait for
+      // the result stores just issued (CDNA4 counts stores in vmcnt) at every group boundary
+      nl_lds_barrier();  // every wavefront is done with ws[buf ^ 1]'s previous contents and with its own slab
+      store_stage(buf ^ 1);
+      nl_lds_barrier();
+      buf ^= 1;
+    }
+    zbase = zbase_next;
+    have = next_valid;
   }
 }
 
-__global__ __launch_bounds__(256) void node_linear_mfma_kernel(const NodeLinearArgs<float> a) {
+__global__ __launch_bounds__(256, 2) void node_linear_mfma_kernel(const NodeLinearArgs<float> a) {
   __shared__ __align__(16) float ws[2 * kNLK * kNLW];  // 32 KiB: double-buffered weight slab
   __shared__ __align__(16) float xs[4 * kNLXS];        // 4 x 8.1 KiB: per-wavefront x / result slabs
   // exact 1-D grid: chunk c owns workgroups [blk_begin[c], blk_begin[c+1])
@@ -406,12 +438,13 @@ __global__ __launch_bounds__(256) void node_linear_mfma_kernel(const NodeLinearA
   while (c + 1 < a.n_chunks && (int)blockIdx.x >= a.blk_begin[c + 1]) ++c;
   const NodeChunk ch = a.chunks[c];
   const int bx = (int)blockIdx.x - a.blk_begin[c];
+  const int nblk = a.blk_begin[c + 1] - a.blk_begin[c];
   switch (ch.d) {
-    case 1: node_linear_mfma_block<1>(a, ch, bx, ws, xs); break;
-    case 3: node_linear_mfma_block<3>(a, ch, bx, ws, xs); break;
-    case 5: node_linear_mfma_block<5>(a, ch, bx, ws, xs); break;
-    case 7: node_linear_mfma_block<7>(a, ch, bx, ws, xs); break;
-    case 9: node_linear_mfma_block<9>(a, ch, bx, ws, xs); break;
+    case 1: node_linear_mfma_block<1>(a, ch, bx, nblk, ws, xs); break;
+    case 3: node_linear_mfma_block<3>(a, ch, bx, nblk, ws, xs); break;
+    case 5: node_linear_mfma_block<5>(a, ch, bx, nblk, ws, xs); break;
+    case 7: node_linear_mfma_block<7>(a, ch, bx, nblk, ws, xs); break;
+    case 9: node_linear_mfma_block<9>(a, ch, bx, nblk, ws, xs); break;
     default: break;
   }
 }
@@ -568,17 +601,39 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     a.wstride = weight_stride;
     a.N = num_nodes;
     a.scale = (float)scale;
+    {
+      static const int dbg = [] {
+        const char* e = std::getenv("NQA_NODE_DBG");
+        return e ? std::atoi(e) : 0;
+      }();
+      a.dbg = dbg;
+    }
     if (use_mfma) {
-      int64_t nblk = 0;
+      // atom groups per workgroup: enough workgroups to fill the chip a few times over, few enough that each
+      // amortises its first (exposed) operand fetch over several groups
+      int64_t total_groups = 0;
       for (int c = 0; c < n_chunks; ++c) {
-        a.blk_begin[c] = (int32_t)nblk;
         const int d = a.chunks[c].d;
         if (d != 1 && d != 3 && d != 5 && d != 7 && d != 9) {
           set_error("nqa_node_linear: irrep dimension above 9 (l > 4)");
           return NQA_ERR_UNSUPPORTED;
         }
-        const int per_blk = 4 * (32 / d);  // atoms per workgroup
-        nblk += (num_nodes + per_blk - 1) / per_blk;
+        const int per_grp = 4 * (32 / d);
+        total_groups += (num_nodes + per_grp - 1) / per_grp;
+      }
+      static const int gpb_env = [] {
+        const char* e = std::getenv("NQA_NODE_GPB");
+        return e ? std::atoi(e) : 0;
+      }();
+      int64_t gpb = gpb_env > 0 ? gpb_env : (total_groups + 1023) / 1024;
+      if (gpb < 1) gpb = 1;
+      if (gpb > 8) gpb = 8;
+      int64_t nblk = 0;
+      for (int c = 0; c < n_chunks; ++c) {
+        a.blk_begin[c] = (int32_t)nblk;
+        const int per_grp = 4 * (32 / a.chunks[c].d);
+        const int64_t groups = (num_nodes + per_grp - 1) / per_grp;
+        nblk += (groups + gpb - 1) / gpb;
       }
       a.blk_begin[n_chunks] = (int32_t)nblk;
       if (nblk == 0) return NQA_OK;
