@@ -496,39 +496,49 @@ struct GateArgs {
   int64_t N;
 };
 
+constexpr int kGateAtoms = 16;  // atoms per workgroup: a thread keeps its column's table record in registers for all of them
+
 template <typename T>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateArgs<T> a) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.N * a.dout) return;
-  const int64_t z = i / a.dout;
-  const int c = (int)(i - z * a.dout);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // output column
+  if (c >= a.dout) return;
   const GateCol t = a.cols[c];
-  const T* __restrict__ row = a.in + z * a.din;
   const T cst = (T)t.cst;
-  const T xs = row[t.a];
-  a.out[i] = t.b < 0 ? act_eval(t.c, xs, cst) : act_eval(t.c, row[t.b], cst) * xs;
+  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z1 = min(z0 + kGateAtoms, a.N);
+#pragma unroll 4
+  for (int64_t z = z0; z < z1; ++z) {
+    const T* __restrict__ row = a.in + z * a.din;
+    const T xs = row[t.a];
+    a.out[z * a.dout + c] = t.b < 0 ? act_eval(t.c, xs, cst) : act_eval(t.c, row[t.b], cst) * xs;
+  }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateArgs<T> a) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.N * a.din) return;
-  const int64_t z = i / a.din;
-  const int c = (int)(i - z * a.din);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // input column
+  if (c >= a.din) return;
   const GateCol t = a.cols[c];
-  const T* __restrict__ row = a.in + z * a.din;
-  const T* __restrict__ g = a.gout + z * a.dout;
   const T cst = (T)t.cst;
-  if (t.a == 0) {
-    a.out[i] = g[t.c] * act_grad(t.b, row[c], cst);
-  } else if (t.a == 1) {
-    T s = T(0);
-    for (int m = 0; m < t.e; ++m) s += g[t.c + m] * row[t.d + m];
-    a.out[i] = s * act_grad(t.b, row[c], cst);
-  } else if (t.a == 2) {
-    a.out[i] = act_eval(t.b, row[t.f], cst) * g[t.c];
-  } else {
-    a.out[i] = T(0);
+  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z1 = min(z0 + kGateAtoms, a.N);
+#pragma unroll 4
+  for (int64_t z = z0; z < z1; ++z) {
+    const T* __restrict__ row = a.in + z * a.din;
+    const T* __restrict__ g = a.gout + z * a.dout;
+    T r;
+    if (t.a == 0) {
+      r = g[t.c] * act_grad(t.b, row[c], cst);
+    } else if (t.a == 1) {
+      T s = T(0);
+      for (int m = 0; m < t.e; ++m) s += g[t.c + m] * row[t.d + m];
+      r = s * act_grad(t.b, row[c], cst);
+    } else if (t.a == 2) {
+      r = act_eval(t.b, row[t.f], cst) * g[t.c];
+    } else {
+      r = T(0);
+    }
+    a.out[z * a.din + c] = r;
   }
 }
 
@@ -687,8 +697,14 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
   }
   if (num_nodes == 0) return NQA_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t total = num_nodes * (int64_t)(backward ? dim_in : dim_out);
-  const unsigned grid = (unsigned)((total + 255) / 256);
+  const int cols = backward ? dim_in : dim_out;
+  const int64_t ny = (num_nodes + kGateAtoms - 1) / kGateAtoms;
+  if (ny > 2147483647LL) {
+    set_error("nqa_gate: too many atoms for one launch");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  const unsigned bdim = cols >= 256 ? 256u : (unsigned)(((cols + 63) / 64) * 64);
+  const dim3 grid((unsigned)((cols + bdim - 1) / bdim), (unsigned)ny);
 #define NQA_GATE_LAUNCH(T)                                                                        \
   {                                                                                               \
     GateArgs<T> a{};                                                                              \
@@ -700,9 +716,9 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
     a.dout = dim_out;                                                                             \
     a.N = num_nodes;                                                                              \
     if (backward)                                                                                 \
-      hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(grid), dim3(256), 0, s, a);                     \
+      hipLaunchKernelGGL(gate_bwd_kernel<T>, grid, dim3(bdim), 0, s, a);                     \
     else                                                                                          \
-      hipLaunchKernelGGL(gate_fwd_kernel<T>, dim3(grid), dim3(256), 0, s, a);                     \
+      hipLaunchKernelGGL(gate_fwd_kernel<T>, grid, dim3(bdim), 0, s, a);                     \
   }
   if (dtype == NQA_F32) NQA_GATE_LAUNCH(float) else NQA_GATE_LAUNCH(double)
 #undef NQA_GATE_LAUNCH
