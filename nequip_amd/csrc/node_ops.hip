@@ -3,16 +3,17 @@
 // Replaces, on the N atom rows, the e3nn modules the reference calls around the tensor product:
 //   o3.Linear            linear_1 / linear_2                     (nequip/nn/interaction_block.py:82-87,129-138,177,201)
 //   FullyConnectedTP     self-connection sc(x, node_attrs)      (nequip/nn/interaction_block.py:142-146,175)
-//   AvgNumNeighborsNorm  x * 1/sqrt(avg_num_neighbors)          (nequip/nn/norm.py:48-68)   [folded into the weights]
+//   AvgNumNeighborsNorm  x * 1/sqrt(avg_num_neighbors)          (nequip/nn/norm.py:48-68)   [the launch's `scale`]
 //   Gate                 act(scalars) (+) act(gates) * gated    (nequip/nn/convnetlayer.py:104-112,162-164)
 // which in the reference (and in a plain PyTorch port) are ~40 small ATen kernels per layer (slices, transposes,
 // per-irrep GEMMs, cats, adds): 2.2 ms of the 7.8 ms cfg-3 step (profiles/).  Here every linear map of a layer is
 // one launch:  out[z, ob, w, m] = scale * sum_{(ib -> ob)} sum_u x[z, ib, u, m] * W_{type(z)}[ib->ob][u, w]  (+ addend)
-// in mul_ir layout.  A workgroup stages the full input rows of NZ = 8 atoms in LDS; wavefronts own 64-channel output
-// chunks (lanes = output channel w), stream the weight rows coalesced from L2 and read the inputs as LDS broadcasts.
-// FLOPs are tiny (~5 GFLOP per evaluation); this is a launch-count / HBM-round-trip optimisation (fp32 FMA on the
-// VALU at the same rate as fp32 MFMA).  The self-connection uses per-atom-type pre-contracted weights (exact
-// re-association of sum_v W[u,v,w] emb[t,v]).
+// in mul_ir layout.  float32 runs on fp32 MFMA with LDS-staged operand / result slabs (node_linear_mfma_kernel, below);
+// float64 -- and float32 on request -- on a VALU kernel: a workgroup stages the full input rows of NZ = 4 atoms in LDS,
+// wavefronts own 64-channel output chunks (lanes = output channel w), stream the weight rows coalesced from L2 and
+// read the inputs as LDS broadcasts.  14 GFLOP per cfg-3 evaluation at 16 FLOP/byte: between the HBM and fp32-MFMA
+// roofs.  The self-connection uses per-atom-type pre-contracted weights (exact re-association of
+// sum_v W[u,v,w] emb[t,v]); AvgNumNeighborsNorm rides on linear_1 as the `scale` argument.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

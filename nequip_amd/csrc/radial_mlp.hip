@@ -5,15 +5,19 @@
 // nequip/nn/mlp.py:141-156,194-196,262-268: bias-free layers y = x @ (W * alpha), alpha = gain/sqrt(fan_in),
 // SiLU in between) for the standard one-hidden-layer radial MLP, and the autograd of those mm/SiLU ops.
 //
-// This is the one true dense GEMM on the hot path ([E,H] x [H,W], K = H = 64/128): it runs on exact-fp32 MFMA
-// (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, 157 TFLOP/s peak) -- no reduced precision.
+// This is the one true dense GEMM on the hot path ([E,H] x [H,W], K = H = 64/128).  Two interchangeable GEMM modes:
+//   NQA_MLP_FP32   : exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, 157 TFLOP/s peak);
+//   NQA_MLP_BF16X6 : every fp32 operand split exactly into three bf16 terms, six partial products accumulated in fp32 on
+//                    v_mfma_f32_32x32x16_bf16 (fp32-accurate, 2.7x the fp32-MFMA ceiling) -- second half of this file.
+// Kernel structure (both modes):
 //   forward : a workgroup owns 128 edges; each wavefront keeps the SiLU-activated hidden rows of its 32 edges in
-//             VGPRs as MFMA A-fragments for the whole kernel (the hidden layer never touches HBM) and streams
-//             the second-layer weights through LDS in 64-column chunks;
-//   backward: g_h = g_w @ (W1*a1)^T with K = W streamed from HBM through LDS in 32-column chunks, then
+//             VGPRs as MFMA fragments for the whole kernel (the hidden layer never touches HBM) and streams
+//             the second-layer weights through LDS in column chunks;
+//   backward: g_h = g_w @ (W1*a1)^T with K = W streamed from HBM, then
 //             g_emb = (g_h * silu'(pre)) @ (W0*a0)^T with the pre-activations recomputed from the embedding
 //             (8 FMAs per element) instead of being stored.
-// Roofline: MFMA-bound (2*H*W FLOP per edge vs 4*W bytes written/read per edge).
+// Roofline: 2*H*W FLOP per edge vs 4*W bytes written/read per edge: MFMA-bound in fp32 mode, between the bf16-MFMA
+// and HBM roofs in split mode.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
