@@ -109,8 +109,9 @@ extern "C" {
 int nqa_edge_vectors_fwd(const double* pos, const int64_t* edge_dst, const int64_t* edge_src,
                          const double* edge_cell_shift, const double* cell, const int64_t* batch, int64_t num_edges,
                          double* edge_vec, nqa_stream stream) {
+  // (empty tensors have NULL data pointers: operands are only required when there are edges)
   if (num_edges < 0 || (num_edges > 0 && (!pos || !edge_dst || !edge_src || !edge_vec)) ||
-      (cell != nullptr && edge_cell_shift == nullptr)) {
+      (num_edges > 0 && cell != nullptr && edge_cell_shift == nullptr)) {
     set_error("nqa_edge_vectors_fwd: invalid argument");
     return NQA_ERR_INVALID;
   }
@@ -129,8 +130,9 @@ int nqa_edge_vectors_fwd(const double* pos, const int64_t* edge_dst, const int64
 int nqa_edge_vectors_bwd(const double* g_edge_vec, const double* edge_cell_shift, const int32_t* rowptr_dst,
                          const int32_t* edge_id_dst, const int32_t* rowptr_src, const int32_t* edge_id_src,
                          int64_t num_nodes, double* g_pos, double* g_cell_per_node, nqa_stream stream) {
-  if (num_nodes < 0 || (num_nodes > 0 && (!g_pos || !rowptr_dst || !rowptr_src)) ||
-      (g_cell_per_node != nullptr && edge_cell_shift == nullptr)) {
+  // (g_edge_vec / edge_cell_shift are only dereferenced inside non-empty edge rows: NULL is legal for a graph without
+  // edges, where empty tensors have NULL data pointers)
+  if (num_nodes < 0 || (num_nodes > 0 && (!g_pos || !rowptr_dst || !rowptr_src))) {
     set_error("nqa_edge_vectors_bwd: invalid argument");
     return NQA_ERR_INVALID;
   }

@@ -170,3 +170,24 @@ def test_cutoff_smoothness(device):
     assert d_in_out < 1e-6, d_in_out  # p = 6 polynomial envelope: value and derivatives vanish at r_max
     f_jump = (e[0][K.FORCE_KEY][0] - e[1][K.FORCE_KEY][0]).abs().max().item()
     assert f_jump < 1e-4, f_jump
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodic", [False, True])
+def test_no_edges(device, periodic):
+    """Atoms farther apart than r_max: energy = sum of per-type constants, forces / virial exactly zero (no edge at all
+    reaches the kernels: E = 0 everywhere, first and only use of the empty-graph paths end to end)."""
+    from nequip_amd.data import AtomicDataDict as K
+
+    names = ["C", "H", "O"]
+    model = _model(device, names, parity=True, l_max=2)
+    pos = np.array([[0.0, 0.0, 0.0], [9.0, 0.0, 0.0], [0.0, 11.0, 0.0]])
+    types = np.array([0, 1, 2])
+    cell = np.eye(3) * 30.0 if periodic else None
+    out = _eval(model, pos, types, device, cell)
+    assert torch.isfinite(out[K.TOTAL_ENERGY_KEY]).all()
+    assert float(out[K.FORCE_KEY].abs().max()) == 0.0
+    if periodic:
+        assert float(out[K.VIRIAL_KEY].abs().max()) == 0.0
+    single = [_eval(model, pos[i : i + 1], types[i : i + 1], device, cell)[K.TOTAL_ENERGY_KEY].item() for i in range(3)]
+    assert abs(sum(single) - out[K.TOTAL_ENERGY_KEY].item()) < 1e-5
