@@ -250,56 +250,80 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
 
   float4 wreg[4];
   float4 xreg[XV4];
-  auto load_stage = [&](const NodeInstr& si, int st, int sk0, int64_t zbase) {
+  // lanes of float4 slot v that map to a real atom run: all of them except possibly in the last slot
+  auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
+  auto load_stage = [&](const NodeInstr& si, int st, int sk0, int64_t zbase, bool with_w) {
     // weight slab rows u = sk0 .. sk0+63, columns c0 .. c0+63 of W_t [mul_in][mul_out]
     const float* __restrict__ wb = a.w + (int64_t)st * a.wstride + si.w_off + ch.c0;
     const bool wal = ((ch.mul_out | ch.c0 | si.w_off) & 3) == 0 && (a.wstride & 3) == 0;
+    if (!with_w) {
+      // single-stage chunk: the weight slab staged for the first atom group serves all of them
+    } else if (wal && cw == kNLW && sk0 + kNLK <= si.mul_in) {
+      // common case (wave-uniform): full aligned slab, no per-element predication
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int idx = tid + v * 256;      // float4 index in the [64][16] slab
-      const int u = idx >> 4, c4 = (idx & 15) * 4;
-      const int ug = sk0 + u;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ug < si.mul_in) {
-        const float* __restrict__ p = wb + (int64_t)ug * ch.mul_out + c4;
-        if (wal && c4 + 3 < cw) {
-          r = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (c4 + 0 < cw) r.x = p[0];
-          if (c4 + 1 < cw) r.y = p[1];
-          if (c4 + 2 < cw) r.z = p[2];
-          if (c4 + 3 < cw) r.w = p[3];
-        }
+      for (int v = 0; v < 4; ++v) {
+        const int idx = tid + v * 256;  // float4 index in the [64][16] slab
+        wreg[v] = *reinterpret_cast<const float4*>(wb + (int64_t)(sk0 + (idx >> 4)) * ch.mul_out + (idx & 15) * 4);
       }
-      wreg[v] = r;
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int idx = tid + v * 256;
+        const int u = idx >> 4, c4 = (idx & 15) * 4;
+        const int ug = sk0 + u;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ug < si.mul_in) {
+          const float* __restrict__ p = wb + (int64_t)ug * ch.mul_out + c4;
+          if (wal && c4 + 3 < cw) {
+            r = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (c4 + 0 < cw) r.x = p[0];
+            if (c4 + 1 < cw) r.y = p[1];
+            if (c4 + 2 < cw) r.z = p[2];
+            if (c4 + 3 < cw) r.w = p[3];
+          }
+        }
+        wreg[v] = r;
+      }
     }
     // x slab: atom zz contributes the contiguous run x[zz, x_off + sk0*d .. + 64*d) (zero beyond mul_in)
     const int kk = min(kNLK, si.mul_in - sk0) * D;  // valid floats per atom
     const bool xal = ((a.din | si.x_off) & 3) == 0;  // (sk0*d is a multiple of 64)
+    if (xal && kk == kNLK * D && zbase + NZT <= a.N) {
+      // common case (wave-uniform): aligned full runs of a complete atom group
+      const float* __restrict__ xb0 = a.x + zbase * a.din + si.x_off + sk0 * D;
 #pragma unroll
-    for (int v = 0; v < XV4; ++v) {
-      const int64_t zg = zbase + xz[v];
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xz[v] < NZT && zg < a.N && xo[v] < kk) {
-        const float* __restrict__ p = a.x + zg * a.din + si.x_off + sk0 * D + xo[v];
-        if (xal && xo[v] + 3 < kk) {
-          r = *reinterpret_cast<const float4*>(p);
-        } else {
-          r.x = p[0];
-          if (xo[v] + 1 < kk) r.y = p[1];
-          if (xo[v] + 2 < kk) r.z = p[2];
-          if (xo[v] + 3 < kk) r.w = p[3];
-        }
+      for (int v = 0; v < XV4; ++v) {
+        if (slot_ok(v)) xreg[v] = *reinterpret_cast<const float4*>(xb0 + (int64_t)xz[v] * a.din + xo[v]);
       }
-      xreg[v] = r;
+    } else {
+#pragma unroll
+      for (int v = 0; v < XV4; ++v) {
+        const int64_t zg = zbase + xz[v];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xz[v] < NZT && zg < a.N && xo[v] < kk) {
+          const float* __restrict__ p = a.x + zg * a.din + si.x_off + sk0 * D + xo[v];
+          if (xal && xo[v] + 3 < kk) {
+            r = *reinterpret_cast<const float4*>(p);
+          } else {
+            r.x = p[0];
+            if (xo[v] + 1 < kk) r.y = p[1];
+            if (xo[v] + 2 < kk) r.z = p[2];
+            if (xo[v] + 3 < kk) r.w = p[3];
+          }
+        }
+        xreg[v] = r;
+      }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, bool with_w) {
+    if (with_w) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(ws + buf * (kNLK * kNLW) + (tid + v * 256) * 4) = wreg[v];
+      for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(ws + buf * (kNLK * kNLW) + (tid + v * 256) * 4) = wreg[v];
+    }
 #pragma unroll
     for (int v = 0; v < XV4; ++v) {
-      if (xz[v] < NZT) {
+      if (slot_ok(v)) {
         float* __restrict__ d = xs + xz[v] * S + xo[v];
         if constexpr (kVecLds) {
           *reinterpret_cast<float4*>(d) = xreg[v];
@@ -315,9 +339,12 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
   int64_t g = bx;
   int64_t zbase = (g * 4 + wv) * NZT;  // first atom of this wavefront in the current group
   bool have = true;
+  // one stage per group (one instruction, one type, K <= 64 -- every backward launch and linear_1): the weight slab is
+  // loop invariant, later groups re-stage only their wavefront-private x slab and need no workgroup barrier at all
+  const bool single_stage = any_stage && ch.instr_end - ch.instr_begin == 1 && a.n_types == 1 && ins.mul_in <= kNLK;
   if (any_stage) {
-    if (!(a.dbg & 1)) load_stage(ins, t, k0, zbase);
-    store_stage(0);
+    if (!(a.dbg & 1)) load_stage(ins, t, k0, zbase, true);
+    store_stage(0, true);
   }
   __syncthreads();
   int buf = 0;
@@ -340,7 +367,7 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
         next_valid = true;
       }
     }
-    if (next_valid && any_stage && !(a.dbg & 1)) load_stage(ins, t, k0, zbase_next);  // lands behind the MFMAs below
+    if (next_valid && any_stage && !(a.dbg & 1)) load_stage(ins, t, k0, zbase_next, !single_stage);  // lands behind the MFMAs
     if (any_stage) {
       const bool bsel = col_ok && (a.n_types == 1 || tzj == cur_t);
       const float* __restrict__ wsb = ws + buf * (kNLK * kNLW) + j;
@@ -379,7 +406,7 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
     if (last_of_group) {
       // result tile -> this wavefront's slab as [atom][w*d + m] (same padded stride), then contiguous runs per atom
       // (the x slab is free: all MFMAs of the group are issued; same wavefront, LDS operations complete in order)
-      if (zlr < NZT) {
+      if (zlr < NZT && (!(a.dbg & 8) || acc0[0] == 12345.f)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -391,40 +418,62 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
       acc1 = (f32x16n){0};
       const int run = cw * D;  // valid floats per atom
       const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
+      if (oal && cw == kNLW && zbase + NZT <= a.N && kVecLds) {
+        // common case (wave-uniform): full aligned runs of a complete atom group
+        const int64_t ob = zbase * a.dout + ch.o_off + (int64_t)ch.c0 * D;
 #pragma unroll
-      for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = zbase + xz[v];
-        if (xz[v] < NZT && zg < a.N && xo[v] < run) {
-          const float* __restrict__ sp = xs + xz[v] * S + xo[v];
-          float4 r;
-          if constexpr (kVecLds) {
-            r = *reinterpret_cast<const float4*>(sp);
-          } else {
-            r = make_float4(sp[0], sp[1], sp[2], sp[3]);
-          }
-          const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + xo[v];
-          r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
-          if (oal && xo[v] + 3 < run) {
+        for (int v = 0; v < XV4; ++v) {
+          if (slot_ok(v)) {
+            float4 r = *reinterpret_cast<const float4*>(xs + xz[v] * S + xo[v]);
+            const int64_t o = ob + (int64_t)xz[v] * a.dout + xo[v];
+            r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
             if (a.addend != nullptr) {
               const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
               r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
             }
             if (!(a.dbg & 4) || r.x == 12345.f) *reinterpret_cast<float4*>(a.out + o) = r;
-          } else {
-            const float rv[4] = {r.x, r.y, r.z, r.w};
-            for (int e = 0; e < 4; ++e)
-              if (xo[v] + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < XV4; ++v) {
+          const int64_t zg = zbase + xz[v];
+          if (xz[v] < NZT && zg < a.N && xo[v] < run) {
+            const float* __restrict__ sp = xs + xz[v] * S + xo[v];
+            float4 r;
+            if constexpr (kVecLds) {
+              r = *reinterpret_cast<const float4*>(sp);
+            } else {
+              r = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+            const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + xo[v];
+            r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+            if (oal && xo[v] + 3 < run) {
+              if (a.addend != nullptr) {
+                const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+                r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+              }
+              *reinterpret_cast<float4*>(a.out + o) = r;
+            } else {
+              const float rv[4] = {r.x, r.y, r.z, r.w};
+              for (int e = 0; e < 4; ++e)
+                if (xo[v] + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
+            }
           }
         }
       }
     }
     if (next_valid && any_stage) {
-      // LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain vmcnt, i.e. wait for
-      // the result stores just issued (CDNA4 counts stores in vmcnt) at every group boundary
-      nl_lds_barrier();  // every wavefront is done with ws[buf ^ 1]'s previous contents and with its own slab
-      store_stage(buf ^ 1);
-      nl_lds_barrier();
-      buf ^= 1;
+      if (single_stage) {
+        store_stage(buf, false);  // wavefront-private slab: in-order LDS, no barrier
+      } else {
+        // LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain vmcnt, i.e. wait for
+        // the result stores just issued (CDNA4 counts stores in vmcnt) at every group boundary
+        if (!(a.dbg & 16)) nl_lds_barrier();  // all wavefronts are done with ws[buf ^ 1] and with their own slab
+        if (!(a.dbg & 32)) store_stage(buf ^ 1, true);
+        if (!(a.dbg & 16)) nl_lds_barrier();
+        buf ^= 1;
+      }
     }
     zbase = zbase_next;
     have = next_valid;
