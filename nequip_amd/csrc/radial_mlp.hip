@@ -457,28 +457,32 @@ __global__ __launch_bounds__(256) void radial_mlp_split_w1_bwd_kernel(const floa
   o[0] = h; o[(int64_t)NT * 64] = m; o[(int64_t)2 * NT * 64] = l;
 }
 
-template <int H>
-__global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_kernel(const float* __restrict__ emb,
+// NW wavefronts (32 edges each) share every staged weight tile: 8 instead of 4 halves the L2 -> LDS weight traffic
+// (1.7 GB per middle-layer launch at NW = 4, i.e. the whole L2 bandwidth for ~100 us).
+template <int H, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wf, float a0, int nb,
                                                                     int W, int64_t E, float* __restrict__ out,
                                                                     int dbg) {
   constexpr int KS = H / 16;            // bf16 k-steps
   constexpr int TILE = KS * 3 * 64;     // uint4 per 32-column weight tile (24 KiB for H = 128)
-  constexpr int NV = TILE / 256;        // uint4 per thread per tile
+  constexpr int NTH = NW * 64;          // threads per workgroup
+  constexpr int NV = TILE / NTH;        // uint4 per thread per tile
+  static_assert(TILE % NTH == 0, "tile must divide evenly over the workgroup");
   constexpr int kTS = 36;               // padded row stride (floats) of the per-wave output transpose tile
   __shared__ float w0s[H * kMaxNb];     // [k][c]
   __shared__ u32x4 as[2][TILE];
-  __shared__ __align__(16) float tbuf[4 * 32 * kTS];
+  __shared__ __align__(16) float tbuf[NW * 32 * kTS];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
   const int half = lane >> 5;
   const int l31 = lane & 31;
-  const int64_t myrow = (int64_t)blockIdx.x * kMlpRows + wv * 32 + l31;
+  const int64_t myrow = (int64_t)blockIdx.x * (NW * 32) + wv * 32 + l31;
   const bool row_ok = myrow < E;
 
-  for (int i = tid; i < H * kMaxNb; i += 256) {
+  for (int i = tid; i < H * kMaxNb; i += NTH) {
     const int k = i / kMaxNb, c = i - k * kMaxNb;
     w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
   }
@@ -486,11 +490,11 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_kernel(const flo
   u32x4 pre[NV];
   auto stage_load = [&](int tile) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) pre[v] = Wf[(int64_t)tile * TILE + tid + v * 256];
+    for (int v = 0; v < NV; ++v) pre[v] = Wf[(int64_t)tile * TILE + tid + v * NTH];
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) as[buf][tid + v * 256] = pre[v];
+    for (int v = 0; v < NV; ++v) as[buf][tid + v * NTH] = pre[v];
   };
   // Weight tiles are fetched two tiles ahead (global -> registers during tile t-1, registers -> LDS at the start of
   // tile t, consumed in tile t+1): vmcnt retires in order and also counts the output stores, so waiting for a
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_kernel(const flo
   // instruction would touch 32 lines with 32 B each.  A wave-private LDS transpose (4 KiB) turns the tile into
   // row-major order so that each store instruction writes 8 complete 128 B row segments.
   float* __restrict__ tb = tbuf + wv * (32 * kTS);
-  const int64_t wrow0 = (int64_t)((dbg & 8) ? (blockIdx.x & 15) : blockIdx.x) * kMlpRows + wv * 32;
+  const int64_t wrow0 = (int64_t)((dbg & 8) ? (blockIdx.x & 15) : blockIdx.x) * (NW * 32) + wv * 32;
   auto emit = [&](const f32x16& pa, const f32x16& pb, int tile) {
     if (dbg & 1) {
       if (pa[0] == 12345.f && pb[3] == 777.f) out[0] = 1.f;  // ablation: keep the MFMAs live, skip the stores
@@ -549,11 +553,19 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_kernel(const flo
                       pa[4 * g + 3] + pb[4 * g + 3]);
     const int n0 = tile * 32;
     const int c4 = lane & 7, rsub = lane >> 3;
+    if (wrow0 + 32 <= E && n0 + 32 <= W) {  // wave-uniform common case: full tile, unpredicated stores
+      float* __restrict__ ob = out + (wrow0 + rsub) * W + n0 + 4 * c4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 8 * i + rsub;
-      const float4 v = *reinterpret_cast<const float4*>(tb + r * kTS + 4 * c4);
-      if (wrow0 + r < E && n0 + 4 * c4 + 3 < W) *reinterpret_cast<float4*>(out + (wrow0 + r) * W + n0 + 4 * c4) = v;
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(ob + (int64_t)(8 * i) * W) =
+            *reinterpret_cast<const float4*>(tb + (8 * i + rsub) * kTS + 4 * c4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + rsub;
+        const float4 v = *reinterpret_cast<const float4*>(tb + r * kTS + 4 * c4);
+        if (wrow0 + r < E && n0 + 4 * c4 + 3 < W) *reinterpret_cast<float4*>(out + (wrow0 + r) * W + n0 + 4 * c4) = v;
+      }
     }
   };
   auto tile_body = [&](int tile, f32x16& accA, f32x16& accB, const f32x16& prevA, const f32x16& prevB) {
@@ -604,7 +616,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wb,
                                                                     const float* __restrict__ gw, float a0, int nb,
-                                                                    int W, int64_t E, float* __restrict__ g_emb) {
+                                                                    int W, int64_t E, float* __restrict__ g_emb,
+                                                                    int dbg) {
   // K (= W) is consumed in chunks of 32 columns = two bf16 k-steps; lane (row, half) owns the 16 contiguous floats
   // 32*chunk + 16*half + [0, 16) of its g_w row per chunk: HBM -> registers directly, split in registers.
   constexpr int NT = H / 32;
@@ -642,12 +655,19 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   const int nchunks = (W + 31) / 32;
   u32x4 pb[NV];
   const float* __restrict__ grow = gw + (row_ok ? myrow : 0) * W + 16 * half;
+  const bool rows_full = blk0 + kMlpRows <= E;  // workgroup-uniform
   auto load_a = [&](int ch, float4 (&pa)[4]) {
+    if (dbg & 1) return;  // ablation: no g_w traffic
+    if (rows_full && 32 * ch + 32 <= W) {  // uniform common case: unpredicated loads
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int k = 32 * ch + 16 * half + 4 * v;
-      pa[v] = (row_ok && k + 3 < W) ? *reinterpret_cast<const float4*>(grow + 32 * ch + 4 * v)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);  // W % 4 == 0
+      for (int v = 0; v < 4; ++v) pa[v] = *reinterpret_cast<const float4*>(grow + 32 * ch + 4 * v);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = 32 * ch + 16 * half + 4 * v;
+        pa[v] = (row_ok && k + 3 < W) ? *reinterpret_cast<const float4*>(grow + 32 * ch + 4 * v)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);  // W % 4 == 0
+      }
     }
   };
   auto load_b = [&](int ch) {
@@ -688,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
       split_pair(pa[2 * s + 1].z, pa[2 * s + 1].w, a, b, c);
       ah[s][3] = a; am[s][3] = b; al[s][3] = c;
     }
-    if (ch + 1 < nchunks) load_b(ch + 1);
+    if (ch + 1 < nchunks && !(dbg & 2) && !((dbg & 8) && (ch & 1))) load_b(ch + 1);
     if (ch + 2 < nchunks) load_a(ch + 2, pa);
     const u32x4* __restrict__ bs = bsm + buf * CH + lane;
 #pragma unroll
@@ -713,8 +733,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
       for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(ah[s], fb[0][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ch + 1 < nchunks) store_b(buf ^ 1);
-    lds_barrier();
+    if (ch + 1 < nchunks && !(dbg & 2) && !((dbg & 8) && (ch & 1))) store_b(buf ^ 1);
+    if (!(dbg & 4)) lds_barrier();
   };
   for (int ch = 0; ch < nchunks; ch += 2) {
     body(ch, paA);
@@ -859,11 +879,16 @@ int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
     if (!workspace_ready)
       hipLaunchKernelGGL(radial_mlp_split_w1_fwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
                          (float)alpha1, hidden, out_features, wf);
-    if (hidden == 128)
-      hipLaunchKernelGGL(radial_mlp_fwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
+    const bool wide = (dbg & 64) != 0;  // NQA_MLP_DBG bit 6: 8 wavefronts (256 edges) per workgroup (measured: no gain)
+    const unsigned g8 = (unsigned)((num_edges + 255) / 256);
+    if (hidden == 128 && wide)
+      hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<128, 8>), dim3(g8), dim3(512), 0, s, e, a, wf, (float)alpha0,
+                         num_basis, out_features, num_edges, o, dbg);
+    else if (hidden == 128)
+      hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<128, 4>), dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
                          num_basis, out_features, num_edges, o, dbg);
     else
-      hipLaunchKernelGGL(radial_mlp_fwd_bf16x6_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
+      hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<64, 4>), dim3(grid), dim3(256), 0, s, e, a, wf, (float)alpha0,
                          num_basis, out_features, num_edges, o, dbg);
     return launch_status("nqa_radial_mlp_fwd");
   }
@@ -900,6 +925,10 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
   const float* b = static_cast<const float*>(w1);
   const float* g = static_cast<const float*>(grad_edge_weight);
   float* o = static_cast<float*>(grad_edge_embedding);
+  static const int dbg = [] {
+    const char* v = std::getenv("NQA_MLP_DBG_BWD");
+    return v ? std::atoi(v) : 0;
+  }();
   if (mode == NQA_MLP_BF16X6) {
     u32x4* wb = static_cast<u32x4*>(workspace);
     const int nfrag = ((out_features + 31) / 32) * 2 * (hidden / 32) * 64;
@@ -908,10 +937,10 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
                          (float)alpha1, hidden, out_features, wb);
     if (hidden == 128)
       hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
-                         num_basis, out_features, num_edges, o);
+                         num_basis, out_features, num_edges, o, dbg);
     else
       hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
-                         num_basis, out_features, num_edges, o);
+                         num_basis, out_features, num_edges, o, dbg);
     return launch_status("nqa_radial_mlp_bwd");
   }
   float* w1t = static_cast<float*>(workspace);  // [W (+ padding rows read by the last chunk)][H]
