@@ -118,6 +118,10 @@ def _emit(st: Structure) -> str:
     used_blocks = sorted({b for b, _, _ in st.instr})
     used_y = sorted({j for _, j, _ in st.instr})
     tag = st.tag()
+    # register-heavy structures (l_max = 3 middle layer): ask for two wavefronts per SIMD so that the compiler does not
+    # spend the whole register file on load hoisting at occupancy 1
+    big = (OD + 2 * (XD + NP + S)) > 160
+    lb = "__launch_bounds__(256, 2)" if big else "__launch_bounds__(256)"
     L = []
     A = L.append
     A(f"// GENERATED by gen_spec.py for structure '{st.name}': {st.key()}")
@@ -174,7 +178,7 @@ def _emit(st: Structure) -> str:
 
     # ------------------------------------------------------------------ forward
     A("template <typename T, int WPN>")
-    A("__global__ __launch_bounds__(256) void fwd_kernel(const SpecArgs<T> a) {")
+    A(f"__global__ {lb} void fwd_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
     A("  const int mul = a.mul;")
@@ -193,9 +197,15 @@ def _emit(st: Structure) -> str:
     A("#pragma unroll")
     A("  for (int k = 0; k < kOD; ++k) acc[k] = T(0);")
     A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
-    A("  // Two register sets (A/B): the operands of edge i+1 are requested before edge i is evaluated, the indices of")
-    A("  // edge i+2 before that -- every HBM/L2 round trip of an edge hides behind the arithmetic of the previous one.")
-    L.extend(["  T wvA[kNP], wvB[kNP];"] + decl_x("  ", "A") + decl_x("  ", "B") + decl_y("  ", "A") + decl_y("  ", "B"))
+    # register budget: accumulators + two operand sets; big structures (l_max = 3 middle layer: 99 accumulators, 23
+    # paths) would hit the 256-VGPR wall at one wavefront per SIMD, so they run the plain loop at twice the occupancy
+    pipelined = not big
+    if pipelined:
+        A("  // Two register sets (A/B): the operands of edge i+1 are requested before edge i is evaluated, the indices of")
+        A("  // edge i+2 before that -- every HBM/L2 round trip of an edge hides behind the arithmetic of the previous one.")
+        L.extend(["  T wvA[kNP], wvB[kNP];"] + decl_x("  ", "A") + decl_x("  ", "B") + decl_y("  ", "A") + decl_y("  ", "B"))
+    else:
+        L.extend(["  T wvA[kNP];"] + decl_x("  ", "A") + decl_y("  ", "A"))
 
     def fwd_loads(sfx, e, sv):
         out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
@@ -218,31 +228,44 @@ def _emit(st: Structure) -> str:
             out.append("    }")
         return out
 
-    A("  int idx = beg + wsub;")
-    A("  int nidx = idx + WPN;")
-    A("  int e0 = 0, s0 = 0, e1 = 0, s1 = 0;")
-    A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); }")
-    A("  if (idx < end) {")
-    L.extend(fwd_loads("A", "e0", "s0"))
-    A("  }")
-    A("  if (nidx < end) { e1 = spec_uniform(a.eid[nidx]); s1 = spec_uniform(a.nbr[nidx]); }")
-    A("  while (idx < end) {")
-    A("    if (nidx < end) {")
-    L.extend(fwd_loads("B", "e1", "s1"))
-    A("    }")
-    A("    int nn = nidx + WPN;")
-    A("    if (nn < end) { e0 = spec_uniform(a.eid[nn]); s0 = spec_uniform(a.nbr[nn]); }")
-    L.extend(fwd_compute("A"))
-    A("    idx = nidx; nidx = nn;")
-    A("    if (idx >= end) break;")
-    A("    if (nidx < end) {")
-    L.extend(fwd_loads("A", "e0", "s0"))
-    A("    }")
-    A("    nn = nidx + WPN;")
-    A("    if (nn < end) { e1 = spec_uniform(a.eid[nn]); s1 = spec_uniform(a.nbr[nn]); }")
-    L.extend(fwd_compute("B"))
-    A("    idx = nidx; nidx = nn;")
-    A("  }")
+    if pipelined:
+        A("  int idx = beg + wsub;")
+        A("  int nidx = idx + WPN;")
+        A("  int e0 = 0, s0 = 0, e1 = 0, s1 = 0;")
+        A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); }")
+        A("  if (idx < end) {")
+        L.extend(fwd_loads("A", "e0", "s0"))
+        A("  }")
+        A("  if (nidx < end) { e1 = spec_uniform(a.eid[nidx]); s1 = spec_uniform(a.nbr[nidx]); }")
+        A("  while (idx < end) {")
+        A("    if (nidx < end) {")
+        L.extend(fwd_loads("B", "e1", "s1"))
+        A("    }")
+        A("    int nn = nidx + WPN;")
+        A("    if (nn < end) { e0 = spec_uniform(a.eid[nn]); s0 = spec_uniform(a.nbr[nn]); }")
+        L.extend(fwd_compute("A"))
+        A("    idx = nidx; nidx = nn;")
+        A("    if (idx >= end) break;")
+        A("    if (nidx < end) {")
+        L.extend(fwd_loads("A", "e0", "s0"))
+        A("    }")
+        A("    nn = nidx + WPN;")
+        A("    if (nn < end) { e1 = spec_uniform(a.eid[nn]); s1 = spec_uniform(a.nbr[nn]); }")
+        L.extend(fwd_compute("B"))
+        A("    idx = nidx; nidx = nn;")
+        A("  }")
+    else:
+        A("  int idx = beg + wsub;")
+        A("  int e0 = 0, s0 = 0;")
+        A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); }")
+        A("  while (idx < end) {")
+        A("    const int nidx = idx + WPN;")
+        A("    int e_n = 0, s_n = 0;")
+        A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); }")
+        L.extend(fwd_loads("A", "e0", "s0"))
+        L.extend(fwd_compute("A"))
+        A("    idx = nidx; e0 = e_n; s0 = s_n;")
+        A("  }")
     # scale by path coefficient: slots shared by several instructions have equal coeff per slot (same l3, same n_into)
     slot_coeff = [None] * NS
     for p, (_, _, s) in enumerate(st.instr):
@@ -280,7 +303,7 @@ def _emit(st: Structure) -> str:
     # gy_j += w_p B^p_j.  FUSED additionally forms A^p_i = sum_jk C^p_ijk y_j g_k and emits the edge's contribution
     # w_p A^p_i to grad_x[src] (grad_out[dst] is already in registers), summed per source node afterwards.
     A("template <typename T, int WPN, bool FUSED, bool GW, bool GY>")
-    A("__global__ __launch_bounds__(256) void bwd_edge_kernel(const SpecArgs<T> a) {")
+    A("__global__ __launch_bounds__(256) void bwd_edge_kernel(const SpecArgs<T> a) {")  # (256, 2) spills here: slower
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
     A("  const int mul = a.mul;")
@@ -372,7 +395,7 @@ def _emit(st: Structure) -> str:
 
     # ------------------------------------------------------------------ backward (node features)
     A("template <typename T, int WPN>")
-    A("__global__ __launch_bounds__(256) void bwd_x_kernel(const SpecArgs<T> a) {")
+    A(f"__global__ {lb} void bwd_x_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
     A("  const int mul = a.mul;")
