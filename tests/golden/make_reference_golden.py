@@ -7,6 +7,7 @@ hot path whose arithmetic lives in nequip itself rather than in e3nn:
                                                     nequip/nn/embedding/_edge.py:18-151, cutoffs.py:17-27
     a4  ScalarMLPFunction (the radial MLP)          nequip/nn/mlp.py:81-268
     a6  AvgNumNeighborsNorm                         nequip/nn/norm.py:7-68
+    a9  scatter                                     nequip/nn/utils.py:24-53
         PerTypeScaleShift, AtomwiseReduce           nequip/nn/atomwise.py:62-284
     a12 ForceStressOutput (forces, virial, stress by autograd through a pair-energy stand-in)
                                                     nequip/nn/grad_output.py:107-298
@@ -177,7 +178,7 @@ def main():
     # ---- a4: ScalarMLPFunction as the radial MLP ---------------------------------------------------------------
     out = {}
     for tag, (din, width, depth, dout) in {"d1": (8, 64, 1, 96), "d2": (8, 32, 2, 40), "d0": (8, None, 0, 24)}.items():
-        torch.manual_seed(hash(tag) % 1000)
+        torch.manual_seed({"d1": 11, "d2": 22, "d0": 33}[tag])  # (str hashes are salted per process)
         m = mlp.ScalarMLPFunction(input_dim=din, output_dim=dout, hidden_layers_depth=depth, hidden_layers_width=width,
                                   nonlinearity="silu", bias=False)
         x = (torch.randn(50, din, generator=g) * 0.7).requires_grad_(True)
@@ -212,6 +213,13 @@ def main():
                norm_per_type=_np(d2[K.NODE_FEATURES_KEY]), e_atom=_np(e_atom), e_scaled=_np(d3[K.PER_ATOM_ENERGY_KEY]),
                batch=_np(batch), e_total=_np(d4[K.TOTAL_ENERGY_KEY]))
     np.savez_compressed(os.path.join(HERE, "ref_atomwise.npz"), **out)
+
+    # ---- a9: scatter (sum over edges onto nodes; isolated nodes stay zero; repeated, unsorted indices) ---------------
+    src = torch.randn(37, 5, generator=g)
+    index = torch.randint(0, 9, (37,), generator=g)
+    index[index == 4] = 3  # node 4 (and nodes 9, 10) receive nothing
+    sc = nn_utils.scatter(src, index, dim=0, dim_size=11)
+    np.savez_compressed(os.path.join(HERE, "ref_scatter.npz"), src=_np(src), index=_np(index), out=_np(sc))
 
     # ---- a12: ForceStressOutput around a pair-energy stand-in (E = sum_e w_e * |r_e|^2 * exp(-|r_e|)) ------------
     from nequip.nn._graph_mixin import GraphModuleMixin

@@ -69,6 +69,15 @@ def test_oracle_scalar_mlp_matches_reference():
             _close(grads[1 + i], f[f"{tag}_gw{i}"], 5e-6)
 
 
+def test_oracle_scatter_matches_reference():
+    from oracle import tp as otp
+
+    f = _load("ref_scatter.npz")
+    out = otp.scatter(f["src"], f["index"], 11)
+    torch.testing.assert_close(out, f["out"], atol=1e-6, rtol=1e-6)
+    assert (f["out"][[4, 9, 10]] == 0).all()
+
+
 # ------------------------------------------------------------------------------------------- host mirrors (CPU)
 def test_host_modules_match_reference():
     from nequip_amd.data import AtomicDataDict as K
