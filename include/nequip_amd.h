@@ -174,7 +174,14 @@ int nqa_edge_vectors_fwd(const double* pos, const int64_t* edge_dst, const int64
                          int64_t num_edges, double* edge_vec, nqa_stream stream);
 int nqa_edge_vectors_bwd(const double* g_edge_vec, const double* edge_cell_shift, const int32_t* rowptr_dst,
                          const int32_t* edge_id_dst, const int32_t* rowptr_src, const int32_t* edge_id_src,
-                         int64_t num_nodes, double* g_pos, double* g_cell_per_node, nqa_stream stream);
+                         int64_t num_nodes, double sign, double* g_pos, double* g_cell_per_node, nqa_stream stream);
+/* `sign` multiplies g_pos (-1: forces = -dE/dpos directly).  g_cell_per_node[n] = sum_{e: centre(e)=n} left[e] (x) g[e]
+ * with left = edge_cell_shift -- or any other [E,3] per-edge factor: with left = edge_vec it is the per-atom virial
+ * sum, which nqa_virial_finalize reduces per frame:
+ *   virial[f] = -sym(sum_n per_atom[n]),  stress[f] = sym(...) / |det cell[f]|   (nequip/nn/grad_output.py:222-271;
+ *   stress may be NULL (no cell); batch [N] int64 is required iff num_frames > 1). */
+int nqa_virial_finalize(const double* per_atom, const int64_t* batch, const double* cell, int64_t num_nodes,
+                        int64_t num_frames, double* virial, double* stress, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge embedding: real spherical harmonics + Bessel radial basis with polynomial cutoff.

@@ -83,8 +83,9 @@ SIGNATURES = {
     ),
     "nqa_edge_vectors_bwd": (
         c_int32,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p],
     ),
+    "nqa_virial_finalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "nqa_edge_embed_fwd": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]

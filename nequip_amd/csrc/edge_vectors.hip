@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void edge_vectors_bwd_kernel(const double* __r
                                                                const int32_t* __restrict__ eid_dst,
                                                                const int32_t* __restrict__ rowptr_src,
                                                                const int32_t* __restrict__ eid_src, int64_t N,
-                                                               double* __restrict__ g_pos,
+                                                               double sign, double* __restrict__ g_pos,
                                                                double* __restrict__ cell_part) {
   const int lane = threadIdx.x & 63;
   const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -90,12 +90,52 @@ __global__ __launch_bounds__(256) void edge_vectors_bwd_kernel(const double* __r
     for (int i = 0; i < 9; ++i) m[i] = wave_sum_f64(m[i]);
   }
   if (lane == 0) {
-    g_pos[3 * n + 0] = ax;
-    g_pos[3 * n + 1] = ay;
-    g_pos[3 * n + 2] = az;
+    g_pos[3 * n + 0] = sign * ax;
+    g_pos[3 * n + 1] = sign * ay;
+    g_pos[3 * n + 2] = sign * az;
     if (cell_part != nullptr) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) cell_part[9 * n + i] = m[i];
+    }
+  }
+}
+
+// One workgroup per frame: m = sum over the frame's atoms of part[n] (ordered tree reduction), virial = -sym(m),
+// stress = sym(m) / |det cell|.  Replaces the tail of ForceStressOutput.forward (nequip/nn/grad_output.py:222-271).
+__global__ __launch_bounds__(256) void virial_finalize_kernel(const double* __restrict__ part,
+                                                              const int64_t* __restrict__ batch,
+                                                              const double* __restrict__ cell, int64_t N,
+                                                              double* __restrict__ virial,
+                                                              double* __restrict__ stress) {
+  __shared__ double red[9][256];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  double m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = 0.0;
+  for (int64_t n = tid; n < N; n += 256) {
+    if (batch != nullptr && batch[n] != f) continue;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] += part[9 * n + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) red[i][tid] = m[i];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) red[i][tid] += red[i][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 9) {
+    const int a = tid / 3, b = tid - 3 * a;
+    const double sym = 0.5 * (red[3 * a + b][0] + red[3 * b + a][0]);
+    virial[9 * f + tid] = -sym;
+    if (stress != nullptr) {
+      const double* __restrict__ c = cell + 9 * f;
+      const double vol = fabs(c[0] * (c[4] * c[8] - c[5] * c[7]) - c[1] * (c[3] * c[8] - c[5] * c[6]) +
+                              c[2] * (c[3] * c[7] - c[4] * c[6]));
+      stress[9 * f + tid] = sym / vol;
     }
   }
 }
@@ -129,7 +169,7 @@ int nqa_edge_vectors_fwd(const double* pos, const int64_t* edge_dst, const int64
 
 int nqa_edge_vectors_bwd(const double* g_edge_vec, const double* edge_cell_shift, const int32_t* rowptr_dst,
                          const int32_t* edge_id_dst, const int32_t* rowptr_src, const int32_t* edge_id_src,
-                         int64_t num_nodes, double* g_pos, double* g_cell_per_node, nqa_stream stream) {
+                         int64_t num_nodes, double sign, double* g_pos, double* g_cell_per_node, nqa_stream stream) {
   // (g_edge_vec / edge_cell_shift are only dereferenced inside non-empty edge rows: NULL is legal for a graph without
   // edges, where empty tensors have NULL data pointers)
   if (num_nodes < 0 || (num_nodes > 0 && (!g_pos || !rowptr_dst || !rowptr_src))) {
@@ -139,11 +179,30 @@ int nqa_edge_vectors_bwd(const double* g_edge_vec, const double* edge_cell_shift
   if (num_nodes == 0) return NQA_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(edge_vectors_bwd_kernel, dim3((unsigned)((num_nodes + 3) / 4)), dim3(256), 0, s, g_edge_vec,
-                     edge_cell_shift, rowptr_dst, edge_id_dst, rowptr_src, edge_id_src, num_nodes, g_pos,
+                     edge_cell_shift, rowptr_dst, edge_id_dst, rowptr_src, edge_id_src, num_nodes, sign, g_pos,
                      g_cell_per_node);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_edge_vectors_bwd: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_virial_finalize(const double* per_atom, const int64_t* batch, const double* cell, int64_t num_nodes,
+                        int64_t num_frames, double* virial, double* stress, nqa_stream stream) {
+  if (num_nodes < 0 || num_frames < 0 || (num_frames > 0 && !virial) || (num_nodes > 0 && !per_atom) ||
+      (stress != nullptr && cell == nullptr) || (num_frames > 1 && batch == nullptr)) {
+    set_error("nqa_virial_finalize: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  if (num_frames == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(virial_finalize_kernel, dim3((unsigned)num_frames), dim3(256), 0, s, per_atom,
+                     num_frames > 1 ? batch : nullptr, cell, num_nodes, virial, stress);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_virial_finalize: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

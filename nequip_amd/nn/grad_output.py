@@ -117,24 +117,25 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         rp_d, eid_d, _ = topo.by_dst
         rp_s, eid_s, _ = topo.by_src
         ev = edge_vec.detach()
-        g_pos = torch.empty((num_nodes, 3), dtype=torch.float64, device=pos.device)
+        forces = torch.empty((num_nodes, 3), dtype=torch.float64, device=pos.device)
         part = torch.empty((num_nodes, 9), dtype=torch.float64, device=pos.device)
+        virial = torch.empty((num_batch, 3, 3), dtype=torch.float64, device=pos.device)
+        stress = torch.empty((num_batch, 3, 3), dtype=torch.float64, device=pos.device) if has_cell else None
+        cell_c = cell.contiguous() if has_cell else None
+        stream = current_stream_ptr(pos.device)
         with torch.cuda.device(pos.device):
             # the kernel's generic per-edge left factor (the cell shift in the autograd adjoint) is the edge vector here:
-            # part[n] = sum_{e: centre(e) = n} edge_vec_e (x) g_e
+            # part[n] = sum_{e: centre(e) = n} edge_vec_e (x) g_e;  sign -1: forces = -dE/dpos directly
             rc = lib.nqa_edge_vectors_bwd(_ptr(g), _ptr(ev), _ptr(rp_d), _ptr(eid_d), _ptr(rp_s), _ptr(eid_s),
-                                          num_nodes, _ptr(g_pos), _ptr(part), current_stream_ptr(pos.device))
-        _lib.check(rc, "nqa_edge_vectors_bwd")
-        data[K.FORCE_KEY] = torch.neg(g_pos)
-        if num_batch > 1:
-            m = torch.zeros((num_batch, 9), dtype=torch.float64, device=pos.device).index_add_(0, batch, part)
-        else:
-            m = part.sum(0, keepdim=True)
-        m = m.view(num_batch, 3, 3)
-        virial = 0.5 * (m + m.transpose(-1, -2))
+                                          num_nodes, -1.0, _ptr(forces), _ptr(part), stream)
+            _lib.check(rc, "nqa_edge_vectors_bwd")
+            # virial = -sym(sum_n part[n]) per frame, stress = sym / volume: one launch instead of ten small ATen kernels
+            rc = lib.nqa_virial_finalize(_ptr(part), _ptr(batch.contiguous() if batch is not None else None),
+                                         _ptr(cell_c), num_nodes, num_batch, _ptr(virial), _ptr(stress), stream)
+            _lib.check(rc, "nqa_virial_finalize")
+        data[K.FORCE_KEY] = forces
         if has_cell:
-            volume = torch.sum(cell[:, 0] * torch.linalg.cross(cell[:, 1], cell[:, 2], dim=-1), dim=-1).abs()
-            data[K.STRESS_KEY] = virial / volume.view(num_batch, 1, 1)
-        data[K.VIRIAL_KEY] = torch.neg(virial)
+            data[K.STRESS_KEY] = stress
+        data[K.VIRIAL_KEY] = virial
         data[K.EDGE_VECTORS_KEY] = ev
         return data

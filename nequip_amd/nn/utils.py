@@ -80,7 +80,7 @@ class _EdgeVectorsAdjFn(torch.autograd.Function):
         part = torch.empty((num_nodes, 9), dtype=torch.float64, device=g.device) if cell_shape is not None else None
         with torch.cuda.device(g.device):
             rc = lib.nqa_edge_vectors_bwd(_ptr(g), _ptr(shift), _ptr(rp_d), _ptr(eid_d), _ptr(rp_s), _ptr(eid_s),
-                                          num_nodes, _ptr(g_pos), _ptr(part), current_stream_ptr(g.device))
+                                          num_nodes, 1.0, _ptr(g_pos), _ptr(part), current_stream_ptr(g.device))
         _lib.check(rc, "nqa_edge_vectors_bwd")
         g_cell = None
         if cell_shape is not None:
