@@ -258,6 +258,7 @@ def main():
         try:
             # the edge topology (CSR) is static for a fixed neighbour list: it is built once in the eager
             # warm-up above and stays cached; the graph captures the model evaluation only
+            torch.cuda.empty_cache()  # the graph gets a private pool: hand the warm-up's cached blocks back first
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
