@@ -31,7 +31,8 @@ def _compute_neighborlist_single_frame(
     r_max: float,
     cell: Optional[torch.Tensor] = None,
     pbc: Union[bool, Tuple[bool, bool, bool], torch.Tensor] = False,
-) -> Tuple[torch.Tensor, torch.Tensor]:
+    return_rowptr: bool = False,
+):
     """``(edge_index [2, E] int64, edge_cell_shift [E, 3])`` of one frame (``nequip/data/_nl.py:63-165``)."""
     if not pos.is_cuda:
         raise RuntimeError("the `nequip_amd` neighbour list runs on the GPU: positions must be a CUDA/HIP tensor")
@@ -63,6 +64,8 @@ def _compute_neighborlist_single_frame(
         shifts = torch.empty((E, 3), dtype=torch.float64, device=device)
         rc = lib.nqa_neighbor_list_fill(_ptr(ws), _ptr(rowptr), N, E, _ptr(edge_index), _ptr(shifts), stream)
         _lib.check(rc, "nqa_neighbor_list_fill")
+    if return_rowptr:
+        return edge_index, shifts.to(out_dtype), rowptr
     return edge_index, shifts.to(out_dtype)
 
 
@@ -97,17 +100,32 @@ def compute_neighborlist_(data: AtomicDataDict.Type, r_max: float,
     for c in counts:
         offsets.append(offsets[-1] + int(c))
     has_cell = data.get(K.CELL_KEY, None) is not None
-    eidx, shifts = [], []
+    eidx, shifts, rowptrs = [], [], []
     for f in range(nframes):
         frame = _frame_from_batched(data, f, offsets)
         cell = frame.get(K.CELL_KEY, None)
         pbc = frame.get(K.PBC_KEY, None)
         if pbc is None:
             pbc = False
-        ei, sh = _compute_neighborlist_single_frame(frame[K.POSITIONS_KEY], r_max, cell=cell, pbc=pbc)
+        ei, sh, rp = _compute_neighborlist_single_frame(frame[K.POSITIONS_KEY], r_max, cell=cell, pbc=pbc,
+                                                        return_rowptr=True)
         eidx.append(ei + offsets[f])
+        rowptrs.append(rp)
         shifts.append(sh)
     data[K.EDGE_INDEX_KEY] = torch.cat(eidx, dim=1) if len(eidx) > 1 else eidx[0]
+    # the list is grouped by centre atom: give the tensor-product kernels its row pointer (saves the dst sort)
+    from ..nn._topology import topology_cache
+
+    if len(rowptrs) == 1:
+        rowptr = rowptrs[0]
+    else:
+        parts, eoff = [], 0
+        for f, rp in enumerate(rowptrs):
+            parts.append(rp[:-1] + eoff)
+            eoff += int(eidx[f].shape[1])
+        parts.append(torch.tensor([eoff], dtype=torch.int32, device=rowptrs[0].device))
+        rowptr = torch.cat(parts).to(torch.int32)
+    topology_cache.hint_sorted(data[K.EDGE_INDEX_KEY], rowptr)
     if has_cell:
         data[K.EDGE_CELL_SHIFT_KEY] = torch.cat(shifts, dim=0) if len(shifts) > 1 else shifts[0]
     return data

@@ -10,6 +10,7 @@ device by ``nqa_csr_build`` and reused by the three convolution layers and their
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -31,7 +32,8 @@ class EdgeTopology:
 
     check_indices: bool = False  # set True to validate 0 <= index < num_nodes (costs a device sync)
 
-    def __init__(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int):
+    def __init__(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int,
+                 rowptr_dst: Optional[torch.Tensor] = None):
         if not edge_dst.is_cuda:
             raise RuntimeError(
                 "nequip_amd kernels run on the GPU only (got CPU index tensors); there is no CPU fallback"
@@ -45,6 +47,12 @@ class EdgeTopology:
         self._src = edge_src.contiguous()
         self._by_dst: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._by_src: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        if rowptr_dst is not None and rowptr_dst.numel() == self.num_nodes + 1:
+            # edges already grouped by destination in ascending order (the device neighbour list emits them that way and
+            # hands over its row pointer): the dst-CSR is the identity permutation, no sort needed
+            eid = torch.arange(max(self.num_edges, 1), dtype=torch.int32, device=self.device)
+            oth = self._src.to(torch.int32) if self.num_edges else torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._by_dst = (rowptr_dst, eid, oth)
 
     def _build(self, key: torch.Tensor, other: torch.Tensor):
         lib = _lib.load()
@@ -93,6 +101,21 @@ class _TopologyCache:
     def _base(t: torch.Tensor) -> torch.Tensor:
         return t._base if t._base is not None else t
 
+    def hint_sorted(self, edge_index: torch.Tensor, rowptr_dst: torch.Tensor) -> None:
+        """Called by the device neighbour list: `edge_index` ([2, E], rows = dst, src) is grouped by dst in ascending order
+        and `rowptr_dst` ([N+1] int32) is its row pointer.  Used by the next `get` on views of that very tensor."""
+        self._hint = (weakref.ref(edge_index), edge_index.data_ptr(), edge_index._version, rowptr_dst)
+
+    def _rowptr_hint(self, bd: torch.Tensor, edge_dst: torch.Tensor, num_nodes: int):
+        hint = getattr(self, "_hint", None)
+        if os.environ.get("NQA_NO_NL_HINT", "") not in ("", "0"):
+            return None
+        if hint is None or hint[0]() is not bd or bd.data_ptr() != hint[1] or bd._version != hint[2]:
+            return None
+        if edge_dst.data_ptr() != bd.data_ptr() or hint[3].numel() != num_nodes + 1:
+            return None  # not row 0 of the hinted tensor
+        return hint[3]
+
     def get(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int) -> EdgeTopology:
         bd, bs = self._base(edge_dst), self._base(edge_src)
         key = (
@@ -102,7 +125,7 @@ class _TopologyCache:
         alive = self._ref is not None and self._ref[0]() is bd and self._ref[1]() is bs
         if self._topo is not None and alive and key == self._key:
             return self._topo
-        topo = EdgeTopology(edge_dst, edge_src, num_nodes)
+        topo = EdgeTopology(edge_dst, edge_src, num_nodes, rowptr_dst=self._rowptr_hint(bd, edge_dst, num_nodes))
         self._key = key
         self._ref = (weakref.ref(bd), weakref.ref(bs))
         self._topo = topo
@@ -110,6 +133,7 @@ class _TopologyCache:
 
     def clear(self):
         self._key = self._ref = self._topo = None
+        self._hint = None
 
 
 topology_cache = _TopologyCache()
