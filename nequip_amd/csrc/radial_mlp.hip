@@ -482,6 +482,10 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
   const int64_t myrow = (int64_t)blockIdx.x * (NW * 32) + wv * 32 + l31;
   const bool row_ok = myrow < E;
 
+  // this lane's embedding row first: its HBM latency overlaps the weight staging below
+  float ev[kMaxNb];
+#pragma unroll
+  for (int c = 0; c < kMaxNb; ++c) ev[c] = (c < nb && row_ok) ? emb[myrow * nb + c] : 0.f;
   for (int i = tid; i < H * kMaxNb; i += NTH) {
     const int k = i / kMaxNb, c = i - k * kMaxNb;
     w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
@@ -507,20 +511,24 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
   // ---- step 1: hidden layer (K = nb <= 8) in exact fp32 on MFMA, SiLU, split into bf16 B fragments ---------------
   u32x4 bh[KS], bm[KS], bl[KS];
   {
-    float ev[kMaxNb];
-#pragma unroll
-    for (int c = 0; c < kMaxNb; ++c) ev[c] = (c < nb && row_ok) ? emb[myrow * nb + c] : 0.f;
 #pragma unroll
     for (int kb = 0; kb < H / 32; ++kb) {
       f32x16 hacc = {0};
+      if (!(dbg & 16)) {  // (ablation bit 16: skip the hidden-layer MFMAs)
 #pragma unroll
-      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
-        const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];
-        const float bv = half ? ev[2 * s2 + 1] : ev[2 * s2];
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+        for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+          const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];
+          const float bv = half ? ev[2 * s2 + 1] : ev[2 * s2];
+          hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
+        if (dbg & 16) {
+          const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
+          bh[s][tp] = 0x3f803f80u + lane; bm[s][tp] = 0x3c003c00u; bl[s][tp] = 0x38003800u;
+          continue;
+        }
         const float h0 = row_ok ? silu_f(hacc[r]) : 0.f;
         const float h1 = row_ok ? silu_f(hacc[r + 1]) : 0.f;
         uint32_t a, b, c;
@@ -580,12 +588,13 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
     for (int q = 0; q < 3; ++q) fa[0][q] = a[q * 64];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) {
+      if (s + 1 < KS && !(dbg & 32)) {  // (ablation bit 32: no LDS fragment reads after the first k-step)
 #pragma unroll
         for (int q = 0; q < 3; ++q) fa[(s + 1) & 1][q] = a[((s + 1) * 3 + q) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
+      const int sb = (dbg & 32) ? 0 : (s & 1);
+      const u32x4 &ah = fa[sb][0], &am = fa[sb][1], &al = fa[sb][2];
       accA = mfma_bf16(ah, bh[s], accA);
       accB = mfma_bf16(am, bm[s], accB);
       accA = mfma_bf16(ah, bm[s], accA);
