@@ -273,13 +273,16 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  *   out[z,c] = gate < 0 ? act(in[z,src]) : act(in[z,gate]) * in[z,src]; backward, per INPUT column:
  *   {kind, act, o, i, cst, len, gate}: kind 0 (scalar) gin = g[z,o] act'(in[z,c]); kind 1 (gate) gin = act'(in[z,c])
  *   sum_{m<len} g[z,o+m] in[z,i+m]; kind 2 (gated) gin = act(in[z,gate]) g[z,o]; kind 3: zero.
+ *   Second order (training, nequip/nn/grad_output.py:220 create_graph): with a cotangent c [N, dim_in] of gin,
+ *   backward = 2 writes d<c,gin>/d grad_out [N, dim_out] (forward table), backward = 3 writes d<c,gin>/d input
+ *   [N, dim_in] (backward table).
  * ------------------------------------------------------------------------------------------- */
 int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
                     int32_t n_instr, int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out,
                     int64_t num_nodes, double scale, int32_t chunk_width, nqa_stream stream);
-int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
-             const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
+int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, const void* cotangent,
+             void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Neighbour list on the device: replaces _compute_neighborlist_single_frame

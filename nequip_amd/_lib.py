@@ -126,7 +126,7 @@ SIGNATURES = {
     "nqa_neighbor_list_fill": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "nqa_gate": (
         c_int32,
-        [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],
+        [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],
     ),
 }
 

@@ -521,6 +521,19 @@ __device__ __forceinline__ T act_grad(int act, T x, T cst) {
   return T(1);
 }
 
+template <typename T>
+__device__ __forceinline__ T act_grad2(int act, T x, T cst) {
+  if (act == 1) {  // d2/dx2 of x sigma(x)
+    const T s = T(1) / (T(1) + exp(-x));
+    return cst * s * (T(1) - s) * (T(2) + x * (T(1) - T(2) * s));
+  }
+  if (act == 2) {
+    const T t = tanh(x);
+    return -T(2) * cst * t * (T(1) - t * t);
+  }
+  return T(0);
+}
+
 // Column tables (built by the host from the irreps bookkeeping, one 32-byte record per column):
 //   forward,  per OUTPUT column c: {a = src, b = gate (-1: scalar), c = act, cst}
 //       out[z,c] = gate < 0 ? act(in[z,src]) : act(in[z,gate]) * in[z,src]
@@ -539,8 +552,9 @@ static_assert(sizeof(GateCol) == 32, "GateCol layout is part of the C ABI");
 template <typename T>
 struct GateArgs {
   const T* __restrict__ in;
-  const T* __restrict__ gout;  // backward only
-  T* __restrict__ out;         // fwd: out [N, dout]; bwd: gin [N, din]
+  const T* __restrict__ gout;  // backward (and second order) only
+  const T* __restrict__ cot;   // second order only: cotangent of grad_in [N, din]
+  T* __restrict__ out;         // fwd: out [N, dout]; bwd: gin [N, din]; 2: [N, dout]; 3: [N, din]
   const GateCol* __restrict__ cols;
   int32_t din, dout;
   int64_t N;
@@ -585,6 +599,68 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateArgs<T> a) {
       r = s * act_grad(t.b, row[c], cst);
     } else if (t.a == 2) {
       r = act_eval(t.b, row[t.f], cst) * g[t.c];
+    } else {
+      r = T(0);
+    }
+    a.out[z * a.din + c] = r;
+  }
+}
+
+// Second order (force-matching training differentiates the backward pass): with gin = gate_bwd(x, g) and a cotangent
+// c [N, din] of gin,
+//   mode 2 (per OUTPUT column, forward table): d<c, gin>/dg
+//       scalar o <- column s:  c_s a'(x_s);      gated o <- (v column i, gate column q):  c_q a'(x_q) v_i + c_i a(x_q)
+//   mode 3 (per INPUT column, backward table): d<c, gin>/dx
+//       scalar s:  c_s g_o a''(x_s);   gate q:  c_q a''(x_q) sum_m g_{o+m} v_{i+m} + a'(x_q) sum_m c_{i+m} g_{o+m};
+//       gated v_i:  c_q a'(x_q) g_o
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_bwd_g_kernel(const GateArgs<T> a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // output column
+  if (c >= a.dout) return;
+  const GateCol t = a.cols[c];
+  const T cst = (T)t.cst;
+  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z1 = min(z0 + kGateAtoms, a.N);
+#pragma unroll 4
+  for (int64_t z = z0; z < z1; ++z) {
+    const T* __restrict__ row = a.in + z * a.din;
+    const T* __restrict__ ct = a.cot + z * a.din;
+    T r;
+    if (t.b < 0) {
+      r = ct[t.a] * act_grad(t.c, row[t.a], cst);
+    } else {
+      const T xq = row[t.b];
+      r = ct[t.b] * act_grad(t.c, xq, cst) * row[t.a] + ct[t.a] * act_eval(t.c, xq, cst);
+    }
+    a.out[z * a.dout + c] = r;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_bwd_x_kernel(const GateArgs<T> a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // input column
+  if (c >= a.din) return;
+  const GateCol t = a.cols[c];
+  const T cst = (T)t.cst;
+  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z1 = min(z0 + kGateAtoms, a.N);
+#pragma unroll 4
+  for (int64_t z = z0; z < z1; ++z) {
+    const T* __restrict__ row = a.in + z * a.din;
+    const T* __restrict__ g = a.gout + z * a.dout;
+    const T* __restrict__ ct = a.cot + z * a.din;
+    T r;
+    if (t.a == 0) {
+      r = ct[c] * g[t.c] * act_grad2(t.b, row[c], cst);
+    } else if (t.a == 1) {
+      T sgv = T(0), scg = T(0);
+      for (int m = 0; m < t.e; ++m) {
+        sgv += g[t.c + m] * row[t.d + m];
+        scg += ct[t.d + m] * g[t.c + m];
+      }
+      r = ct[c] * act_grad2(t.b, row[c], cst) * sgv + act_grad(t.b, row[c], cst) * scg;
+    } else if (t.a == 2) {
+      r = ct[t.f] * act_grad(t.b, row[t.f], cst) * g[t.c];
     } else {
       r = T(0);
     }
@@ -734,20 +810,22 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
   return NQA_OK;
 }
 
-int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, void* out,
-             const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream) {
+int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, const void* cotangent,
+             void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream) {
   if (dtype != NQA_F32 && dtype != NQA_F64) {
     set_error("nqa_gate: unsupported dtype");
     return NQA_ERR_UNSUPPORTED;
   }
-  if (num_nodes < 0 || (num_nodes > 0 && (!input || !out || !col_table || (backward && !grad_out))) || dim_in <= 0 ||
-      dim_out <= 0) {
+  if (backward < 0 || backward > 3 || num_nodes < 0 ||
+      (num_nodes > 0 && (!input || !out || !col_table || ((backward == 1 || backward == 3) && !grad_out) ||
+                         (backward >= 2 && !cotangent))) ||
+      dim_in <= 0 || dim_out <= 0) {
     set_error("nqa_gate: invalid argument");
     return NQA_ERR_INVALID;
   }
   if (num_nodes == 0) return NQA_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int cols = backward ? dim_in : dim_out;
+  const int cols = (backward == 1 || backward == 3) ? dim_in : dim_out;
   const int64_t ny = (num_nodes + kGateAtoms - 1) / kGateAtoms;
   if (ny > 2147483647LL) {
     set_error("nqa_gate: too many atoms for one launch");
@@ -760,15 +838,20 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
     GateArgs<T> a{};                                                                              \
     a.in = static_cast<const T*>(input);                                                          \
     a.gout = static_cast<const T*>(grad_out);                                                     \
+    a.cot = static_cast<const T*>(cotangent);                                                     \
     a.out = static_cast<T*>(out);                                                                 \
     a.cols = static_cast<const GateCol*>(col_table);                                              \
     a.din = dim_in;                                                                               \
     a.dout = dim_out;                                                                             \
     a.N = num_nodes;                                                                              \
-    if (backward)                                                                                 \
-      hipLaunchKernelGGL(gate_bwd_kernel<T>, grid, dim3(bdim), 0, s, a);                     \
+    if (backward == 1)                                                                            \
+      hipLaunchKernelGGL(gate_bwd_kernel<T>, grid, dim3(bdim), 0, s, a);                          \
+    else if (backward == 2)                                                                       \
+      hipLaunchKernelGGL(gate_bwd_bwd_g_kernel<T>, grid, dim3(bdim), 0, s, a);                    \
+    else if (backward == 3)                                                                       \
+      hipLaunchKernelGGL(gate_bwd_bwd_x_kernel<T>, grid, dim3(bdim), 0, s, a);                    \
     else                                                                                          \
-      hipLaunchKernelGGL(gate_fwd_kernel<T>, grid, dim3(bdim), 0, s, a);                     \
+      hipLaunchKernelGGL(gate_fwd_kernel<T>, grid, dim3(bdim), 0, s, a);                          \
   }
   if (dtype == NQA_F32) NQA_GATE_LAUNCH(float) else NQA_GATE_LAUNCH(double)
 #undef NQA_GATE_LAUNCH

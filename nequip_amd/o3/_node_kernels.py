@@ -235,14 +235,15 @@ class GateMeta:
         return self._dev[key]
 
 
-def _launch_gate(x, gout, meta: GateMeta, backward: bool):
+def _launch_gate(x, gout, meta: GateMeta, mode: int, cot=None):
+    """mode 0: forward; 1: grad_in(x, gout); 2 / 3: gradient of <cot, grad_in> w.r.t. gout / x (second order)."""
     lib = _lib.load()
     ft, bt = meta.device_tables(x.device)
     N = x.shape[0]
-    out = torch.empty((N, meta.din if backward else meta.dout), dtype=x.dtype, device=x.device)
+    out = torch.empty((N, meta.din if mode in (1, 3) else meta.dout), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device), ktimer.region("gate", x.element_size() * N * (meta.din + meta.dout)):
-        rc = lib.nqa_gate(_dt(x.dtype), 1 if backward else 0, _ptr(x), _ptr(gout), _ptr(out),
-                          _ptr(bt if backward else ft), meta.din, meta.dout, N, _stream(x.device))
+        rc = lib.nqa_gate(_dt(x.dtype), mode, _ptr(x), _ptr(gout), _ptr(cot), _ptr(out),
+                          _ptr(bt if mode in (1, 3) else ft), meta.din, meta.dout, N, _stream(x.device))
     _lib.check(rc, "nqa_gate")
     return out
 
@@ -253,14 +254,33 @@ class _GateFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x)
         ctx.meta = meta
-        return _launch_gate(x, None, meta, False)
+        return _launch_gate(x, None, meta, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _GateBwdFn.apply(x, g, ctx.meta), None
+
+
+class _GateBwdFn(torch.autograd.Function):
+    """(x, grad_out) -> grad_in; differentiable once more (force-matching training)."""
+
+    @staticmethod
+    def forward(ctx, x, g, meta: GateMeta):
+        g = g.contiguous()
+        ctx.save_for_backward(x, g)
+        ctx.meta = meta
+        return _launch_gate(x, g, meta, 1)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return _launch_gate(x, g.contiguous(), ctx.meta, True), None
+    def backward(ctx, c):
+        x, g = ctx.saved_tensors
+        c = c.contiguous()
+        gx = _launch_gate(x, g, ctx.meta, 3, cot=c) if ctx.needs_input_grad[0] else None
+        gg = _launch_gate(x, None, ctx.meta, 2, cot=c) if ctx.needs_input_grad[1] else None
+        return gx, gg, None
 
 
-def gate(x, meta: GateMeta, differentiable_twice: bool = False):
+def gate(x, meta: GateMeta):
     return _GateFn.apply(x, meta)

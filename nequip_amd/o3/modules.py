@@ -285,8 +285,8 @@ class Gate(torch.nn.Module):
         return torch.cat(cols, dim=-1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.is_cuda and not self.training and self._kernel_meta is not None and x.dtype in (torch.float32, torch.float64):
-            # inference: one fused launch (first-order differentiable); training keeps the autograd formulation
+        if x.is_cuda and self._kernel_meta is not None and x.dtype in (torch.float32, torch.float64):
+            # one fused launch per pass: forward, backward and (training) the backward's own backward
             return _gate_kernel(x, self._kernel_meta)
         ns, ng = self.irreps_scalars.dim, self.irreps_gates.dim
         if ng == 0:

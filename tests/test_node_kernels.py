@@ -107,3 +107,41 @@ def test_gate_kernel(device, dtype):
         (gx,) = torch.autograd.grad(out, xd, go.to(device))
         torch.testing.assert_close(ref.detach(), out.detach().cpu(), atol=tol, rtol=tol)
         torch.testing.assert_close(gx_ref, gx.cpu(), atol=tol * max(1.0, float(gx_ref.abs().max())), rtol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_gate_kernel_double_backward(device, dtype):
+    """Second order of the gate kernels (what force-matching training differentiates: grad_in as a function of x and
+    grad_out) against autograd through the oracle's Gate restatement."""
+    from nequip_amd.o3.modules import Gate
+
+    tol = 2e-5 if dtype == torch.float32 else 1e-11
+    silu, tanh = torch.nn.functional.silu, torch.tanh
+    names = {silu: "silu", tanh: "tanh"}
+    for sc, acts, ga, actg, gd in [
+        ("64x0e", [silu], "128x0e", [silu], "64x1o+64x2e"),
+        ("8x0e+8x0o", [silu, tanh], "16x0e", [silu], "4x1e+4x1o+4x2e+4x2o"),
+        ("16x0e", [silu], "", [], ""),
+    ]:
+        gate = Gate(sc, acts, ga, actg, gd).train()  # kernels in training mode too
+        g = torch.Generator().manual_seed(9)
+        Z = 21
+        x = torch.randn(Z, gate.irreps_in.dim, generator=g, dtype=dtype)
+        go = torch.randn(Z, gate.irreps_out.dim, generator=g, dtype=dtype)
+        cot = torch.randn(Z, gate.irreps_in.dim, generator=g, dtype=dtype)
+
+        def second_order(fn, x0, go0, cot0):
+            xr = x0.clone().requires_grad_(True)
+            gr = go0.clone().requires_grad_(True)
+            (gin,) = torch.autograd.grad(fn(xr), xr, gr, create_graph=True)
+            gx2, gg2 = torch.autograd.grad(gin, [xr, gr], cot0)
+            return gin.detach(), gx2, gg2
+
+        ref = second_order(lambda t: onn.gate(t, str(gate.irreps_scalars), [names[a] for a in acts],
+                                              str(gate.irreps_gates) if ga else [], [names[a] for a in actg],
+                                              str(gate.irreps_gated) if gd else []), x, go, cot)
+        gate_d = gate.to(device)
+        out = second_order(gate_d, x.to(device), go.to(device), cot.to(device))
+        for r, o in zip(ref, out):
+            torch.testing.assert_close(r, o.cpu(), atol=tol * max(1.0, float(r.abs().max())), rtol=tol)
