@@ -46,6 +46,9 @@ WORKLOADS = {
     # BASELINE config 5: 100k-atom fcc Cu, l_max=3, 128 features (cu20k: same model on a fifth of the box)
     "cu100k": dict(box="cu", reps=(25, 25, 40), l_max=3, num_features=128, num_layers=3),
     "cu20k": dict(box="cu", reps=(25, 25, 8), l_max=3, num_features=128, num_layers=3),
+    # BASELINE config 1: the tutorial hyper-parameters on a batch of 5 aspirin-like 21-atom molecules (non-periodic)
+    "aspirin5": dict(box="aspirin", frames=5, l_max=1, num_features=32, num_layers=4, r_max=5.0, parity=True,
+                     radial_mlp_depth=2, radial_mlp_width=64),
 }
 
 
@@ -59,8 +62,9 @@ def baseline_metric() -> str:
 
 def model_cfg(w, avg_num_neighbors):
     return dict(
-        r_max=4.5, num_layers=w["num_layers"], l_max=w["l_max"], parity=False, num_features=w["num_features"],
-        radial_mlp_depth=1, radial_mlp_width=128, num_bessels=8, polynomial_cutoff_p=6,
+        r_max=w.get("r_max", 4.5), num_layers=w["num_layers"], l_max=w["l_max"], parity=w.get("parity", False),
+        num_features=w["num_features"], radial_mlp_depth=w.get("radial_mlp_depth", 1),
+        radial_mlp_width=w.get("radial_mlp_width", 128), num_bessels=8, polynomial_cutoff_p=6,
         avg_num_neighbors=float(avg_num_neighbors), model_dtype="float32",
     )  # fmt: skip
 
@@ -74,9 +78,18 @@ def build_box(w, seed=0):
         pos, types, cell, names = syn.silicon_box(reps=w["reps"], seed=seed)
     elif w["box"] == "cu":
         pos, types, cell, names = syn.copper_box(reps=tuple(w["reps"]), seed=seed)
+    elif w["box"] == "aspirin":
+        from nequip_amd.data import AtomicDataDict
+
+        frames = []
+        for f in range(w["frames"]):
+            pos, types, _, names = syn.aspirin_like(seed=seed * 100 + f)
+            frames.append(syn.make_data(pos, types, w.get("r_max", 4.5), None, pbc=False))
+        return AtomicDataDict.batched_from_list(frames), names
     else:
         raise ValueError(w["box"])
-    data = syn.make_data(pos, types, 4.5, cell, spatial_sort=os.environ.get("NQA_BENCH_SORT", "0") != "0")
+    data = syn.make_data(pos, types, w.get("r_max", 4.5), cell,
+                         spatial_sort=os.environ.get("NQA_BENCH_SORT", "0") != "0")
     return data, names
 
 
@@ -96,8 +109,11 @@ def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
     # bounded sample: same density / r_max / model, smaller box
     if w["box"] == "water":
         w["n_side"] = min(w["n_side"], 5)
-    else:
+    elif w["box"] == "si":
         w["reps"] = min(w["reps"], 3)
+    elif w["box"] == "cu":
+        w["reps"] = (3, 3, 3)
+    # (aspirin5 is small enough to be timed whole)
     data, names = build_box(w, seed=1)
     n_atoms = data["pos"].shape[0]
     n_edges = data["edge_index"].shape[1]
@@ -386,9 +402,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {n_atoms}-atom periodic {w['box']} box, {n_edges} edges, r_max 4.5, "
-                f"l_max={w['l_max']}, {w['num_features']} features, {w['num_layers']} layers, parity=False, "
-                "radial MLP 8-128-W, fp32 model / fp64 positions, energy+forces (autograd), random-init weights",
+                "workload": f"{args.workload}: {n_atoms}-atom {w['box']} box, {n_edges} edges, r_max {cfg['r_max']}, "
+                f"l_max={w['l_max']}, {w['num_features']} features, {w['num_layers']} layers, parity={cfg['parity']}, "
+                f"radial MLP 8-{cfg['radial_mlp_width']}(x{cfg['radial_mlp_depth']})-W, fp32 model / fp64 positions, "
+                "energy+forces (autograd), random-init weights",
                 "atoms_per_gpu": n_atoms,
                 "edges_per_gpu": n_edges,
                 "parallelism": f"replicas x{world} (frames independent, no data-path collective)",
