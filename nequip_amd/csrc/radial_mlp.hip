@@ -483,9 +483,25 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
   const bool row_ok = myrow < E;
 
   // this lane's embedding row first: its HBM latency overlaps the weight staging below
+  // (unpredicated loads from a clamped row, masked afterwards: per-element predicates would turn into eight
+  // branch + load + wait sequences, i.e. eight serial HBM round trips before the first MFMA)
   float ev[kMaxNb];
+  {
+    const float* __restrict__ er = emb + (row_ok ? myrow : (E - 1)) * nb;
+    if (nb == kMaxNb) {
+      const float4 e0 = *reinterpret_cast<const float4*>(er);
+      const float4 e1 = *reinterpret_cast<const float4*>(er + 4);
+      ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w;
+      ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
+    } else {
 #pragma unroll
-  for (int c = 0; c < kMaxNb; ++c) ev[c] = (c < nb && row_ok) ? emb[myrow * nb + c] : 0.f;
+      for (int c = 0; c < kMaxNb; ++c) ev[c] = er[c < nb ? c : nb - 1];
+#pragma unroll
+      for (int c = 0; c < kMaxNb; ++c) ev[c] = c < nb ? ev[c] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) ev[c] = row_ok ? ev[c] : 0.f;
+  }
   for (int i = tid; i < H * kMaxNb; i += NTH) {
     const int k = i / kMaxNb, c = i - k * kMaxNb;
     w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
@@ -658,7 +674,9 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   }
   for (int i = tid; i < kMlpRows * kMaxNb; i += 256) {
     const int r = i / kMaxNb, c = i - r * kMaxNb;
-    es[i] = (c < nb && blk0 + r < E) ? emb[(blk0 + r) * nb + c] : 0.f;
+    const int64_t rr = blk0 + r < E ? blk0 + r : E - 1;  // clamped, unpredicated load; masked below
+    const float v = emb[rr * nb + (c < nb ? c : nb - 1)];
+    es[i] = (c < nb && blk0 + r < E) ? v : 0.f;
   }
 
   const int nchunks = (W + 31) / 32;
