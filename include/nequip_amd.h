@@ -252,6 +252,32 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
                        int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
                        void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream);
 
+/* Training variants of the fused radial MLP (force-matching training differentiates the force pass once more,
+ *   nequip/nn/grad_output.py:216-221 `create_graph=self.training`; in the reference all of this is autograd through
+ *   ScalarMLPFunction.forward, nequip/nn/mlp.py:194-196).  NQA_MLP_BF16X6 only.  With W_i = w_i alpha_i, P = emb W0,
+ *   G_h = grad_edge_weight W1^T:
+ * nqa_radial_mlp_bwd_train, cotangent == NULL (first order, with the pieces of the parameter gradients):
+ *     grad_edge_embedding = (G_h silu'(P)) W0^T                       [E, num_basis]
+ *     hidden_out          = silu(P)                                   [E, hidden]   (dW1 = alpha1 hidden_out^T grad_edge_weight)
+ *     w0_partials[tile]   = emb_tile^T (G_h silu'(P))_tile            [tiles][num_basis][hidden], dW0 = alpha0 sum_tiles
+ *   cotangent != NULL ([E, num_basis], a cotangent c of grad_edge_embedding; second order), Q = c W0:
+ *     grad_edge_embedding = (Q G_h silu''(P)) W0^T                    = d<c, g_emb>/d emb
+ *     hidden_out          = Q silu'(P)                                (d<c,g_emb>/dW1 = alpha1 hidden_out^T grad_edge_weight)
+ *     w0_partials[tile]   = emb^T (Q G_h silu''(P)) + c^T (G_h silu'(P))   (d<c,g_emb>/dW0 = alpha0 sum_tiles)
+ *   tiles = nqa_radial_mlp_train_tiles(num_edges) (128-edge workgroup tiles).
+ * nqa_radial_mlp_fwd_tangent: out = (Q silu'(P)) W1 = d<c, g_emb>/d grad_edge_weight, the directional derivative of
+ *   the MLP along `cotangent`; same workspace as nqa_radial_mlp_fwd. */
+int64_t nqa_radial_mlp_train_tiles(int64_t num_edges);
+int nqa_radial_mlp_bwd_train(int32_t dtype, int32_t mode, const void* edge_embedding, const void* cotangent,
+                             const void* w0, double alpha0, const void* w1, double alpha1,
+                             const void* grad_edge_weight, int32_t num_basis, int32_t hidden, int32_t out_features,
+                             int64_t num_edges, void* grad_edge_embedding, void* hidden_out, void* w0_partials,
+                             void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream);
+int nqa_radial_mlp_fwd_tangent(int32_t dtype, int32_t mode, const void* edge_embedding, const void* cotangent,
+                               const void* w0, double alpha0, const void* w1, double alpha1, int32_t num_basis,
+                               int32_t hidden, int32_t out_features, int64_t num_edges, void* out, void* workspace,
+                               int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Node-side channel mixing in one launch: replaces e3nn o3.Linear (linear_1 / linear_2,
  *   nequip/nn/interaction_block.py:82-87,129-138,177,201), the self-connection
@@ -283,6 +309,25 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
                     int64_t num_nodes, double scale, int32_t chunk_width, nqa_stream stream);
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, const void* cotangent,
              void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Parameter gradients of the dense maps of the path (training; in the reference these come out of autograd as the
+ *   weight-side `mm` / `einsum` backward of ScalarLinearLayer.forward (nequip/nn/mlp.py:262-268), e3nn o3.Linear
+ *   (nequip/nn/interaction_block.py:82-87,129-138) and the self-connection FullyConnectedTensorProduct (:142-146)):
+ *     dW[t][out_off + i*N + j] = sum_{z < num_rows, type(z) == t} sum_{m < d} A[z*lda + a_off + i*d + m] *
+ *                                                                              B[z*ldb + b_off + j*d + m]
+ *   for every record {int32 a_off, b_off, M, N, d, out_off} of instr_table (HOST pointer, <= 64 records; i < M,
+ *   j < N).  ScalarMLP layer: one record {0, 0, in, out, 1, 0} over the E edge rows; o3.Linear / FCTP: one record per
+ *   (input block -> output block) matrix with d = 2l+1 over the N atom rows (mul_ir layout), row_types / n_types > 1
+ *   for the per-atom-type pre-contracted self-connection weights.
+ *   The reduction over rows is split into `splits` ranges (nqa_wgrad_splits suggests a count that fills the device);
+ *   partials is [splits][n_types][out_stride] floats, every element covered by a record is written (the rest is
+ *   left untouched), and the caller sums over the first axis -- deterministic, no atomics.  float32 only (fp32 MFMA).
+ * ------------------------------------------------------------------------------------------- */
+int32_t nqa_wgrad_splits(const void* instr_table, int32_t n_instr, int32_t n_types, int64_t num_rows);
+int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64_t* row_types,
+              const void* instr_table, int32_t n_instr, int64_t lda, int64_t ldb, int64_t num_rows, int32_t n_types,
+              int64_t out_stride, int32_t splits, void* partials, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Neighbour list on the device: replaces _compute_neighborlist_single_frame

@@ -128,6 +128,23 @@ SIGNATURES = {
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],
     ),
+    "nqa_radial_mlp_train_tiles": (c_int64, [c_int64]),
+    "nqa_radial_mlp_bwd_train": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_double, c_void_p, c_int32, c_int32,
+         c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p],
+    ),
+    "nqa_radial_mlp_fwd_tangent": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_double, c_int32, c_int32, c_int32,
+         c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p],
+    ),
+    "nqa_wgrad_splits": (c_int32, [c_void_p, c_int32, c_int32, c_int64]),
+    "nqa_wgrad": (
+        c_int32,
+        [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_int32, c_int64, c_int32,
+         c_void_p, c_void_p],
+    ),
 }
 
 _lock = threading.Lock()

@@ -38,6 +38,14 @@ constexpr int kMaxNb = 8;    // radial basis size limit of the fused kernels (ne
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// silu(x), silu'(x), silu''(x) from one sigmoid (training epilogues)
+__device__ __forceinline__ void silu_all_f(float x, float& h, float& d1, float& d2) {
+  const float sig = 1.0f / (1.0f + __expf(-x));
+  const float om = 1.0f - sig;
+  h = x * sig;
+  d1 = sig * (1.0f + x * om);
+  d2 = sig * om * (2.0f + x * (1.0f - 2.0f * sig));
+}
 __device__ __forceinline__ float silu_grad_f(float x) {
   const float s = 1.0f / (1.0f + __expf(-x));
   return s * (1.0f + x * (1.0f - s));
@@ -459,12 +467,14 @@ __global__ __launch_bounds__(256) void radial_mlp_split_w1_bwd_kernel(const floa
 
 // NW wavefronts (32 edges each) share every staged weight tile: 8 instead of 4 halves the L2 -> LDS weight traffic
 // (1.7 GB per middle-layer launch at NW = 4, i.e. the whole L2 bandwidth for ~100 us).
-template <int H, int NW>
+// TAN (nqa_radial_mlp_fwd_tangent): the hidden layer fed to the second GEMM is (cemb W0) silu'(emb W0) instead of
+// silu(emb W0) -- the directional derivative of the MLP along cemb; only step 1 differs.
+template <int H, int NW, bool TAN = false>
 __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wf, float a0, int nb,
                                                                     int W, int64_t E, float* __restrict__ out,
-                                                                    int dbg) {
+                                                                    int dbg, const float* __restrict__ cemb = nullptr) {
   constexpr int KS = H / 16;            // bf16 k-steps
   constexpr int TILE = KS * 3 * 64;     // uint4 per 32-column weight tile (24 KiB for H = 128)
   constexpr int NTH = NW * 64;          // threads per workgroup
@@ -502,6 +512,14 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
 #pragma unroll
     for (int c = 0; c < kMaxNb; ++c) ev[c] = row_ok ? ev[c] : 0.f;
   }
+  float cv[kMaxNb];
+  if (TAN) {
+    const float* __restrict__ cr = cemb + (row_ok ? myrow : (E - 1)) * nb;
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) cv[c] = cr[c < nb ? c : nb - 1];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) cv[c] = (row_ok && c < nb) ? cv[c] : 0.f;
+  }
   for (int i = tid; i < H * kMaxNb; i += NTH) {
     const int k = i / kMaxNb, c = i - k * kMaxNb;
     w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
@@ -538,6 +556,15 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
           hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
         }
       }
+      f32x16 qacc = {0};
+      if (TAN) {
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+          const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];
+          const float bv = half ? cv[2 * s2 + 1] : cv[2 * s2];
+          qacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, qacc, 0, 0, 0);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         if (dbg & 16) {
@@ -545,8 +572,8 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
           bh[s][tp] = 0x3f803f80u + lane; bm[s][tp] = 0x3c003c00u; bl[s][tp] = 0x38003800u;
           continue;
         }
-        const float h0 = row_ok ? silu_f(hacc[r]) : 0.f;
-        const float h1 = row_ok ? silu_f(hacc[r + 1]) : 0.f;
+        const float h0 = row_ok ? (TAN ? qacc[r] * silu_grad_f(hacc[r]) : silu_f(hacc[r])) : 0.f;
+        const float h1 = row_ok ? (TAN ? qacc[r + 1] * silu_grad_f(hacc[r + 1]) : silu_f(hacc[r + 1])) : 0.f;
         uint32_t a, b, c;
         split_pair(h0, h1, a, b, c);
         const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
@@ -636,13 +663,19 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
     emit(a1A, a1B, ntiles - 1);
 }
 
-template <int H>
+// TM (training mode, see nqa_radial_mlp_bwd_train): 0 = inference (g_emb only); 1 = additionally hid_out = silu(P)
+// and the per-workgroup partial of dW0 = emb^T (G_h silu'(P)); 2 = second order with a cotangent row block cemb:
+// Q = cemb W0, hid_out = Q silu'(P), g_emb = (Q G_h silu''(P)) W0^T, dW0 partial = emb^T (Q G_h silu'') + cemb^T (G_h silu').
+// Everything happens in the epilogue on the tile that is already on chip; the main loop is the same code.
+template <int H, int TM>
 __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wb,
                                                                     const float* __restrict__ gw, float a0, int nb,
                                                                     int W, int64_t E, float* __restrict__ g_emb,
-                                                                    int dbg) {
+                                                                    int dbg, const float* __restrict__ cemb,
+                                                                    float* __restrict__ hid_out,
+                                                                    float* __restrict__ w0_part) {
   // K (= W) is consumed in chunks of 32 columns = two bf16 k-steps; lane (row, half) owns the 16 contiguous floats
   // 32*chunk + 16*half + [0, 16) of its g_w row per chunk: HBM -> registers directly, split in registers.
   constexpr int NT = H / 32;
@@ -656,6 +689,10 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   __shared__ float w0s[H * kMaxNb];        // [k][c]
   __shared__ float w0t[kMaxNb * H];        // [c][k]
   __shared__ float es[kMlpRows * kMaxNb];  // embedding tile [row][c]
+  // cotangent tile [row][c] of the second-order mode: only needed after the GEMV pass, so for H = 128 (where LDS caps
+  // the occupancy) it reuses w0s' storage; each lane keeps its own cotangent row in registers until then
+  __shared__ float cs_own[(TM == 2 && H * kMaxNb < kMlpRows * kMaxNb) ? kMlpRows * kMaxNb : 1];
+  float* __restrict__ cs = (H * kMaxNb >= kMlpRows * kMaxNb) ? w0s : cs_own;
   u32x4* __restrict__ bsm = reinterpret_cast<u32x4*>(smem_raw);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -677,6 +714,14 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
     const int64_t rr = blk0 + r < E ? blk0 + r : E - 1;  // clamped, unpredicated load; masked below
     const float v = emb[rr * nb + (c < nb ? c : nb - 1)];
     es[i] = (c < nb && blk0 + r < E) ? v : 0.f;
+  }
+  float cvr[kMaxNb];
+  if (TM == 2) {
+    const float* __restrict__ cr = cemb + (row_ok ? myrow : (E - 1)) * nb;
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) cvr[c] = cr[c < nb ? c : nb - 1];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) cvr[c] = (row_ok && c < nb) ? cvr[c] : 0.f;
   }
 
   const int nchunks = (W + 31) / 32;
@@ -782,11 +827,50 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
         const float bv = w0t[(2 * s2 + half) * H + t * 32 + l31];
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, pacc, 0, 0, 0);
       }
-      const int col = t * 32 + l31;
+      f32x16 qacc = {0};
+      if (TM == 2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        gp[lr * GS + col] = acc[t][r] * silu_grad_f(pacc[r]);
+        for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+          const float av = half ? cvr[2 * s2 + 1] : cvr[2 * s2];
+          const float bv = w0t[(2 * s2 + half) * H + t * 32 + l31];
+          qacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, qacc, 0, 0, 0);
+        }
+      }
+      const int col = t * 32 + l31;
+      if (TM == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          gp[lr * GS + col] = acc[t][r] * silu_grad_f(pacc[r]);
+        }
+      } else {
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float h, d1, d2;
+          silu_all_f(pacc[r], h, d1, d2);
+          if (TM == 1) {
+            gp[lr * GS + col] = acc[t][r] * d1;
+            hv[r] = h;
+          } else {
+            gp[lr * GS + col] = qacc[r] * acc[t][r] * d2;
+            hv[r] = qacc[r] * d1;
+            acc[t][r] *= d1;  // G_h silu'(P): second partial pass below
+          }
+        }
+        // hidden-side output rows (silu(P) / Q silu'(P)), 128-byte runs per (row, half)
+        float* __restrict__ hrow = hid_out + (blk0 + wv * 32 + 4 * half) * (int64_t)H + col;
+        if (rows_full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hrow[(int64_t)((r & 3) + 8 * (r >> 2)) * H] = hv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (blk0 + lr < E) hrow[(int64_t)((r & 3) + 8 * (r >> 2)) * H] = hv[r];
+          }
+        }
       }
     }
   }
@@ -810,6 +894,44 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
     for (int c = 0; c < kMaxNb; ++c) sacc[c] += __shfl_xor(sacc[c], 1, 64);
     if (kh == 0 && blk0 + r < E) {
       for (int c = 0; c < nb; ++c) g_emb[(blk0 + r) * nb + c] = sacc[c];
+    }
+  }
+  if (TM != 0) {
+    // this workgroup's partial of dW0[c][k] = sum_rows emb[row][c] * tile[row][k]  (rows past E have emb = 0);
+    // thread = (k, group of CPT basis functions)
+    constexpr int NCG = 256 / H, CPT = kMaxNb / NCG;
+    const int k = tid % H, cg = tid / H;
+    float part[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) part[i] = 0.f;
+    for (int r = 0; r < kMlpRows; ++r) {
+      const float gv = gp[r * GS + k];
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) part[i] += es[r * kMaxNb + cg * CPT + i] * gv;
+    }
+    if (TM == 2) {
+      __syncthreads();  // every reader of the cotangent-side tile (and of w0s, reused for the cotangent rows) is done
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          gp[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * GS + t * 32 + l31] = acc[t][r];
+      if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < kMaxNb; ++c) cs[(wv * 32 + l31) * kMaxNb + c] = cvr[c];
+      }
+      __syncthreads();
+      for (int r = 0; r < kMlpRows; ++r) {
+        const float gv = gp[r * GS + k];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) part[i] += cs[r * kMaxNb + cg * CPT + i] * gv;
+      }
+    }
+    float* __restrict__ wp = w0_part + (int64_t)blockIdx.x * nb * H;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = cg * CPT + i;
+      if (c < nb) wp[c * H + k] = part[i];
     }
   }
 }
@@ -872,10 +994,10 @@ static int launch_status(const char* fn) {
   return NQA_OK;
 }
 
-int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
-                       const void* w1, double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features,
-                       int64_t num_edges, void* edge_weight, void* workspace, int64_t workspace_bytes,
-                       int32_t workspace_ready, nqa_stream stream) {
+static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding, const void* cotangent,
+                        const void* w0, double alpha0, const void* w1, double alpha1, int32_t num_basis,
+                        int32_t hidden, int32_t out_features, int64_t num_edges, void* edge_weight, void* workspace,
+                        int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_fwd");
   if (rc != NQA_OK) return rc;
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_fwd");
@@ -908,6 +1030,16 @@ int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
                          (float)alpha1, hidden, out_features, wf);
     const bool wide = (dbg & 64) != 0;  // NQA_MLP_DBG bit 6: 8 wavefronts (256 edges) per workgroup (measured: no gain)
     const unsigned g8 = (unsigned)((num_edges + 255) / 256);
+    if (cotangent != nullptr) {
+      const float* c = static_cast<const float*>(cotangent);
+      if (hidden == 128)
+        hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<128, 4, true>), dim3(grid), dim3(256), 0, s, e, a, wf,
+                           (float)alpha0, num_basis, out_features, num_edges, o, 0, c);
+      else
+        hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<64, 4, true>), dim3(grid), dim3(256), 0, s, e, a, wf,
+                           (float)alpha0, num_basis, out_features, num_edges, o, 0, c);
+      return launch_status("nqa_radial_mlp_fwd_tangent");
+    }
     if (hidden == 128 && wide)
       hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<128, 8>), dim3(g8), dim3(512), 0, s, e, a, wf, (float)alpha0,
                          num_basis, out_features, num_edges, o, dbg);
@@ -919,6 +1051,10 @@ int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
                          num_basis, out_features, num_edges, o, dbg);
     return launch_status("nqa_radial_mlp_fwd");
   }
+  if (cotangent != nullptr) {
+    set_error("nqa_radial_mlp_fwd_tangent: only NQA_MLP_BF16X6 is implemented");
+    return NQA_ERR_UNSUPPORTED;
+  }
   if (hidden == 128)
     hipLaunchKernelGGL(radial_mlp_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, b, (float)alpha0,
                        (float)alpha1, num_basis, out_features, num_edges, o, dbg);
@@ -928,10 +1064,31 @@ int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
   return launch_status("nqa_radial_mlp_fwd");
 }
 
-int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
-                       const void* w1, double alpha1, const void* grad_edge_weight, int32_t num_basis,
-                       int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
-                       void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
+int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                       const void* w1, double alpha1, int32_t num_basis, int32_t hidden, int32_t out_features,
+                       int64_t num_edges, void* edge_weight, void* workspace, int64_t workspace_bytes,
+                       int32_t workspace_ready, nqa_stream stream) {
+  return mlp_fwd_impl(dtype, mode, edge_embedding, nullptr, w0, alpha0, w1, alpha1, num_basis, hidden, out_features,
+                      num_edges, edge_weight, workspace, workspace_bytes, workspace_ready, stream);
+}
+
+int nqa_radial_mlp_fwd_tangent(int32_t dtype, int32_t mode, const void* edge_embedding, const void* cotangent,
+                               const void* w0, double alpha0, const void* w1, double alpha1, int32_t num_basis,
+                               int32_t hidden, int32_t out_features, int64_t num_edges, void* out, void* workspace,
+                               int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
+  if (num_edges > 0 && cotangent == nullptr) {
+    set_error("nqa_radial_mlp_fwd_tangent: cotangent is required");
+    return NQA_ERR_INVALID;
+  }
+  return mlp_fwd_impl(dtype, mode, edge_embedding, cotangent, w0, alpha0, w1, alpha1, num_basis, hidden,
+                      out_features, num_edges, out, workspace, workspace_bytes, workspace_ready, stream);
+}
+
+static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_embedding, const void* cotangent,
+                        void* hidden_out, void* w0_partials, const void* w0, double alpha0, const void* w1,
+                        double alpha1, const void* grad_edge_weight, int32_t num_basis, int32_t hidden,
+                        int32_t out_features, int64_t num_edges, void* grad_edge_embedding, void* workspace,
+                        int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
@@ -962,13 +1119,27 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
     if (!workspace_ready)
       hipLaunchKernelGGL(radial_mlp_split_w1_bwd_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, s, b,
                          (float)alpha1, hidden, out_features, wb);
-    if (hidden == 128)
-      hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<128>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
-                         num_basis, out_features, num_edges, o, dbg);
-    else
-      hipLaunchKernelGGL(radial_mlp_bwd_bf16x6_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
-                         num_basis, out_features, num_edges, o, dbg);
+    const float* c = static_cast<const float*>(cotangent);
+    float* ho = static_cast<float*>(hidden_out);
+    float* wp = static_cast<float*>(w0_partials);
+#define NQA_MLP_BWD_LAUNCH(HH, TT)                                                                              \
+  hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<HH, TT>), dim3(grid), dim3(256), 0, s, e, a, wb, g,          \
+                     (float)alpha0, num_basis, out_features, num_edges, o, (TT) == 0 ? dbg : 0, c, ho, wp)
+    if (hidden == 128) {
+      if (tm == 0) NQA_MLP_BWD_LAUNCH(128, 0);
+      else if (tm == 1) NQA_MLP_BWD_LAUNCH(128, 1);
+      else NQA_MLP_BWD_LAUNCH(128, 2);
+    } else {
+      if (tm == 0) NQA_MLP_BWD_LAUNCH(64, 0);
+      else if (tm == 1) NQA_MLP_BWD_LAUNCH(64, 1);
+      else NQA_MLP_BWD_LAUNCH(64, 2);
+    }
+#undef NQA_MLP_BWD_LAUNCH
     return launch_status("nqa_radial_mlp_bwd");
+  }
+  if (tm != 0) {
+    set_error("nqa_radial_mlp_bwd_train: only NQA_MLP_BF16X6 is implemented");
+    return NQA_ERR_UNSUPPORTED;
   }
   float* w1t = static_cast<float*>(workspace);  // [W (+ padding rows read by the last chunk)][H]
   if (!workspace_ready)
@@ -981,6 +1152,33 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
     hipLaunchKernelGGL(radial_mlp_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, e, a, w1t, g, (float)alpha0,
                        num_basis, out_features, num_edges, o);
   return launch_status("nqa_radial_mlp_bwd");
+}
+
+int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                       const void* w1, double alpha1, const void* grad_edge_weight, int32_t num_basis,
+                       int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
+                       void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
+  return mlp_bwd_impl(dtype, mode, 0, edge_embedding, nullptr, nullptr, nullptr, w0, alpha0, w1, alpha1,
+                      grad_edge_weight, num_basis, hidden, out_features, num_edges, grad_edge_embedding, workspace,
+                      workspace_bytes, workspace_ready, stream);
+}
+
+int64_t nqa_radial_mlp_train_tiles(int64_t num_edges) {
+  return num_edges <= 0 ? 0 : (num_edges + kMlpRows - 1) / kMlpRows;
+}
+
+int nqa_radial_mlp_bwd_train(int32_t dtype, int32_t mode, const void* edge_embedding, const void* cotangent,
+                             const void* w0, double alpha0, const void* w1, double alpha1,
+                             const void* grad_edge_weight, int32_t num_basis, int32_t hidden, int32_t out_features,
+                             int64_t num_edges, void* grad_edge_embedding, void* hidden_out, void* w0_partials,
+                             void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
+  if (num_edges > 0 && (hidden_out == nullptr || w0_partials == nullptr)) {
+    set_error("nqa_radial_mlp_bwd_train: hidden_out and w0_partials are required");
+    return NQA_ERR_INVALID;
+  }
+  return mlp_bwd_impl(dtype, mode, cotangent ? 2 : 1, edge_embedding, cotangent, hidden_out, w0_partials, w0, alpha0,
+                      w1, alpha1, grad_edge_weight, num_basis, hidden, out_features, num_edges, grad_edge_embedding,
+                      workspace, workspace_bytes, workspace_ready, stream);
 }
 
 }  // extern "C"

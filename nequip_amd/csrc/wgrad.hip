@@ -1,0 +1,301 @@
+// Parameter gradients of the dense maps on the path (training only): the reductions over edges / atoms that autograd
+// produces for
+//   ScalarMLPFunction layers   dW[i, j]    = sum_e a[e, i] g[e, j]                  (nequip/nn/mlp.py:262-268)
+//   e3nn o3.Linear             dW[u, w]    = sum_z sum_m x[z, u, m] g[z, w, m]      (interaction_block.py:82-87,129-138)
+//   self-connection FCTP       dW[t, u, w] = sum_{z: type z = t} sum_m x[z,u,m] g[z,w,m]  (interaction_block.py:142-146)
+// i.e. C = A^T B with a tiny output (<= 128 x 704) and a reduction length of 10^4..10^6 rows.  Library GEMMs run these
+// shapes on a handful of workgroups (no split over the reduction): 0.08-0.5 ms each, 7 ms of a 21 ms cfg-4 training
+// step.  Here the reduction is split over S row ranges; one wavefront owns a (<=128) x 64 output tile of one range and
+// feeds fp32 MFMA 32x32x2 straight from global memory -- both operands are read in their natural row-major layout
+// (lane = output row / column, the two k-slots of the instruction = two consecutive rows), so there is no transposition
+// and no LDS.  The S partial tiles are written to a workspace [S][n_types][weight_numel]; the caller sums over S
+// (deterministic: no atomics).  Operands of the next step are loaded before the MFMAs of the current one.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "plan.h"
+
+namespace nqa {
+
+struct WgradInstr {  // one weight matrix [M, N] (row-major at out_off); A block at a_off, B block at b_off, 2l+1 = d
+  int32_t a_off, b_off, M, N, d, out_off, unit_begin, mt;
+};
+static_assert(sizeof(WgradInstr) == 32, "WgradInstr layout");
+
+constexpr int kMaxWgradInstr = 64;
+constexpr int kWgU = 4;  // row pairs per pipeline step (8 rows)
+
+struct WgradArgs {
+  const float* __restrict__ A;        // [Z, lda]: element (z, i, m) of an instruction at a_off + i*d + m
+  const float* __restrict__ B;        // [Z, ldb]
+  const int64_t* __restrict__ types;  // optional [Z]
+  float* __restrict__ partials;       // [S][T][out_stride]
+  int64_t lda, ldb, Z, out_stride;
+  int32_t T, S, n_instr, zc;  // zc: rows per split (multiple of 2*kWgU)
+  int32_t total_units, pad;
+  WgradInstr instr[kMaxWgradInstr];
+};
+
+typedef float wg_f16 __attribute__((ext_vector_type(16)));
+
+// RB: 32-row blocks of the output tile owned by a wavefront (M <= 32*RB per tile), two 32-column blocks.
+template <int RB, bool TYPED>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
+  const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (unit >= a.total_units) return;
+  int qi = 0;
+  while (qi + 1 < a.n_instr && a.instr[qi + 1].unit_begin <= unit) ++qi;
+  const WgradInstr q = a.instr[qi];
+  const int nt = (q.N + 63) >> 6;
+  int local = unit - q.unit_begin;
+  const int nt_i = local % nt;
+  local /= nt;
+  const int mt_i = local % q.mt;
+  local /= q.mt;
+  const int s = local % a.S;
+  const int t = local / a.S;
+  const int m0 = mt_i * 32 * RB, n0 = nt_i * 64;
+  const int64_t z_begin = (int64_t)s * a.zc;
+  const int64_t z_end = z_begin + a.zc < a.Z ? z_begin + a.zc : a.Z;
+
+  // addressing: wave-uniform base of the step's first row (scalar registers) + a 32-bit per-lane byte offset
+  uint32_t ao[RB], bo[2], amask[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int i = m0 + rb * 32 + li;
+    amask[rb] = i < q.M ? 0xFFFFFFFFu : 0u;
+    ao[rb] = 4u * (uint32_t)(q.a_off + (i < q.M ? i : q.M - 1) * q.d);
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int j = n0 + cb * 32 + li;
+    bo[cb] = 4u * (uint32_t)(q.b_off + (j < q.N ? j : q.N - 1) * q.d);
+  }
+  const uint32_t lda4 = 4u * (uint32_t)a.lda, ldb4 = 4u * (uint32_t)a.ldb;
+
+  wg_f16 acc[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+
+  float av[2][RB][kWgU], bv[2][2][kWgU];
+  uint32_t msk[2][kWgU];
+  // operands of pipeline step (zb, m): rows zb + 2p + half, p < kWgU.  Every load is unconditional (addresses are
+  // clamped into the range); rows outside the range / of another atom type are zeroed through a bit mask on the A
+  // operand that is applied when the value is consumed, so nothing waits on the loads inside the request phase.
+  auto load = [&](int buf, int64_t zb, int m, bool live) {
+    const char* __restrict__ as = reinterpret_cast<const char*>(a.A + zb * a.lda + m);  // uniform
+    const char* __restrict__ bs = reinterpret_cast<const char*>(a.B + zb * a.ldb + m);
+#pragma unroll
+    for (int p = 0; p < kWgU; ++p) {
+      const bool in = live && (zb + 2 * p + half < z_end);
+      const uint32_t row = in ? (uint32_t)(2 * p + half) : 0u;  // row zb itself is always inside the range
+      uint32_t mk = in ? 0xFFFFFFFFu : 0u;
+      if (TYPED) {
+        const int64_t ty = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(a.types + zb) + 8u * row);
+        msk[buf][p] = ty == (int64_t)t ? mk : 0u;
+      } else {
+        msk[buf][p] = mk;
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) av[buf][rb][p] = *reinterpret_cast<const float*>(as + (row * lda4 + ao[rb]));
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) bv[buf][cb][p] = *reinterpret_cast<const float*>(bs + (row * ldb4 + bo[cb]));
+    }
+  };
+  auto mfma_all = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < kWgU; ++p)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const float x =
+            __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av[buf][rb][p]) & msk[buf][p] & amask[rb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bv[buf][cb][p], acc[rb][cb], 0, 0, 0);
+      }
+  };
+  if (z_begin < z_end) {
+    // steps (row block zb, component m), m fastest; the count is padded to an even number (the padding step re-reads the
+    // last block with a zero A operand) so that the two-phase loop has a single exit and the accumulators stay in place
+    const int64_t nzb = (z_end - z_begin + 2 * kWgU - 1) / (2 * kWgU);
+    const int64_t nsteps = nzb * q.d;
+    int64_t zb = z_begin;
+    int m = 0;
+    int64_t it = 0;
+    // one pipeline phase: request the operands of the next step into the other register set, then issue the MFMAs
+    // of the current one (buffer indices are literals at both call sites: no dynamic register indexing)
+    auto phase = [&](int cur_buf, int nxt_buf) {
+      int64_t zb_n = zb;
+      int m_n = m + 1;
+      if (m_n == q.d) {
+        m_n = 0;
+        zb_n = zb + 2 * kWgU;
+      }
+      ++it;
+      const bool live = it < nsteps;
+      if (!live) {
+        zb_n = zb;
+        m_n = 0;
+      }
+      load(nxt_buf, zb_n, m_n, live);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_all(cur_buf);
+      __builtin_amdgcn_sched_barrier(0);
+      zb = zb_n;
+      m = m_n;
+    };
+    load(0, zb, m, true);
+    const int64_t npairs = (nsteps + 1) / 2;
+    for (int64_t pr = 0; pr < npairs; ++pr) {
+      phase(0, 1);
+      phase(1, 0);
+    }
+  }
+  float* outp = a.partials + ((int64_t)s * a.T + t) * a.out_stride + q.out_off;
+  const bool full = (m0 + 32 * RB <= q.M) && (n0 + 64 <= q.N);  // wave-uniform: interior tiles store unpredicated
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int j = n0 + cb * 32 + li;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          outp[(int64_t)i * q.N + j] = acc[rb][cb][r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (i < q.M && j < q.N) outp[(int64_t)i * q.N + j] = acc[rb][cb][r];
+        }
+      }
+    }
+}
+
+}  // namespace nqa
+
+using namespace nqa;
+
+extern "C" {
+
+int32_t nqa_wgrad_splits(const void* instr_table, int32_t n_instr, int32_t n_types, int64_t num_rows) {
+  if (!instr_table || n_instr <= 0 || n_instr > kMaxWgradInstr || n_types < 1 || num_rows < 0) return NQA_ERR_INVALID;
+  const int32_t* tab = static_cast<const int32_t*>(instr_table);
+  int maxM = 0;
+  for (int i = 0; i < n_instr; ++i) maxM = tab[6 * i + 2] > maxM ? tab[6 * i + 2] : maxM;
+  const int RB = maxM <= 32 ? 1 : (maxM <= 64 ? 2 : 4);
+  int64_t tiles = 0;
+  for (int i = 0; i < n_instr; ++i) {
+    const int M = tab[6 * i + 2], N = tab[6 * i + 3];
+    tiles += (int64_t)((M + 32 * RB - 1) / (32 * RB)) * ((N + 63) / 64);
+  }
+  tiles *= n_types;
+  if (tiles <= 0) return NQA_ERR_INVALID;
+  // ~2 wavefronts per SIMD on 256 CUs, at least 64 rows per split
+  int64_t S = (2048 + tiles - 1) / tiles;
+  const int64_t max_s = (num_rows + 63) / 64;
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  return (int32_t)S;
+}
+
+int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64_t* row_types,
+              const void* instr_table, int32_t n_instr, int64_t lda, int64_t ldb, int64_t num_rows, int32_t n_types,
+              int64_t out_stride, int32_t splits, void* partials, nqa_stream stream) {
+  if (dtype != NQA_F32) {
+    set_error("nqa_wgrad: float32 only");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (!instr_table || n_instr <= 0 || n_instr > kMaxWgradInstr || n_types < 1 || (n_types > 1 && !row_types) ||
+      num_rows < 0 || splits < 1 || out_stride <= 0 || lda <= 0 || ldb <= 0 || lda > (1 << 24) || ldb > (1 << 24) || !partials || (num_rows > 0 && (!a_rows || !b_rows))) {
+    set_error("nqa_wgrad: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (num_rows == 0) {
+    if (hipMemsetAsync(partials, 0, sizeof(float) * (size_t)splits * n_types * out_stride, s) != hipSuccess) {
+      set_error("nqa_wgrad: memset failed");
+      return NQA_ERR_LAUNCH;
+    }
+    return NQA_OK;
+  }
+  WgradArgs a{};
+  a.A = static_cast<const float*>(a_rows);
+  a.B = static_cast<const float*>(b_rows);
+  a.types = n_types > 1 ? row_types : nullptr;
+  a.partials = static_cast<float*>(partials);
+  a.lda = lda;
+  a.ldb = ldb;
+  a.Z = num_rows;
+  a.out_stride = out_stride;
+  a.T = n_types;
+  a.S = splits;
+  a.n_instr = n_instr;
+  int64_t zc = (num_rows + splits - 1) / splits;
+  zc = (zc + 2 * kWgU - 1) / (2 * kWgU) * (2 * kWgU);
+  if (zc > 2147483647LL / 2) {
+    set_error("nqa_wgrad: split too long");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  a.zc = (int32_t)zc;
+  const int32_t* tab = static_cast<const int32_t*>(instr_table);
+  int maxM = 0;
+  for (int i = 0; i < n_instr; ++i) maxM = tab[6 * i + 2] > maxM ? tab[6 * i + 2] : maxM;
+  const int RB = maxM <= 32 ? 1 : (maxM <= 64 ? 2 : 4);
+  int64_t units = 0;
+  for (int i = 0; i < n_instr; ++i) {
+    WgradInstr& q = a.instr[i];
+    q.a_off = tab[6 * i + 0];
+    q.b_off = tab[6 * i + 1];
+    q.M = tab[6 * i + 2];
+    q.N = tab[6 * i + 3];
+    q.d = tab[6 * i + 4];
+    q.out_off = tab[6 * i + 5];
+    if (q.M <= 0 || q.N <= 0 || q.d <= 0 || q.a_off < 0 || q.b_off < 0 || q.out_off < 0 ||
+        (int64_t)q.out_off + (int64_t)q.M * q.N > out_stride || (int64_t)q.a_off + (int64_t)q.M * q.d > lda ||
+        (int64_t)q.b_off + (int64_t)q.N * q.d > ldb) {
+      set_error("nqa_wgrad: instruction outside its operand rows / the weight vector");
+      return NQA_ERR_INVALID;
+    }
+    q.mt = (q.M + 32 * RB - 1) / (32 * RB);
+    q.unit_begin = (int32_t)units;
+    units += (int64_t)n_types * splits * q.mt * ((q.N + 63) / 64);
+    if (units > 2147483647LL) {
+      set_error("nqa_wgrad: too many work units");
+      return NQA_ERR_UNSUPPORTED;
+    }
+  }
+  a.total_units = (int32_t)units;
+  const dim3 grid((unsigned)((units + 3) / 4));
+#define NQA_WGRAD_LAUNCH(R)                                                        \
+  if (a.types != nullptr)                                                          \
+    hipLaunchKernelGGL((wgrad_kernel<R, true>), grid, dim3(256), 0, s, a);         \
+  else                                                                             \
+    hipLaunchKernelGGL((wgrad_kernel<R, false>), grid, dim3(256), 0, s, a);
+  if (RB == 1) {
+    NQA_WGRAD_LAUNCH(1)
+  } else if (RB == 2) {
+    NQA_WGRAD_LAUNCH(2)
+  } else {
+    NQA_WGRAD_LAUNCH(4)
+  }
+#undef NQA_WGRAD_LAUNCH
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_wgrad: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@
 import torch
 
 from ..data import AtomicDataDict
+from ..utils.wgrad import inputs_only_backward
 from ._graph_mixin import GraphModuleMixin
 
 
@@ -27,7 +28,8 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
             edge_vectors = data[K.EDGE_VECTORS_KEY]
             edge_vectors.requires_grad_(True)
             data = self.func(data)
-            edge_forces = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vectors])[0]
+            with inputs_only_backward():
+                edge_forces = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vectors])[0]
             data[K.EDGE_FORCE_KEY] = edge_forces
             return data
 
@@ -68,9 +70,11 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
 
         data = self.func(data)
 
-        grads = torch.autograd.grad(
-            [data[K.TOTAL_ENERGY_KEY].sum()], [pos, data["_displacement"]], create_graph=self.training
-        )
+        # only data gradients are requested here: the Functions on the path skip their parameter-gradient outputs
+        with inputs_only_backward():
+            grads = torch.autograd.grad(
+                [data[K.TOTAL_ENERGY_KEY].sum()], [pos, data["_displacement"]], create_graph=self.training
+            )
         data[K.FORCE_KEY] = torch.neg(grads[0])
         virial = grads[1].view(num_batch, 3, 3)
         if has_cell:
@@ -111,7 +115,8 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         edge_vec.requires_grad_(True)
         data[K.EDGE_VECTORS_KEY] = edge_vec
         data = self.func(data)
-        g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].contiguous()
+        with inputs_only_backward():
+            g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].contiguous()
         num_nodes = pos.shape[0]
         topo = topology_cache.get(edge_index[0], edge_index[1], num_nodes)
         rp_d, eid_d, _ = topo.by_dst

@@ -4,6 +4,7 @@
 path: on the GPU it runs through the fused MFMA kernel of ``nequip_amd/csrc/radial_mlp.hip`` when available
 for its shape, otherwise through hipBLASLt ``mm``."""
 
+import os
 from math import sqrt
 from typing import Optional
 
@@ -19,8 +20,6 @@ from ._graph_mixin import GraphModuleMixin
 def radial_mlp_mode() -> int:
     """GEMM mode of the fused radial MLP: split-bf16 (fp32-accurate, default) or exact fp32 MFMA
     (``NQA_MLP_EXACT_FP32=1``)."""
-    import os
-
     return _lib.NQA_MLP_FP32 if os.environ.get("NQA_MLP_EXACT_FP32", "") not in ("", "0") else _lib.NQA_MLP_BF16X6
 
 
@@ -45,26 +44,100 @@ class _WeightImages:
         return self.images[(mode, backward)], hit
 
 
+def _launch_fwd(emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
+    """``silu(emb @ (w0 alpha0)) @ (w1 alpha1)`` in one fused MFMA launch (``nqa_radial_mlp_fwd``)."""
+    from ._topology import _ptr, current_stream_ptr
+
+    lib = _lib.load()
+    E, nb = emb.shape
+    H, W = w1.shape
+    out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
+    flops = 2.0 * E * (nb * H + H * W)
+    ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
+    ws, ready = cache.get(w1, mode, 0, ws_bytes)
+    with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):
+        rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
+                                    _ptr(out), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
+    _lib.check(rc, "nqa_radial_mlp_fwd")
+    return out
+
+
+def _launch_bwd(emb, w0, w1, alpha0: float, alpha1: float, g_w, mode: int, cache: _WeightImages):
+    """Gradient of the fused MLP w.r.t. the edge embedding (``nqa_radial_mlp_bwd``; hidden layer recomputed on chip)."""
+    from ._topology import _ptr, current_stream_ptr
+
+    lib = _lib.load()
+    E, nb = emb.shape
+    H, W = w1.shape
+    g_emb = torch.empty_like(emb)
+    flops = 2.0 * E * (nb * H * 2 + H * W)
+    ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
+    ws, ready = cache.get(w1, mode, 1, ws_bytes)
+    with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
+        rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, _ptr(g_w), nb, H,
+                                    W, E, _ptr(g_emb), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
+    _lib.check(rc, "nqa_radial_mlp_bwd")
+    return g_emb
+
+
+def _launch_bwd_train(emb, w0, w1, alpha0: float, alpha1: float, g_w, cot, mode: int, cache: _WeightImages):
+    """``nqa_radial_mlp_bwd_train``: the embedding-side gradient plus the on-chip pieces of the parameter gradients.
+    ``cot is None``: (g_emb, silu(P), dW0 / alpha0); second order (``cot`` = cotangent of g_emb): (d<cot,g_emb>/d emb,
+    Q silu'(P), d<cot,g_emb>/dW0 / alpha0) -- see include/nequip_amd.h."""
+    from ._topology import _ptr, current_stream_ptr
+
+    lib = _lib.load()
+    E, nb = emb.shape
+    H, W = w1.shape
+    g_emb = torch.empty_like(emb)
+    hid = torch.empty((E, H), dtype=emb.dtype, device=emb.device)
+    tiles = lib.nqa_radial_mlp_train_tiles(E)
+    parts = torch.empty((tiles, nb, H), dtype=emb.dtype, device=emb.device)
+    flops = 2.0 * E * (nb * H * (3 if cot is None else 5) + H * W)
+    ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
+    ws, ready = cache.get(w1, mode, 1, ws_bytes)
+    with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd_train", 4.0 * E * (3 * nb + W + H), flops):
+        rc = lib.nqa_radial_mlp_bwd_train(_lib.NQA_F32, mode, _ptr(emb), _ptr(cot), _ptr(w0), alpha0, _ptr(w1), alpha1,
+                                          _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(hid), _ptr(parts), _ptr(ws),
+                                          ws_bytes, int(ready), current_stream_ptr(emb.device))
+    _lib.check(rc, "nqa_radial_mlp_bwd_train")
+    return g_emb, hid, parts.sum(0)
+
+
+def _launch_fwd_tangent(emb, cot, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
+    """``((cot W0) silu'(emb W0)) W1`` (``nqa_radial_mlp_fwd_tangent``): gradient of <cot, g_emb> w.r.t. grad_out."""
+    from ._topology import _ptr, current_stream_ptr
+
+    lib = _lib.load()
+    E, nb = emb.shape
+    H, W = w1.shape
+    out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
+    ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
+    ws, ready = cache.get(w1, mode, 0, ws_bytes)
+    with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (2 * nb + W), 2.0 * E * (2 * nb * H + H * W)):
+        rc = lib.nqa_radial_mlp_fwd_tangent(_lib.NQA_F32, mode, _ptr(emb), _ptr(cot), _ptr(w0), alpha0, _ptr(w1),
+                                            alpha1, nb, H, W, E, _ptr(out), _ptr(ws), ws_bytes, int(ready),
+                                            current_stream_ptr(emb.device))
+    _lib.check(rc, "nqa_radial_mlp_fwd_tangent")
+    return out
+
+
+def _launch_wgrad(a, b):
+    """``a^T b`` reduced over the edge rows (``nqa_wgrad``): [E, M], [E, N] -> [M, N]."""
+    from ..utils import wgrad as _wg
+
+    M, N = a.shape[1], b.shape[1]
+    return _wg.wgrad(a, b, _wg.WgradTable([(0, 0, M, N, 1, 0)], M * N)).view(M, N)
+
+
 class _RadialMLPFn(torch.autograd.Function):
     """Fused two-layer radial MLP on the matrix cores (``nqa_radial_mlp_fwd/bwd``); inference path: differentiable
     w.r.t. the edge embedding only (that is what the force backward needs)."""
 
     @staticmethod
     def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
-        from ._topology import _ptr, current_stream_ptr
-
-        lib = _lib.load()
         emb = emb.contiguous()
-        E, nb = emb.shape
-        H, W = w1.shape
-        out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
-        flops = 2.0 * E * (nb * H + H * W)
-        ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
-        ws, ready = cache.get(w1, mode, 0, ws_bytes)
-        with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):
-            rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
-                                        _ptr(out), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
-        _lib.check(rc, "nqa_radial_mlp_fwd")
+        out = _launch_fwd(emb, w0, w1, alpha0, alpha1, mode, cache)
         ctx.save_for_backward(emb, w0, w1)
         ctx.alphas = (alpha0, alpha1)
         ctx.mode, ctx.cache = mode, cache
@@ -73,23 +146,105 @@ class _RadialMLPFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_w):
-        from ._topology import _ptr, current_stream_ptr
-
         emb, w0, w1 = ctx.saved_tensors
-        lib = _lib.load()
-        g_w = g_w.contiguous()
-        E, nb = emb.shape
-        H, W = w1.shape
-        g_emb = torch.empty_like(emb)
-        flops = 2.0 * E * (nb * H * 2 + H * W)
-        ws_bytes = lib.nqa_radial_mlp_workspace_bytes(ctx.mode, 1, H, W)
-        ws, ready = ctx.cache.get(w1, ctx.mode, 1, ws_bytes)
-        with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
-            rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, ctx.mode, _ptr(emb), _ptr(w0), ctx.alphas[0], _ptr(w1),
-                                        ctx.alphas[1], _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes,
-                                        int(ready), current_stream_ptr(emb.device))
-        _lib.check(rc, "nqa_radial_mlp_bwd")
+        g_emb = _launch_bwd(emb, w0, w1, ctx.alphas[0], ctx.alphas[1], g_w.contiguous(), ctx.mode, ctx.cache)
         return g_emb, None, None, None, None, None, None
+
+
+def _silu_derivs(p):
+    """silu'(p), silu''(p)."""
+    sig = torch.sigmoid(p)
+    one_m = 1.0 - sig
+    return sig * (1.0 + p * one_m), sig * one_m * (2.0 + p * (1.0 - 2.0 * sig))
+
+
+class _RadialMLPTrainFn(torch.autograd.Function):
+    """Training-mode radial MLP ``(emb, w0, w1) -> silu(emb W0) W1`` (``W_i = w_i alpha_i``): the same fused forward
+    kernel as inference; its backward is ``_RadialMLPTrainBwdFn`` so that force-matching training
+    (``nequip/nn/grad_output.py:220``, ``create_graph=True``) can differentiate the force pass once more."""
+
+    @staticmethod
+    def forward(ctx, emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
+        emb = emb.contiguous()
+        out = _launch_fwd(emb, w0.detach(), w1.detach(), alpha0, alpha1, mode, cache)
+        ctx.save_for_backward(emb, w0, w1)
+        ctx.args = (alpha0, alpha1, mode, cache)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, w0, w1 = ctx.saved_tensors
+        g_emb, g_w0, g_w1 = _RadialMLPTrainBwdFn.apply(emb, w0, w1, g, *ctx.args)
+        return g_emb, g_w0, g_w1, None, None, None, None
+
+
+class _RadialMLPTrainBwdFn(torch.autograd.Function):
+    """``(emb, w0, w1, g) -> (g_emb, g_w0, g_w1)``, the vector-Jacobian product of the MLP, itself differentiable once
+    (second order of force matching).  With P = emb W0, h = silu(P), G_h = g W1^T, G_P = G_h silu'(P):
+    ``g_emb = G_P W0^T``, ``g_W0 = emb^T G_P`` (both inside the fused kernel: ``nqa_radial_mlp_bwd_train``),
+    ``g_W1 = h^T g`` (split-K ``nqa_wgrad`` on the kernel's ``h``).  Parameter gradients are skipped when the caller
+    only wants data gradients (``utils/wgrad.py``).  Its own backward, for a cotangent c of g_emb and Q = c W0:
+    d emb = (Q G_h silu''(P)) W0^T, dW0 (same launch, second-order mode), dW1 = (Q silu'(P))^T g (``nqa_wgrad``),
+    d g = (Q silu'(P)) W1 (``nqa_radial_mlp_fwd_tangent``).  The exact-fp32 GEMM mode (``NQA_MLP_EXACT_FP32``) has no
+    training epilogues: there the pieces are composed from ATen ops around the first-order kernels."""
+
+    @staticmethod
+    def forward(ctx, emb, w0, w1, g, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
+        from ..utils import wgrad as _wg
+
+        g = g.contiguous()
+        w0d, w1d = w0.detach(), w1.detach()
+        g_w0 = g_w1 = None
+        want_params = _wg.param_grads_wanted() and (w0.requires_grad or w1.requires_grad)
+        if not want_params:
+            g_emb = _launch_bwd(emb, w0d, w1d, alpha0, alpha1, g, mode, cache)
+        elif mode == _lib.NQA_MLP_BF16X6:
+            g_emb, h, p0 = _launch_bwd_train(emb, w0d, w1d, alpha0, alpha1, g, None, mode, cache)
+            g_w0 = p0 * alpha0
+            g_w1 = _launch_wgrad(h, g) * alpha1
+        else:
+            g_emb = _launch_bwd(emb, w0d, w1d, alpha0, alpha1, g, mode, cache)
+            P = emb @ (w0d * alpha0)
+            s1, _ = _silu_derivs(P)
+            g_w1 = _launch_wgrad(P * torch.sigmoid(P), g) * alpha1
+            g_w0 = _launch_wgrad(emb, (g @ (w1d * alpha1).t()) * s1) * alpha0
+        ctx.save_for_backward(emb, w0, w1, g)
+        ctx.args = (alpha0, alpha1, mode, cache)
+        ctx.mark_non_differentiable(*[t for t in (g_w0, g_w1) if t is not None])
+        return g_emb, g_w0, g_w1
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, c, c_w0, c_w1):
+        # cotangent c of g_emb only (parameter gradients are leaves of the training step, nobody differentiates them)
+        emb, w0, w1, g = ctx.saved_tensors
+        alpha0, alpha1, mode, cache = ctx.args
+        w0d, w1d = w0.detach(), w1.detach()
+        c = c.contiguous()
+        need_emb, need_w0, need_w1, need_g = ctx.needs_input_grad[:4]
+        d_emb = d_w0 = d_w1 = d_g = None
+        if mode == _lib.NQA_MLP_BF16X6:
+            if need_emb or need_w0 or need_w1:
+                d_emb, R, p0 = _launch_bwd_train(emb, w0d, w1d, alpha0, alpha1, g, c, mode, cache)
+                d_w0 = p0 * alpha0 if need_w0 else None
+                d_w1 = _launch_wgrad(R, g) * alpha1 if need_w1 else None
+            if need_g:
+                d_g = _launch_fwd_tangent(emb, c, w0d, w1d, alpha0, alpha1, mode, cache)
+            return d_emb, d_w0, d_w1, d_g, None, None, None, None
+        W0, W1 = w0d * alpha0, w1d * alpha1
+        P = emb @ W0
+        s1, s2 = _silu_derivs(P)
+        Q = c @ W0
+        R = Q * s1
+        G_h = g @ W1.t()
+        cotP = Q * G_h * s2
+        d_emb = cotP @ W0.t() if need_emb else None
+        d_g = R @ W1 if need_g else None
+        if need_w1:
+            d_w1 = _launch_wgrad(R, g) * alpha1
+        if need_w0:
+            d_w0 = (_launch_wgrad(emb, cotP) + _launch_wgrad(c, G_h * s1)) * alpha0
+        return d_emb, d_w0, d_w1, d_g, None, None, None, None
 
 
 class ScalarLinearLayer(torch.nn.Module):
@@ -137,7 +292,7 @@ class ScalarMLPFunction(torch.nn.Module):
         self.mlp = mlp
 
     def _fused_ok(self, x: torch.Tensor) -> bool:
-        if self.training or not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear:
+        if not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear:
             return False
         ok = getattr(self, "_fused_supported", None)
         if ok is None:
@@ -148,16 +303,20 @@ class ScalarMLPFunction(torch.nn.Module):
         return ok
 
     def forward(self, x):
-        # inference on the GPU: one fused MFMA kernel (hidden layer stays on chip); training keeps the
-        # mm/SiLU formulation so that parameter gradients and double backward come from autograd
+        # GPU, float32, two layers of a supported shape: fused MFMA kernels (the hidden layer stays on chip).  Eval mode:
+        # weights are constants (inference Function, gradient w.r.t. the embedding only).  Training: the same kernels
+        # inside a twice-differentiable Function pair that also produces the parameter gradients.
         if self._fused_ok(x):
             cache = getattr(self, "_weight_images", None)
             if cache is None:
                 cache = self._weight_images = _WeightImages()
-            # (the fused path only runs in eval mode: weights are constants there, as for o3.Linear)
             cache.validate(self.mlp[2].weight)
-            return _RadialMLPFn.apply(x, self.mlp[0].weight.detach(), self.mlp[2].weight.detach(), self._alphas[0],
-                                      self._alphas[1], radial_mlp_mode(), cache)
+            if self.training and os.environ.get("NQA_MLP_TRAIN_ATEN", "") in ("", "0"):
+                return _RadialMLPTrainFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0],
+                                               self._alphas[1], radial_mlp_mode(), cache)
+            if not self.training:
+                return _RadialMLPFn.apply(x, self.mlp[0].weight.detach(), self.mlp[2].weight.detach(),
+                                          self._alphas[0], self._alphas[1], radial_mlp_mode(), cache)
         return self.mlp(x)
 
 

@@ -18,6 +18,7 @@ import torch
 
 from .. import _lib
 from ..utils import ktimer
+from ..utils import wgrad as _wgrad
 from .irreps import Irreps
 
 
@@ -82,6 +83,17 @@ class NodeLinearMeta:
                                  ctypes.create_string_buffer(ib, max(len(ib), 1)), len(instr))
         return self._host[which]
 
+    def wgrad_table(self) -> "_wgrad.WgradTable":
+        """Records of ``nqa_wgrad`` for the packed forward weights: A = input rows, B = output-gradient rows."""
+        if getattr(self, "_wgrad_table", None) is None:
+            in_off, out_off = self.irreps_in.offsets(), self.irreps_out.offsets()
+            recs = []
+            for (i, o), off in zip(self.instructions, self.w_off):
+                mi, ir = self.irreps_in[i]
+                recs.append((in_off[i], out_off[o], mi, self.irreps_out[o].mul, ir.dim, off))
+            self._wgrad_table = _wgrad.WgradTable(recs, self.wstride)
+        return self._wgrad_table
+
     def transpose_weights(self, wp: torch.Tensor) -> torch.Tensor:
         """[T, wstride] packed forward weights -> packed transposed weights with the same offsets."""
         T = wp.shape[0]
@@ -129,8 +141,10 @@ class _NodeLinearFn(torch.autograd.Function):
         gx = gwp = gadd = None
         if ctx.needs_input_grad[0]:
             gx = _NodeLinearFn.apply(g, meta_transposed_weights(meta, wp), None, types, _transposed(meta), ctx.scale)
-        if ctx.needs_input_grad[1]:
-            gwp = _weight_grad(x, g, types, meta, wp.shape[0]) * ctx.scale
+        if ctx.needs_input_grad[1] and _wgrad.param_grads_wanted():
+            gwp = _weight_grad(x, g, types, meta, wp.shape[0])
+            if ctx.scale != 1.0:
+                gwp = gwp * ctx.scale
         if ctx.has_addend and ctx.needs_input_grad[2]:
             gadd = g
         return gx, gwp, gadd, None, None, None
@@ -161,7 +175,12 @@ def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Ten
 
 
 def _weight_grad(x, g, types, meta: NodeLinearMeta, T: int):
-    """d/dWp of sum(out * g): per instruction  gW[t, u, w] = sum_{z: type z = t} sum_m x[z,u,m] g[z,w,m]."""
+    """d/dWp of sum(out * g): per instruction  gW[t, u, w] = sum_{z: type z = t} sum_m x[z,u,m] g[z,w,m].
+
+    First-order training backward (no graph requested), float32: one ``nqa_wgrad`` launch for all instructions and atom
+    types; otherwise (float64, or a differentiable result is asked for) the einsum formulation below."""
+    if not torch.is_grad_enabled() and _wgrad.supported(x, g):
+        return _wgrad.wgrad(x, g.contiguous(), meta.wgrad_table(), types, T)
     Z = x.shape[0]
     in_off, out_off = meta.irreps_in.offsets(), meta.irreps_out.offsets()
     parts = []

@@ -82,14 +82,64 @@ def test_radial_mlp_split_bf16_has_fp32_accuracy(device, monkeypatch):
     assert errs["bf16x6"][1] < 3 * max(errs["fp32"][1], gerr_cpu)
 
 
+def _force_matching_loss(mlp_fn, emb, v, f_t):
+    out = mlp_fn(emb)
+    (force,) = torch.autograd.grad((out * v).sum(), emb, create_graph=True)
+    return (force - f_t).square().sum() + out.square().sum() / max(1, out.numel())
+
+
 @pytest.mark.gpu
-def test_radial_mlp_training_mode_uses_autograd_path(device):
-    """In training mode parameter gradients must exist (mm/SiLU formulation, not the inference kernel)."""
+@pytest.mark.parametrize("E,H,W", [(1000, 128, 192), (4133, 128, 704), (77, 64, 64), (0, 128, 192)])
+def test_radial_mlp_training_mode_second_order(device, mlp_mode, E, H, W):
+    """Training mode: fused kernels inside the twice-differentiable Function pair.  Parameter and input gradients of a
+    force-matching style loss (first derivative inside the loss) against float64 autograd of the oracle's restatement."""
+    from nequip_amd.nn.mlp import ScalarMLPFunction, _RadialMLPTrainFn
+
+    torch.manual_seed(E + W)
+    mlp = ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=1, hidden_layers_width=H).train()
+    emb = torch.randn(E, 8) * 0.7
+    v, f_t = torch.randn(E, W), torch.randn(E, 8)
+
+    w_ref = [mlp.mlp[0].weight.detach().double().requires_grad_(True),
+             mlp.mlp[2].weight.detach().double().requires_grad_(True)]
+    e_ref = emb.double().requires_grad_(True)
+    loss_ref = _force_matching_loss(lambda e: onn.scalar_mlp(e, w_ref, "silu"), e_ref, v.double(), f_t.double())
+    g_ref = torch.autograd.grad(loss_ref, [e_ref] + w_ref)
+
+    mlp = mlp.to(device)
+    e_dev = emb.to(device).requires_grad_(True)
+    assert mlp._fused_ok(e_dev)
+    seen = []
+    orig = _RadialMLPTrainFn.forward
+    try:
+        _RadialMLPTrainFn.forward = staticmethod(lambda *a, **k: (seen.append(1), orig(*a, **k))[1])
+        loss = _force_matching_loss(mlp, e_dev, v.to(device), f_t.to(device))
+    finally:
+        _RadialMLPTrainFn.forward = staticmethod(orig)
+    assert seen, "training mode must run the fused Function pair for this shape"
+    loss.backward()
+    got = [e_dev.grad, mlp.mlp[0].weight.grad, mlp.mlp[2].weight.grad]
+    torch.testing.assert_close(loss.detach().cpu().double(), loss_ref.detach(), atol=1e-4 * max(1.0, float(loss_ref)), rtol=1e-4)
+    for r, g in zip(g_ref, got):
+        assert g is not None
+        torch.testing.assert_close(g.cpu().double(), r, atol=2e-4 * max(1e-6, float(r.abs().max())) if r.numel() else 0.0,
+                                   rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_radial_mlp_training_aten_switch(device, monkeypatch):
+    """NQA_MLP_TRAIN_ATEN=1 keeps the mm/SiLU formulation in training mode (debugging switch); both give parameter
+    gradients."""
     from nequip_amd.nn.mlp import ScalarMLPFunction
 
     mlp = ScalarMLPFunction(input_dim=8, output_dim=192, hidden_layers_depth=1, hidden_layers_width=128).to(device)
     mlp.train()
     x = torch.randn(300, 8, device=device)
-    assert not mlp._fused_ok(x)
     mlp(x).square().sum().backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mlp.parameters())
+    fused = [p.grad.clone() for p in mlp.parameters()]
+    monkeypatch.setenv("NQA_MLP_TRAIN_ATEN", "1")
+    mlp.zero_grad()
+    mlp(x).square().sum().backward()
+    for a, b in zip(fused, [p.grad for p in mlp.parameters()]):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, atol=1e-4 * float(b.abs().max()), rtol=1e-3)
