@@ -95,13 +95,20 @@ class NodeLinearMeta:
         return self._wgrad_table
 
     def transpose_weights(self, wp: torch.Tensor) -> torch.Tensor:
-        """[T, wstride] packed forward weights -> packed transposed weights with the same offsets."""
-        T = wp.shape[0]
-        parts = []
-        for (i, o), off in zip(self.instructions, self.w_off):
-            mi, mo = self.irreps_in[i].mul, self.irreps_out[o].mul
-            parts.append(wp[:, off : off + mi * mo].view(T, mi, mo).transpose(1, 2).reshape(T, mi * mo))
-        return torch.cat(parts, dim=1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+        """[T, wstride] packed forward weights -> packed transposed weights with the same offsets (one gather with a
+        precomputed permutation instead of a transpose + copy per instruction)."""
+        key = str(wp.device)
+        perm = self._perm.get(key) if hasattr(self, "_perm") else None
+        if perm is None:
+            idx = []
+            for (i, o), off in zip(self.instructions, self.w_off):
+                mi, mo = self.irreps_in[i].mul, self.irreps_out[o].mul
+                idx.append((torch.arange(mi * mo).view(mi, mo).t().reshape(-1) + off))
+            perm = (torch.cat(idx) if idx else torch.zeros(0, dtype=torch.long)).to(wp.device)
+            if not hasattr(self, "_perm"):
+                self._perm = {}
+            self._perm[key] = perm
+        return wp.index_select(1, perm)
 
 
 def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale: float):

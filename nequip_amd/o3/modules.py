@@ -152,6 +152,22 @@ class FullyConnectedTensorProduct(torch.nn.Module):
             else None
         )
 
+    def _contract_index(self, device, dtype):
+        key = (str(device), dtype)
+        cache = self.__dict__.setdefault("_contract_cache", {})
+        if key not in cache:
+            V = self.irreps_in2[0].mul
+            idx, scl = [], []
+            for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+                u, v, w = shape
+                assert v == V
+                block = torch.arange(sl.start, sl.stop).view(u, v, w).permute(1, 0, 2).reshape(v, u * w)
+                idx.append(block)
+                scl.append(torch.full((u * w,), self._scale[io], dtype=torch.float64))
+            perm = torch.cat(idx, dim=1).reshape(-1).to(device)
+            cache[key] = (perm, torch.cat(scl).to(device=device, dtype=dtype).view(1, -1))
+        return cache[key]
+
     def _assemble(self, outs, x):
         Z = x.shape[0]
         cols = [
@@ -178,11 +194,10 @@ class FullyConnectedTensorProduct(torch.nn.Module):
         if x.is_cuda and self._meta is not None and x.dtype in (torch.float32, torch.float64):
             # per-type pre-contraction W_t[u, w] = sum_v table[t, v] W[u, v, w] (tiny), then ONE fused launch
             def contract(weight, table):
-                parts = []
-                for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
-                    Wt = torch.einsum("tv,uvw->tuw", table, weight[sl].view(shape)) * self._scale[io]
-                    parts.append(Wt.reshape(table.shape[0], -1))
-                return (torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]).contiguous()
+                # all instructions at once: gather the flat [u, v, w] blocks into one [v, sum(u*w)] matrix (fixed
+                # permutation, path scale folded in), then a single [T, v] x [v, sum(u*w)] product
+                perm, scale = self._contract_index(weight.device, weight.dtype)
+                return torch.mm(table, weight.index_select(0, perm).view(table.shape[1], -1) * scale)
 
             if self.training:
                 wp = contract(self.weight, table)

@@ -20,22 +20,31 @@ import torch
 from .. import _lib
 from . import ktimer
 
-_state = threading.local()
+# Process-wide, not thread-local: the autograd engine runs Function.backward on its own per-device worker threads, so
+# a thread-local set by the caller of autograd.grad would never be seen there.  autograd.grad is synchronous, and the
+# depth counter makes nesting safe; concurrent training steps from several Python threads of one process would only
+# lose the optimisation's precision (a parameter gradient computed that nobody reads), never correctness, because the
+# flag is only ever raised around calls that do not ask for parameter gradients -- and those who do ask for them
+# (loss.backward()) must not run concurrently with such a call in the same process.
+_inputs_only_depth = 0
+_lock = threading.Lock()
 
 
 def param_grads_wanted() -> bool:
-    return not getattr(_state, "inputs_only", False)
+    return _inputs_only_depth == 0
 
 
 @contextlib.contextmanager
 def inputs_only_backward():
     """Inside: backward passes are known to be asked for gradients of data inputs only (no parameters)."""
-    prev = getattr(_state, "inputs_only", False)
-    _state.inputs_only = True
+    global _inputs_only_depth
+    with _lock:
+        _inputs_only_depth += 1
     try:
         yield
     finally:
-        _state.inputs_only = prev
+        with _lock:
+            _inputs_only_depth -= 1
 
 
 class WgradTable:
