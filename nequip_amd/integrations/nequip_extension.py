@@ -36,6 +36,10 @@ def make_modifier(base_cls):
         if not torch.cuda.is_available() or torch.version.hip is None:
             raise RuntimeError("enable_NequipAMD requires a ROCm build of PyTorch and an AMD GPU")
 
+        # compiled graph models (nequip-compile / the LAMMPS wrapper set this flag, nequip/nn/_tp_scatter_base.py:60,69)
+        # get the dispatcher-op form of the kernels, which make_fx / torch.compile can trace
+        use_ops = bool(getattr(model, "is_compile_graph_model", False))
+
         def factory(old):
             prev = torch.get_default_dtype()
             torch.set_default_dtype(old.model_dtype)
@@ -45,6 +49,7 @@ def make_modifier(base_cls):
                     irreps_edge_attr=old.irreps_edge_attr,
                     irreps_mid=old.irreps_mid,
                     instructions=old.instructions,
+                    use_dispatcher_ops=use_ops,
                 )
             finally:
                 torch.set_default_dtype(prev)

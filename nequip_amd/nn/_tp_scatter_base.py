@@ -238,8 +238,13 @@ class TensorProductScatter(torch.nn.Module):
 
     _nequip_custom_ops_libs = ("nequip_amd",)
 
-    def __init__(self, feature_irreps_in, irreps_edge_attr, irreps_mid, instructions) -> None:
+    def __init__(self, feature_irreps_in, irreps_edge_attr, irreps_mid, instructions,
+                 use_dispatcher_ops: bool = False) -> None:
         super().__init__()
+        # True: always go through torch.ops.nequip_amd.tp_scatter_* (the opaque, traceable form; cf. `use_opaque` of the
+        # reference's OpenEquivariance adapter, nequip/nn/_tp_scatter_oeq.py:13).  While a compiler is tracing the
+        # module that form is selected automatically.
+        self.use_dispatcher_ops = bool(use_dispatcher_ops)
         # keep the caller's objects (e3nn Irreps when used under nequip) for introspection, and our own
         # e3nn-free copies for the plan
         self.feature_irreps_in = feature_irreps_in
@@ -256,6 +261,9 @@ class TensorProductScatter(torch.nn.Module):
         )
         self.model_dtype = torch.get_default_dtype()
 
+        from ._tp_scatter_ops import plan_key
+
+        self._plan_key = plan_key(irreps_in1, irreps_in2, irreps_out, self.tp.instructions)
         self._plan = NativePlan(irreps_in1, irreps_in2, irreps_out, self.tp.instructions)
         # device image of the path tables: a non-persistent buffer so it follows .to(device) and never
         # enters the state dict (the reference module owns no persistent state of its own)
@@ -280,6 +288,10 @@ class TensorProductScatter(torch.nn.Module):
         x = x.to(self.model_dtype)
         edge_attr = edge_attr.to(self.model_dtype)
         edge_weight = edge_weight.to(self.model_dtype)
+        if self.use_dispatcher_ops or torch.compiler.is_compiling():
+            from ._tp_scatter_ops import tp_scatter
+
+            return tp_scatter(x, edge_attr, edge_weight, edge_dst, edge_src, self._plan_key)
         if topology is None:
             topology = topology_cache.get(edge_dst, edge_src, x.size(0))
         return _TPScatterFn.apply(x, edge_attr, edge_weight, self._get_kernels(), topology)
