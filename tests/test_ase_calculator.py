@@ -1,0 +1,77 @@
+"""ASE-style calculator (nequip_amd/integrations/ase.py, mirror of nequip/integrations/ase.py:13-160): same results keys
+and units as the reference's calculator, graph built on the device.  ASE is not installed here: a stand-in object with
+the `Atoms` accessors the calculator uses plays its role (with ASE installed the very same calls hit a real Atoms)."""
+import numpy as np
+import pytest
+import torch
+
+from nequip_amd.integrations.ase import NequIPCalculator, full_3x3_to_voigt_6_stress
+
+
+class FakeAtoms:
+    def __init__(self, symbols, positions, cell=None, pbc=False):
+        self._s, self._p = list(symbols), np.asarray(positions, dtype=np.float64)
+        self._c = np.zeros((3, 3)) if cell is None else np.asarray(cell, dtype=np.float64)
+        self._pbc = np.array([pbc] * 3 if isinstance(pbc, bool) else pbc, dtype=bool)
+
+    def get_chemical_symbols(self):
+        return self._s
+
+    def get_positions(self):
+        return self._p
+
+    def get_cell(self):
+        return self._c
+
+    def get_pbc(self):
+        return self._pbc
+
+    def __len__(self):
+        return len(self._s)
+
+
+def test_voigt_order_and_symmetrisation():
+    s = np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0], [7.0, 8.0, 9.0]])
+    np.testing.assert_allclose(full_3x3_to_voigt_6_stress(s), [1.0, 5.0, 9.0, 7.0, 5.0, 3.0])
+
+
+def test_calculator_is_gpu_only_and_wants_eval_mode():
+    model = torch.nn.Linear(1, 1)
+    model.type_names = ["H"]
+    with pytest.raises(AssertionError):
+        NequIPCalculator(model.train(), "cuda", r_max=4.0)
+    with pytest.raises(RuntimeError):
+        NequIPCalculator(model.eval(), "cpu", r_max=4.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodic", [True, False])
+def test_calculator_matches_direct_model_call(device, periodic):
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=3)
+    model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.0, type_names=names, num_layers=2, l_max=2,
+                           parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=64,
+                           avg_num_neighbors=20.0).to(device).eval()
+    data = syn.make_data(pos, types, 4.0, cell if periodic else None, pbc=periodic)
+    ref = model(AtomicDataDict.to_device(data, device))
+
+    atoms = FakeAtoms([names[t] for t in types], pos, cell if periodic else None, pbc=periodic)
+    calc = NequIPCalculator(model, device, r_max=4.0, energy_units_to_eV=2.0, length_units_to_A=0.5)
+    e = calc.get_potential_energy(atoms)
+    f = calc.get_forces(atoms)
+    assert set(calc.results) >= {"energy", "free_energy", "energies", "forces"}
+    np.testing.assert_allclose(e, 2.0 * float(ref["total_energy"]), rtol=2e-5, atol=2e-5 * len(pos))
+    fr = ref["forces"].cpu().numpy() * (2.0 / 0.5)
+    np.testing.assert_allclose(f, fr, rtol=0, atol=2e-4 * max(1.0, np.abs(fr).max()))
+    np.testing.assert_allclose(calc.results["energies"].sum(), e, rtol=1e-5, atol=1e-4)
+    if periodic:
+        s = calc.get_stress(atoms)
+        sr = full_3x3_to_voigt_6_stress(ref["stress"].cpu().numpy().reshape(3, 3)) * (2.0 / 0.5**3)
+        np.testing.assert_allclose(s, sr, rtol=0, atol=2e-4 * max(1e-3, np.abs(sr).max()))
+    else:
+        assert "stress" not in calc.results
+    with pytest.raises(ValueError):
+        calc.calculate(FakeAtoms(["Xx"] * 3, pos[:3]))
