@@ -207,9 +207,9 @@ def _emit(st: Structure) -> str:
     else:
         L.extend(["  T wvA[kNP];"] + decl_x("  ", "A") + decl_y("  ", "A"))
 
-    def fwd_loads(sfx, e, sv):
+    def fwd_loads(sfx, e, sv, r):
         out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
-               f"      const T* __restrict__ wr = a.w + (int64_t){e} * a.wn;",
+               f"      const T* __restrict__ wr = a.w + (int64_t){r} * a.wn;",
                f"      const T* __restrict__ yr = a.y + (int64_t){e} * kS;"]
         out += load_w("      ", "wr", sfx=sfx, decl=False)
         out += load_x("      ", "xr", sfx=sfx, decl=False)
@@ -231,40 +231,40 @@ def _emit(st: Structure) -> str:
     if pipelined:
         A("  int idx = beg + wsub;")
         A("  int nidx = idx + WPN;")
-        A("  int e0 = 0, s0 = 0, e1 = 0, s1 = 0;")
-        A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); }")
+        A("  int e0 = 0, s0 = 0, e1 = 0, s1 = 0, r0 = 0, r1 = 0;  // r: row of the edge's weights (tp_spec.h spec_wrow)")
+        A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); r0 = spec_wrow(a, idx); }")
         A("  if (idx < end) {")
-        L.extend(fwd_loads("A", "e0", "s0"))
+        L.extend(fwd_loads("A", "e0", "s0", "r0"))
         A("  }")
-        A("  if (nidx < end) { e1 = spec_uniform(a.eid[nidx]); s1 = spec_uniform(a.nbr[nidx]); }")
+        A("  if (nidx < end) { e1 = spec_uniform(a.eid[nidx]); s1 = spec_uniform(a.nbr[nidx]); r1 = spec_wrow(a, nidx); }")
         A("  while (idx < end) {")
         A("    if (nidx < end) {")
-        L.extend(fwd_loads("B", "e1", "s1"))
+        L.extend(fwd_loads("B", "e1", "s1", "r1"))
         A("    }")
         A("    int nn = nidx + WPN;")
-        A("    if (nn < end) { e0 = spec_uniform(a.eid[nn]); s0 = spec_uniform(a.nbr[nn]); }")
+        A("    if (nn < end) { e0 = spec_uniform(a.eid[nn]); s0 = spec_uniform(a.nbr[nn]); r0 = spec_wrow(a, nn); }")
         L.extend(fwd_compute("A"))
         A("    idx = nidx; nidx = nn;")
         A("    if (idx >= end) break;")
         A("    if (nidx < end) {")
-        L.extend(fwd_loads("A", "e0", "s0"))
+        L.extend(fwd_loads("A", "e0", "s0", "r0"))
         A("    }")
         A("    nn = nidx + WPN;")
-        A("    if (nn < end) { e1 = spec_uniform(a.eid[nn]); s1 = spec_uniform(a.nbr[nn]); }")
+        A("    if (nn < end) { e1 = spec_uniform(a.eid[nn]); s1 = spec_uniform(a.nbr[nn]); r1 = spec_wrow(a, nn); }")
         L.extend(fwd_compute("B"))
         A("    idx = nidx; nidx = nn;")
         A("  }")
     else:
         A("  int idx = beg + wsub;")
-        A("  int e0 = 0, s0 = 0;")
-        A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); }")
+        A("  int e0 = 0, s0 = 0, r0 = 0;")
+        A("  if (idx < end) { e0 = spec_uniform(a.eid[idx]); s0 = spec_uniform(a.nbr[idx]); r0 = spec_wrow(a, idx); }")
         A("  while (idx < end) {")
         A("    const int nidx = idx + WPN;")
-        A("    int e_n = 0, s_n = 0;")
-        A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); }")
-        L.extend(fwd_loads("A", "e0", "s0"))
+        A("    int e_n = 0, s_n = 0, r_n = 0;")
+        A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); r_n = spec_wrow(a, nidx); }")
+        L.extend(fwd_loads("A", "e0", "s0", "r0"))
         L.extend(fwd_compute("A"))
-        A("    idx = nidx; e0 = e_n; s0 = s_n;")
+        A("    idx = nidx; e0 = e_n; s0 = s_n; r0 = r_n;")
         A("  }")
     # scale by path coefficient: slots shared by several instructions have equal coeff per slot (same l3, same n_into)
     slot_coeff = [None] * NS
@@ -330,13 +330,14 @@ def _emit(st: Structure) -> str:
     L.extend(lane_offsets("  "))
     A("  int idx = beg + wsub;")
     A("  int e = spec_uniform(a.eid[idx]), s = spec_uniform(a.nbr[idx]);")
+    A("  int rg = spec_gwrow(a, idx);  // row of grad_w written by this edge; its weights are row spec_wrow_of(a, rg)")
     A("  while (idx < end) {")
     A("    const int nidx = idx + WPN;")
-    A("    int e_n = 0, s_n = 0;")
-    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); }")
+    A("    int e_n = 0, s_n = 0, rg_n = 0;")
+    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); rg_n = spec_gwrow(a, nidx); }")
     A("    const T* __restrict__ xr = a.x + (int64_t)s * a.din;")
     A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
-    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn;")
+    A("    const T* __restrict__ wr = a.w + (int64_t)spec_wrow_of(a, rg) * a.wn;")
     L.extend(load_x("    ", "xr"))
     A("    T wv[kNP];")
     A("    if (GY || FUSED) {")
@@ -380,7 +381,7 @@ def _emit(st: Structure) -> str:
     A("    }")
     A("    if (GW) {")
     A("      if (act) {")
-    A("        T* __restrict__ gwr = a.gw + (int64_t)e * a.wn;")
+    A("        T* __restrict__ gwr = a.gw + (int64_t)rg * a.wn;")
     for p in range(NP):
         A(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
     A("      }")
@@ -389,7 +390,7 @@ def _emit(st: Structure) -> str:
     A("      T* __restrict__ gyr = a.gy + (int64_t)e * a.gy_stride + chunk * kS;")
     A("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")
     A("    }")
-    A("    idx = nidx; e = e_n; s = s_n;")
+    A("    idx = nidx; e = e_n; s = s_n; rg = rg_n;")
     A("  }")
     A("}")
 
@@ -415,14 +416,14 @@ def _emit(st: Structure) -> str:
     A("  for (int i = 0; i < kXD; ++i) acc[i] = T(0);")
     A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
     A("  int idx = beg + wsub;")
-    A("  int e = 0, d = 0;")
-    A("  if (idx < end) { e = spec_uniform(a.eid[idx]); d = spec_uniform(a.nbr[idx]); }")
+    A("  int e = 0, d = 0, r = 0;")
+    A("  if (idx < end) { e = spec_uniform(a.eid[idx]); d = spec_uniform(a.nbr[idx]); r = spec_wrow(a, idx); }")
     A("  while (idx < end) {")
     A("    const int nidx = idx + WPN;")
-    A("    int e_n = 0, d_n = 0;")
-    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); d_n = spec_uniform(a.nbr[nidx]); }")
+    A("    int e_n = 0, d_n = 0, r_n = 0;")
+    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); d_n = spec_uniform(a.nbr[nidx]); r_n = spec_wrow(a, nidx); }")
     A("    const T* __restrict__ gr = a.g + (int64_t)d * a.dout;")
-    A("    const T* __restrict__ wr = a.w + (int64_t)e * a.wn;")
+    A("    const T* __restrict__ wr = a.w + (int64_t)r * a.wn;")
     A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
     L.extend(load_w("    ", "wr", scale=True))
     used_slots = sorted({s for _, _, s in st.instr})
@@ -439,7 +440,7 @@ def _emit(st: Structure) -> str:
         for i in range(d1):
             A(f"      acc[{xpre[b] + i}] += wv[{p}] * t[{i}];")
         A("    }")
-    A("    idx = nidx; e = e_n; d = d_n;")
+    A("    idx = nidx; e = e_n; d = d_n; r = r_n;")
     A("  }")
     A("  if (WPN > 1) {")
     A("    extern __shared__ __align__(16) unsigned char nqa_smem[];")

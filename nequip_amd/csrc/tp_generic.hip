@@ -475,10 +475,10 @@ using namespace nqa;
 
 extern "C" {
 
-int nqa_tp_scatter_fwd(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+static int nqa_tp_scatter_fwd_impl(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
                        const void* w, const int32_t* rowptr_dst, const int32_t* edge_id_dst,
                        const int32_t* src_sorted, void* out, int64_t num_nodes, int64_t num_edges,
-                       nqa_stream stream) {
+                       nqa_stream stream, const int32_t* weight_rows, int64_t num_pairs) {
   int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_fwd");
   if (rc != NQA_OK) return rc;
   if (num_nodes < 0 || num_edges < 0 || (num_nodes > 0 && (!out || !rowptr_dst)) ||
@@ -498,8 +498,14 @@ int nqa_tp_scatter_fwd(const nqa_plan* plan, const void* plan_image, int32_t dty
     a.rowptr = rowptr_dst;
     a.eid = edge_id_dst;
     a.nbr = src_sorted;
+    a.wid = weight_rows ? weight_rows : edge_id_dst;
+    a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
     plan->spec->launch(0, spec_wpn(plan, num_nodes), a, s);
     return check_launch("nqa_tp_scatter_fwd(spec)");
+  }
+  if (weight_rows != nullptr) {
+    set_error("nqa_tp_scatter_fwd_paired: no structure-specialised float32 kernel for this plan");
+    return NQA_ERR_UNSUPPORTED;
   }
   return dtype == NQA_F32
              ? launch_fwd<float>(plan, plan_image, x, y, w, rowptr_dst, edge_id_dst, src_sorted, out, num_nodes,
@@ -514,11 +520,11 @@ int64_t nqa_tp_bwd_edge_workspace_bytes(const nqa_plan* plan, int32_t dtype, int
   return num_edges * (int64_t)plan->ypart_width * es;
 }
 
-int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+static int nqa_tp_scatter_bwd_edge_impl(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
                             const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
                             const int32_t* edge_id_dst, const int32_t* src_sorted, void* grad_w, void* grad_y,
                             void* workspace, int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges,
-                            nqa_stream stream) {
+                            nqa_stream stream, const int32_t* weight_rows, int64_t num_pairs) {
   int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_edge");
   if (rc != NQA_OK) return rc;
   if (grad_w == nullptr && grad_y == nullptr) return NQA_OK;
@@ -545,6 +551,8 @@ int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_
     a.rowptr = rowptr_dst;
     a.eid = edge_id_dst;
     a.nbr = src_sorted;
+    a.wid = weight_rows ? weight_rows : edge_id_dst;
+    a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
     if (grad_y != nullptr) {
       if (nchunk == 1) {
         a.gy = static_cast<float*>(grad_y);
@@ -566,6 +574,10 @@ int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_
     }
     return NQA_OK;
   }
+  if (weight_rows != nullptr) {
+    set_error("nqa_tp_scatter_bwd_edge_paired: no structure-specialised float32 kernel for this plan");
+    return NQA_ERR_UNSUPPORTED;
+  }
   return dtype == NQA_F32 ? launch_bwd_edge<float>(plan, plan_image, x, y, w, grad_out, rowptr_dst, edge_id_dst,
                                                    src_sorted, grad_w, grad_y, workspace, num_nodes, num_edges, s)
                           : launch_bwd_edge<double>(plan, plan_image, x, y, w, grad_out, rowptr_dst, edge_id_dst,
@@ -579,11 +591,11 @@ int64_t nqa_tp_bwd_fused_workspace_bytes(const nqa_plan* plan, int32_t dtype, in
   return ((ypart + 255) & ~(int64_t)255) + num_edges * (int64_t)plan->dim_in1 * 4;
 }
 
-int nqa_tp_scatter_bwd_fused(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+static int nqa_tp_scatter_bwd_fused_impl(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
                              const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
                              const int32_t* edge_id_dst, const int32_t* src_sorted, const int32_t* rowptr_src,
                              const int32_t* edge_id_src, void* grad_w, void* grad_y, void* grad_x, void* workspace,
-                             int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, nqa_stream stream) {
+                             int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, nqa_stream stream, const int32_t* weight_rows, int64_t num_pairs) {
   int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_fused");
   if (rc != NQA_OK) return rc;
   if (!use_spec(plan, dtype)) {
@@ -618,6 +630,8 @@ int nqa_tp_scatter_bwd_fused(const nqa_plan* plan, const void* plan_image, int32
     a.rowptr = rowptr_dst;
     a.eid = edge_id_dst;
     a.nbr = src_sorted;
+    a.wid = weight_rows ? weight_rows : edge_id_dst;
+    a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
     if (grad_y != nullptr) {
       if (nchunk == 1) {
         a.gy = static_cast<float*>(grad_y);
@@ -649,10 +663,10 @@ int nqa_tp_scatter_bwd_fused(const nqa_plan* plan, const void* plan_image, int32
   return check_launch("nqa_tp_scatter_bwd_fused(sum)");
 }
 
-int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
+static int nqa_tp_scatter_bwd_x_impl(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
                          const void* grad_out, const int32_t* rowptr_src, const int32_t* edge_id_src,
                          const int32_t* dst_sorted, void* grad_x, int64_t num_nodes, int64_t num_edges,
-                         nqa_stream stream) {
+                         nqa_stream stream, const int32_t* weight_rows, int64_t num_pairs) {
   int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_x");
   if (rc != NQA_OK) return rc;
   if ((num_nodes > 0 && (!grad_x || !rowptr_src)) ||
@@ -672,13 +686,95 @@ int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t d
     a.rowptr = rowptr_src;
     a.eid = edge_id_src;
     a.nbr = dst_sorted;
+    a.wid = weight_rows ? weight_rows : edge_id_src;
+    a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
     plan->spec->launch(2, spec_wpn(plan, num_nodes), a, s);
     return check_launch("nqa_tp_scatter_bwd_x(spec)");
+  }
+  if (weight_rows != nullptr) {
+    set_error("nqa_tp_scatter_bwd_x_paired: no structure-specialised float32 kernel for this plan");
+    return NQA_ERR_UNSUPPORTED;
   }
   return dtype == NQA_F32 ? launch_bwd_x<float>(plan, plan_image, y, w, grad_out, rowptr_src, edge_id_src,
                                                 dst_sorted, grad_x, num_nodes, num_edges, s)
                           : launch_bwd_x<double>(plan, plan_image, y, w, grad_out, rowptr_src, edge_id_src,
                                                  dst_sorted, grad_x, num_nodes, num_edges, s);
+}
+
+int nqa_tp_scatter_fwd(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                       const void* w, const int32_t* rowptr_dst, const int32_t* edge_id_dst,
+                       const int32_t* src_sorted, void* out, int64_t num_nodes, int64_t num_edges,
+                       nqa_stream stream) {
+  return nqa_tp_scatter_fwd_impl(plan, plan_image, dtype, x, y, w, rowptr_dst, edge_id_dst, src_sorted, out, num_nodes, num_edges, stream, nullptr, 0);
+}
+
+int nqa_tp_scatter_fwd_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                       const void* w, const int32_t* rowptr_dst, const int32_t* edge_id_dst,
+                       const int32_t* src_sorted, void* out, int64_t num_nodes, int64_t num_edges,
+                       const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream) {
+  if (weight_rows == nullptr || num_pairs <= 0 || num_pairs > 1073741823) {
+    set_error("nqa_tp_scatter_fwd_paired: weight_rows / num_pairs missing or out of range");
+    return NQA_ERR_INVALID;
+  }
+  return nqa_tp_scatter_fwd_impl(plan, plan_image, dtype, x, y, w, rowptr_dst, edge_id_dst, src_sorted, out, num_nodes, num_edges, stream, weight_rows, num_pairs);
+}
+
+int nqa_tp_scatter_bwd_edge(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                            const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                            const int32_t* edge_id_dst, const int32_t* src_sorted, void* grad_w, void* grad_y,
+                            void* workspace, int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges,
+                            nqa_stream stream) {
+  return nqa_tp_scatter_bwd_edge_impl(plan, plan_image, dtype, x, y, w, grad_out, rowptr_dst, edge_id_dst, src_sorted, grad_w, grad_y, workspace, workspace_bytes, num_nodes, num_edges, stream, nullptr, 0);
+}
+
+int nqa_tp_scatter_bwd_edge_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                            const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                            const int32_t* edge_id_dst, const int32_t* src_sorted, void* grad_w, void* grad_y,
+                            void* workspace, int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges,
+                            const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream) {
+  if (weight_rows == nullptr || num_pairs <= 0 || num_pairs > 1073741823) {
+    set_error("nqa_tp_scatter_bwd_edge_paired: weight_rows / num_pairs missing or out of range");
+    return NQA_ERR_INVALID;
+  }
+  return nqa_tp_scatter_bwd_edge_impl(plan, plan_image, dtype, x, y, w, grad_out, rowptr_dst, edge_id_dst, src_sorted, grad_w, grad_y, workspace, workspace_bytes, num_nodes, num_edges, stream, weight_rows, num_pairs);
+}
+
+int nqa_tp_scatter_bwd_fused(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                             const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                             const int32_t* edge_id_dst, const int32_t* src_sorted, const int32_t* rowptr_src,
+                             const int32_t* edge_id_src, void* grad_w, void* grad_y, void* grad_x, void* workspace,
+                             int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, nqa_stream stream) {
+  return nqa_tp_scatter_bwd_fused_impl(plan, plan_image, dtype, x, y, w, grad_out, rowptr_dst, edge_id_dst, src_sorted, rowptr_src, edge_id_src, grad_w, grad_y, grad_x, workspace, workspace_bytes, num_nodes, num_edges, stream, nullptr, 0);
+}
+
+int nqa_tp_scatter_bwd_fused_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                             const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                             const int32_t* edge_id_dst, const int32_t* src_sorted, const int32_t* rowptr_src,
+                             const int32_t* edge_id_src, void* grad_w, void* grad_y, void* grad_x, void* workspace,
+                             int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream) {
+  if (weight_rows == nullptr || num_pairs <= 0 || num_pairs > 1073741823) {
+    set_error("nqa_tp_scatter_bwd_fused_paired: weight_rows / num_pairs missing or out of range");
+    return NQA_ERR_INVALID;
+  }
+  return nqa_tp_scatter_bwd_fused_impl(plan, plan_image, dtype, x, y, w, grad_out, rowptr_dst, edge_id_dst, src_sorted, rowptr_src, edge_id_src, grad_w, grad_y, grad_x, workspace, workspace_bytes, num_nodes, num_edges, stream, weight_rows, num_pairs);
+}
+
+int nqa_tp_scatter_bwd_x(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
+                         const void* grad_out, const int32_t* rowptr_src, const int32_t* edge_id_src,
+                         const int32_t* dst_sorted, void* grad_x, int64_t num_nodes, int64_t num_edges,
+                         nqa_stream stream) {
+  return nqa_tp_scatter_bwd_x_impl(plan, plan_image, dtype, y, w, grad_out, rowptr_src, edge_id_src, dst_sorted, grad_x, num_nodes, num_edges, stream, nullptr, 0);
+}
+
+int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
+                         const void* grad_out, const int32_t* rowptr_src, const int32_t* edge_id_src,
+                         const int32_t* dst_sorted, void* grad_x, int64_t num_nodes, int64_t num_edges,
+                         const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream) {
+  if (weight_rows == nullptr || num_pairs <= 0 || num_pairs > 1073741823) {
+    set_error("nqa_tp_scatter_bwd_x_paired: weight_rows / num_pairs missing or out of range");
+    return NQA_ERR_INVALID;
+  }
+  return nqa_tp_scatter_bwd_x_impl(plan, plan_image, dtype, y, w, grad_out, rowptr_src, edge_id_src, dst_sorted, grad_x, num_nodes, num_edges, stream, weight_rows, num_pairs);
 }
 
 }  // extern "C"

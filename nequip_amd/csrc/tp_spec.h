@@ -21,6 +21,10 @@ struct SpecArgs {
   const int32_t* __restrict__ rowptr;
   const int32_t* __restrict__ eid;
   const int32_t* __restrict__ nbr;
+  // Weight rows (paired radial weights, nqa_tp_scatter_*_paired): wid[slot] in CSR slot order is the row of grad_w the
+  // edge writes, row (wid < wP ? wid : wid - wP) of w holds its weights.  Unpaired calls pass wid = eid, wP = INT32_MAX.
+  const int32_t* __restrict__ wid;
+  int32_t wP;
   int32_t N;
   int32_t mul;
   int32_t din, dout, wn;
@@ -75,6 +79,18 @@ __device__ __forceinline__ const T* spec_at(const T* uniform_base, unsigned lane
   return reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) + lane_bytes);
 }
 __device__ __forceinline__ int spec_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ int spec_gwrow(const SpecArgs<T>& a, int slot) {
+  return spec_uniform(a.wid[slot]);
+}
+template <typename T>
+__device__ __forceinline__ int spec_wrow_of(const SpecArgs<T>& a, int gwrow) {
+  return gwrow >= a.wP ? gwrow - a.wP : gwrow;
+}
+template <typename T>
+__device__ __forceinline__ int spec_wrow(const SpecArgs<T>& a, int slot) {
+  return spec_wrow_of(a, spec_gwrow(a, slot));
+}
 
 // ---- wave64 reductions -------------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wavefront with DPP row operations (no LDS traffic):
