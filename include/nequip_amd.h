@@ -267,6 +267,14 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  *   tiles = nqa_radial_mlp_train_tiles(num_edges) (128-edge workgroup tiles).
  * nqa_radial_mlp_fwd_tangent: out = (Q silu'(P)) W1 = d<c, g_emb>/d grad_edge_weight, the directional derivative of
  *   the MLP along `cotangent`; same workspace as nqa_radial_mlp_fwd. */
+/* nqa_radial_mlp_bwd_paired: nqa_radial_mlp_bwd for an incoming gradient given as two row streams that are added on
+ *   the fly (grad_edge_weight[row] + grad_edge_weight2[row]): the halves written by the two directed edges of a pair in
+ *   nqa_tp_scatter_bwd_*_paired.  num_edges counts rows (pairs).  NQA_MLP_BF16X6 only. */
+int nqa_radial_mlp_bwd_paired(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                              const void* w1, double alpha1, const void* grad_edge_weight,
+                              const void* grad_edge_weight2, int32_t num_basis, int32_t hidden, int32_t out_features,
+                              int64_t num_edges, void* grad_edge_embedding, void* workspace, int64_t workspace_bytes,
+                              int32_t workspace_ready, nqa_stream stream);
 int64_t nqa_radial_mlp_train_tiles(int64_t num_edges);
 int nqa_radial_mlp_bwd_train(int32_t dtype, int32_t mode, const void* edge_embedding, const void* cotangent,
                              const void* w0, double alpha0, const void* w1, double alpha1,
@@ -309,6 +317,44 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
                     int64_t num_nodes, double scale, int32_t chunk_width, nqa_stream stream);
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, const void* cotangent,
              void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Paired radial weights.  InteractionBlock.edge_mlp (nequip/nn/interaction_block.py:119-127,190-192) is a function of
+ *   the edge length alone, and a neighbour list holds every interaction as (i <- j, S) and (j <- i, -S): the reference
+ *   evaluates the MLP twice per pair.  nqa_edge_pairs finds the pairs of a list:
+ *     weight_rows[e] = p (representative edge of pair p: dst < src, or a self image with a "positive" shift) or
+ *                      p + P (its reverse), P = num_edges / 2;  rep_edge[p] = the representative edge;
+ *     *ok (device int32) = 1 iff every edge has exactly one reverse partner (else the arrays are not to be used).
+ *   edge_cell_shift: [E, 3] float32 / float64 (shift_dtype) integer-valued, or NULL.
+ * nqa_tp_scatter_{fwd,bwd_edge,bwd_x,bwd_fused}_paired: the tensor-product entry points above with
+ *   w = [num_pairs, weight_numel] (one row per pair) and, for the edge backward, grad_w = [2 * num_pairs, weight_numel]
+ *   (row weight_rows[e] receives edge e's gradient; the caller -- or nqa_radial_mlp_bwd's second stream -- adds the two
+ *   halves).  weight_rows is given in CSR slot order of the respective topology (weight_rows[edge_id[slot]]).
+ *   Structure-specialised float32 plans only (NQA_ERR_UNSUPPORTED otherwise).
+ * ------------------------------------------------------------------------------------------- */
+int64_t nqa_edge_pairs_workspace_bytes(int64_t num_edges);
+int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void* edge_cell_shift, int32_t shift_dtype,
+                   int64_t num_edges, int64_t num_nodes, void* workspace, int64_t workspace_bytes,
+                   int32_t* weight_rows, int64_t* rep_edge, int32_t* ok, nqa_stream stream);
+int nqa_tp_scatter_fwd_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                              const void* w, const int32_t* rowptr_dst, const int32_t* edge_id_dst,
+                              const int32_t* src_sorted, void* out, int64_t num_nodes, int64_t num_edges,
+                              const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream);
+int nqa_tp_scatter_bwd_edge_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                                   const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                                   const int32_t* edge_id_dst, const int32_t* src_sorted, void* grad_w, void* grad_y,
+                                   void* workspace, int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges,
+                                   const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream);
+int nqa_tp_scatter_bwd_fused_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                                    const void* y, const void* w, const void* grad_out, const int32_t* rowptr_dst,
+                                    const int32_t* edge_id_dst, const int32_t* src_sorted, const int32_t* rowptr_src,
+                                    const int32_t* edge_id_src, void* grad_w, void* grad_y, void* grad_x,
+                                    void* workspace, int64_t workspace_bytes, int64_t num_nodes, int64_t num_edges,
+                                    const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream);
+int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y,
+                                const void* w, const void* grad_out, const int32_t* rowptr_src,
+                                const int32_t* edge_id_src, const int32_t* dst_sorted, void* grad_x, int64_t num_nodes,
+                                int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Parameter gradients of the dense maps of the path (training; in the reference these come out of autograd as the

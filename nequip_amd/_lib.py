@@ -77,6 +77,33 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         + [c_int64, c_int64, c_void_p],
     ),
+    "nqa_edge_pairs_workspace_bytes": (c_int64, [c_int64]),
+    "nqa_edge_pairs": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "nqa_tp_scatter_fwd_paired": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
+    "nqa_tp_scatter_bwd_edge_paired": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
+    "nqa_tp_scatter_bwd_fused_paired": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_void_p] * 5
+        + [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
+    "nqa_tp_scatter_bwd_x_paired": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        + [c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
     "nqa_edge_vectors_fwd": (
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
@@ -127,6 +154,11 @@ SIGNATURES = {
     "nqa_gate": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],
+    ),
+    "nqa_radial_mlp_bwd_paired": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_double, c_void_p, c_void_p, c_int32, c_int32,
+         c_int32, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p],
     ),
     "nqa_radial_mlp_train_tiles": (c_int64, [c_int64]),
     "nqa_radial_mlp_bwd_train": (

@@ -1,0 +1,186 @@
+// Reverse-edge pairing of a neighbour list, on device.
+//
+// The radial network of an interaction block (InteractionBlock.edge_mlp, nequip/nn/interaction_block.py:119-127,190-192)
+// maps the edge embedding -- a function of the edge LENGTH only (BesselEdgeLengthEncoding + PolynomialCutoff,
+// nequip/nn/embedding/_edge.py:136-150) -- to the per-edge tensor-product weights.  A neighbour list built with one
+// cutoff contains every interaction twice, as (i <- j, S) and (j <- i, -S), with bitwise identical lengths, so the
+// reference evaluates that MLP (the only dense GEMM on the edge side, 182 kFLOP/edge) twice per pair.  This kernel family
+// finds the pairs so that the MLP runs once per pair and the tensor-product kernels read the shared row through an index
+// (nqa_tp_scatter_*_paired):
+//   weight_rows[e] = p      for the representative edge of pair p (dst < src, or dst == src with a "positive" shift)
+//                  = p + P  for its reverse               (P = E / 2 pairs)
+//   rep_edge[p]    = the representative edge
+// Method: canonical 64-bit key (min(i,j), max(i,j), shift of the canonical orientation) per edge, radix sort of
+// (key, edge id), then every even sorted position must hold exactly two edges with the same key and opposite
+// orientation.  Anything else (odd E, a missing reverse edge, duplicates, shifts outside [-8, 7], > 2^26 atoms) clears
+// the `ok` flag and the caller keeps the per-edge evaluation.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+#include <string>
+
+#include "plan.h"
+
+namespace nqa {
+
+static int64_t ep_align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct PairKey {
+  uint64_t key;
+  int rep;  // 1: this edge has the canonical orientation
+  int bad;
+};
+
+template <typename ST>
+__device__ __forceinline__ PairKey pair_key(const int64_t* __restrict__ dst, const int64_t* __restrict__ src,
+                                            const ST* __restrict__ shift, int64_t e, int64_t N) {
+  PairKey r;
+  const int64_t i = dst[e], j = src[e];
+  int sx = 0, sy = 0, sz = 0;
+  if (shift != nullptr) {
+    sx = (int)lrint((double)shift[3 * e + 0]);
+    sy = (int)lrint((double)shift[3 * e + 1]);
+    sz = (int)lrint((double)shift[3 * e + 2]);
+  }
+  r.bad = (i < 0 || j < 0 || i >= N || j >= N || i >= (1 << 26) || j >= (1 << 26) || sx < -8 || sx > 7 || sy < -8 ||
+           sy > 7 || sz < -8 || sz > 7)
+              ? 1
+              : 0;
+  // canonical orientation: dst < src; self images by the sign of the first non-zero shift component
+  bool rep;
+  if (i != j) rep = i < j;
+  else rep = sx > 0 || (sx == 0 && (sy > 0 || (sy == 0 && sz > 0)));
+  if (i == j && sx == 0 && sy == 0 && sz == 0) r.bad = 1;  // a self edge without a shift has no partner
+  const int64_t lo = rep ? i : j, hi = rep ? j : i;
+  if (!rep) { sx = -sx; sy = -sy; sz = -sz; }
+  if (sx < -8 || sx > 7 || sy < -8 || sy > 7 || sz < -8 || sz > 7) r.bad = 1;
+  const uint64_t sc = (uint64_t)((sx + 8) & 15) << 8 | (uint64_t)((sy + 8) & 15) << 4 | (uint64_t)((sz + 8) & 15);
+  r.key = ((uint64_t)(lo & ((1 << 26) - 1)) << 38) | ((uint64_t)(hi & ((1 << 26) - 1)) << 12) | sc;
+  r.rep = rep ? 1 : 0;
+  return r;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void edge_pairs_key_kernel(const int64_t* __restrict__ dst,
+                                                              const int64_t* __restrict__ src,
+                                                              const ST* __restrict__ shift, int64_t E, int64_t N,
+                                                              uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                              int32_t* __restrict__ ok) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const PairKey k = pair_key(dst, src, shift, e, N);
+  if (k.bad) atomicAnd(ok, 0);
+  keys[e] = k.key;
+  vals[e] = (int32_t)e;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void edge_pairs_assign_kernel(const int64_t* __restrict__ dst,
+                                                                 const int64_t* __restrict__ src,
+                                                                 const ST* __restrict__ shift, int64_t E, int64_t N,
+                                                                 const uint64_t* __restrict__ keys_sorted,
+                                                                 const int32_t* __restrict__ vals_sorted,
+                                                                 int32_t* __restrict__ weight_rows,
+                                                                 int64_t* __restrict__ rep_edge,
+                                                                 int32_t* __restrict__ ok) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
+  const int64_t P = E / 2;
+  if (p >= P) return;
+  const uint64_t k0 = keys_sorted[2 * p], k1 = keys_sorted[2 * p + 1];
+  const int32_t e0 = vals_sorted[2 * p], e1 = vals_sorted[2 * p + 1];
+  bool good = k0 == k1;
+  if (2 * p + 2 < E && keys_sorted[2 * p + 2] == k0) good = false;  // more than two edges with this key
+  const int r0 = pair_key(dst, src, shift, (int64_t)e0, N).rep;
+  const int r1 = pair_key(dst, src, shift, (int64_t)e1, N).rep;
+  if (r0 == r1) good = false;  // duplicates instead of a reverse edge
+  if (!good) {
+    atomicAnd(ok, 0);
+    return;
+  }
+  const int32_t rep = r0 ? e0 : e1, other = r0 ? e1 : e0;
+  weight_rows[rep] = (int32_t)p;
+  weight_rows[other] = (int32_t)(p + P);
+  rep_edge[p] = (int64_t)rep;
+}
+
+static size_t ep_cub_bytes(int64_t E) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)E, 0, 64, (hipStream_t)0);
+  return bytes;
+}
+
+}  // namespace nqa
+
+using namespace nqa;
+
+extern "C" {
+
+int64_t nqa_edge_pairs_workspace_bytes(int64_t num_edges) {
+  if (num_edges < 0 || num_edges > 2147483647LL) return -1;
+  const int64_t E = num_edges > 0 ? num_edges : 1;
+  return 2 * ep_align256(E * 8) + 2 * ep_align256(E * 4) + ep_align256((int64_t)ep_cub_bytes(E));
+}
+
+int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void* edge_cell_shift, int32_t shift_dtype,
+                   int64_t num_edges, int64_t num_nodes, void* workspace, int64_t workspace_bytes,
+                   int32_t* weight_rows, int64_t* rep_edge, int32_t* ok, nqa_stream stream) {
+  if (num_edges < 0 || num_nodes < 0 || !ok || (num_edges > 0 && (!edge_dst || !edge_src || !weight_rows || !rep_edge)) ||
+      (edge_cell_shift && shift_dtype != NQA_F32 && shift_dtype != NQA_F64)) {
+    set_error("nqa_edge_pairs: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  const int64_t need = nqa_edge_pairs_workspace_bytes(num_edges);
+  if (need < 0) {
+    set_error("nqa_edge_pairs: too many edges");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (num_edges > 0 && (!workspace || workspace_bytes < need)) {
+    set_error("nqa_edge_pairs: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // ok = 1 unless E is odd or empty; the kernels clear it on any violation
+  const int32_t init = (num_edges > 0 && (num_edges % 2) == 0) ? 1 : 0;
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ok), init, 1, s) != hipSuccess) {
+    set_error("nqa_edge_pairs: flag initialisation failed");
+    return NQA_ERR_LAUNCH;
+  }
+  if (!init) return NQA_OK;
+  const int64_t E = num_edges;
+  char* p = static_cast<char*>(workspace);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(p);
+  p += ep_align256(E * 8);
+  uint64_t* keys_sorted = reinterpret_cast<uint64_t*>(p);
+  p += ep_align256(E * 8);
+  int32_t* vals = reinterpret_cast<int32_t*>(p);
+  p += ep_align256(E * 4);
+  int32_t* vals_sorted = reinterpret_cast<int32_t*>(p);
+  p += ep_align256(E * 4);
+  size_t cub_bytes = ep_cub_bytes(E);
+  const unsigned ge = (unsigned)((E + 255) / 256), gp = (unsigned)((E / 2 + 255) / 256);
+#define NQA_EP_RUN(ST)                                                                                          \
+  {                                                                                                            \
+    const ST* sh = static_cast<const ST*>(edge_cell_shift);                                                     \
+    hipLaunchKernelGGL(edge_pairs_key_kernel<ST>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src, sh, E,         \
+                       num_nodes, keys, vals, ok);                                                              \
+    if (hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, keys, keys_sorted, vals, vals_sorted, (int)E, 0, 64,   \
+                                           s) != hipSuccess) {                                                  \
+      set_error("nqa_edge_pairs: radix sort failed");                                                           \
+      return NQA_ERR_LAUNCH;                                                                                    \
+    }                                                                                                          \
+    hipLaunchKernelGGL(edge_pairs_assign_kernel<ST>, dim3(gp), dim3(256), 0, s, edge_dst, edge_src, sh, E,      \
+                       num_nodes, keys_sorted, vals_sorted, weight_rows, rep_edge, ok);                         \
+  }
+  if (edge_cell_shift && shift_dtype == NQA_F32) NQA_EP_RUN(float) else NQA_EP_RUN(double)
+#undef NQA_EP_RUN
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_edge_pairs: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+}  // extern "C"

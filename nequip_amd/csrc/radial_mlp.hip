@@ -667,7 +667,9 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
 // and the per-workgroup partial of dW0 = emb^T (G_h silu'(P)); 2 = second order with a cotangent row block cemb:
 // Q = cemb W0, hid_out = Q silu'(P), g_emb = (Q G_h silu''(P)) W0^T, dW0 partial = emb^T (Q G_h silu'') + cemb^T (G_h silu').
 // Everything happens in the epilogue on the tile that is already on chip; the main loop is the same code.
-template <int H, int TM>
+// PAIR (nqa_radial_mlp_bwd_paired): the incoming gradient is the sum of two row streams gw[row] + gw2[row] (the two
+// directed edges of a pair wrote their halves separately), added in registers when a chunk is consumed.
+template <int H, int TM, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wb,
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
                                                                     int W, int64_t E, float* __restrict__ g_emb,
                                                                     int dbg, const float* __restrict__ cemb,
                                                                     float* __restrict__ hid_out,
-                                                                    float* __restrict__ w0_part) {
+                                                                    float* __restrict__ w0_part,
+                                                                    const float* __restrict__ gw2 = nullptr) {
   // K (= W) is consumed in chunks of 32 columns = two bf16 k-steps; lane (row, half) owns the 16 contiguous floats
   // 32*chunk + 16*half + [0, 16) of its g_w row per chunk: HBM -> registers directly, split in registers.
   constexpr int NT = H / 32;
@@ -727,20 +730,25 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   const int nchunks = (W + 31) / 32;
   u32x4 pb[NV];
   const float* __restrict__ grow = gw + (row_ok ? myrow : 0) * W + 16 * half;
+  const float* __restrict__ grow2 = PAIR ? gw2 + (row_ok ? myrow : 0) * W + 16 * half : nullptr;
   const bool rows_full = blk0 + kMlpRows <= E;  // workgroup-uniform
-  auto load_a = [&](int ch, float4 (&pa)[4]) {
-    if (dbg & 1) return;  // ablation: no g_w traffic
+  auto load_rows = [&](const float* __restrict__ gr, int ch, float4 (&pa)[4]) {
     if (rows_full && 32 * ch + 32 <= W) {  // uniform common case: unpredicated loads
 #pragma unroll
-      for (int v = 0; v < 4; ++v) pa[v] = *reinterpret_cast<const float4*>(grow + 32 * ch + 4 * v);
+      for (int v = 0; v < 4; ++v) pa[v] = *reinterpret_cast<const float4*>(gr + 32 * ch + 4 * v);
     } else {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int k = 32 * ch + 16 * half + 4 * v;
-        pa[v] = (row_ok && k + 3 < W) ? *reinterpret_cast<const float4*>(grow + 32 * ch + 4 * v)
+        pa[v] = (row_ok && k + 3 < W) ? *reinterpret_cast<const float4*>(gr + 32 * ch + 4 * v)
                                       : make_float4(0.f, 0.f, 0.f, 0.f);  // W % 4 == 0
       }
     }
+  };
+  auto load_a = [&](int ch, float4 (&pa)[4], float4 (&pc)[4]) {
+    if (dbg & 1) return;  // ablation: no g_w traffic
+    load_rows(grow, ch, pa);
+    if (PAIR) load_rows(grow2, ch, pc);
   };
   auto load_b = [&](int ch) {
 #pragma unroll
@@ -754,18 +762,25 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   // and *before* the g_w request of the same iteration: vmcnt retires in order, so the wait for the fragments then
   // leaves the younger HBM loads in flight.
   float4 paA[4], paB[4];
+  float4 pcA[PAIR ? 4 : 1], pcB[PAIR ? 4 : 1];  // second row stream (PAIR)
   load_b(0);
-  load_a(0, paA);
+  load_a(0, paA, reinterpret_cast<float4(&)[4]>(pcA));
   store_b(0);
-  if (nchunks > 1) load_a(1, paB);
+  if (nchunks > 1) load_a(1, paB, reinterpret_cast<float4(&)[4]>(pcB));
   __syncthreads();
 
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
 
-  auto body = [&](int ch, float4 (&pa)[4]) {
+  auto body = [&](int ch, float4 (&pa)[4], float4 (&pc)[4]) {
     const int buf = ch & 1;
+    if (PAIR) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        pa[v].x += pc[v].x; pa[v].y += pc[v].y; pa[v].z += pc[v].z; pa[v].w += pc[v].w;
+      }
+    }
     // split this chunk's 16 floats into the A fragments of its two k-steps
     u32x4 ah[2], am[2], al[2];
 #pragma unroll
@@ -781,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
       ah[s][3] = a; am[s][3] = b; al[s][3] = c;
     }
     if (ch + 1 < nchunks && !(dbg & 2) && !((dbg & 8) && (ch & 1))) load_b(ch + 1);
-    if (ch + 2 < nchunks) load_a(ch + 2, pa);
+    if (ch + 2 < nchunks) load_a(ch + 2, pa, pc);
     const u32x4* __restrict__ bs = bsm + buf * CH + lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -809,8 +824,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
     if (!(dbg & 4)) lds_barrier();
   };
   for (int ch = 0; ch < nchunks; ch += 2) {
-    body(ch, paA);
-    if (ch + 1 < nchunks) body(ch + 1, paB);
+    body(ch, paA, reinterpret_cast<float4(&)[4]>(pcA));
+    if (ch + 1 < nchunks) body(ch + 1, paB, reinterpret_cast<float4(&)[4]>(pcB));
   }
 
   // epilogue (exact fp32): pre-activations recomputed on MFMA in the accumulator layout, g_pre = g_h * silu'(pre),
@@ -1086,7 +1101,8 @@ int nqa_radial_mlp_fwd_tangent(int32_t dtype, int32_t mode, const void* edge_emb
 
 static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_embedding, const void* cotangent,
                         void* hidden_out, void* w0_partials, const void* w0, double alpha0, const void* w1,
-                        double alpha1, const void* grad_edge_weight, int32_t num_basis, int32_t hidden,
+                        double alpha1, const void* grad_edge_weight, const void* grad_edge_weight2,
+                        int32_t num_basis, int32_t hidden,
                         int32_t out_features, int64_t num_edges, void* grad_edge_embedding, void* workspace,
                         int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
@@ -1125,6 +1141,20 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
 #define NQA_MLP_BWD_LAUNCH(HH, TT)                                                                              \
   hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<HH, TT>), dim3(grid), dim3(256), 0, s, e, a, wb, g,          \
                      (float)alpha0, num_basis, out_features, num_edges, o, (TT) == 0 ? dbg : 0, c, ho, wp)
+    if (grad_edge_weight2 != nullptr) {
+      const float* g2 = static_cast<const float*>(grad_edge_weight2);
+      if (tm != 0) {
+        set_error("nqa_radial_mlp_bwd_paired: inference backward only");
+        return NQA_ERR_UNSUPPORTED;
+      }
+      if (hidden == 128)
+        hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<128, 0, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,
+                           (float)alpha0, num_basis, out_features, num_edges, o, 0, c, ho, wp, g2);
+      else
+        hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<64, 0, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,
+                           (float)alpha0, num_basis, out_features, num_edges, o, 0, c, ho, wp, g2);
+      return launch_status("nqa_radial_mlp_bwd_paired");
+    }
     if (hidden == 128) {
       if (tm == 0) NQA_MLP_BWD_LAUNCH(128, 0);
       else if (tm == 1) NQA_MLP_BWD_LAUNCH(128, 1);
@@ -1137,8 +1167,8 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
 #undef NQA_MLP_BWD_LAUNCH
     return launch_status("nqa_radial_mlp_bwd");
   }
-  if (tm != 0) {
-    set_error("nqa_radial_mlp_bwd_train: only NQA_MLP_BF16X6 is implemented");
+  if (tm != 0 || grad_edge_weight2 != nullptr) {
+    set_error("nqa_radial_mlp_bwd_train / _paired: only NQA_MLP_BF16X6 is implemented");
     return NQA_ERR_UNSUPPORTED;
   }
   float* w1t = static_cast<float*>(workspace);  // [W (+ padding rows read by the last chunk)][H]
@@ -1159,8 +1189,22 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
                        int32_t hidden, int32_t out_features, int64_t num_edges, void* grad_edge_embedding,
                        void* workspace, int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   return mlp_bwd_impl(dtype, mode, 0, edge_embedding, nullptr, nullptr, nullptr, w0, alpha0, w1, alpha1,
-                      grad_edge_weight, num_basis, hidden, out_features, num_edges, grad_edge_embedding, workspace,
+                      grad_edge_weight, nullptr, num_basis, hidden, out_features, num_edges, grad_edge_embedding, workspace,
                       workspace_bytes, workspace_ready, stream);
+}
+
+int nqa_radial_mlp_bwd_paired(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
+                              const void* w1, double alpha1, const void* grad_edge_weight,
+                              const void* grad_edge_weight2, int32_t num_basis, int32_t hidden, int32_t out_features,
+                              int64_t num_edges, void* grad_edge_embedding, void* workspace, int64_t workspace_bytes,
+                              int32_t workspace_ready, nqa_stream stream) {
+  if (num_edges > 0 && grad_edge_weight2 == nullptr) {
+    set_error("nqa_radial_mlp_bwd_paired: second gradient stream is required");
+    return NQA_ERR_INVALID;
+  }
+  return mlp_bwd_impl(dtype, mode, 0, edge_embedding, nullptr, nullptr, nullptr, w0, alpha0, w1, alpha1,
+                      grad_edge_weight, grad_edge_weight2, num_basis, hidden, out_features, num_edges,
+                      grad_edge_embedding, workspace, workspace_bytes, workspace_ready, stream);
 }
 
 int64_t nqa_radial_mlp_train_tiles(int64_t num_edges) {
@@ -1177,7 +1221,7 @@ int nqa_radial_mlp_bwd_train(int32_t dtype, int32_t mode, const void* edge_embed
     return NQA_ERR_INVALID;
   }
   return mlp_bwd_impl(dtype, mode, cotangent ? 2 : 1, edge_embedding, cotangent, hidden_out, w0_partials, w0, alpha0,
-                      w1, alpha1, grad_edge_weight, num_basis, hidden, out_features, num_edges, grad_edge_embedding,
+                      w1, alpha1, grad_edge_weight, nullptr, num_basis, hidden, out_features, num_edges, grad_edge_embedding,
                       workspace, workspace_bytes, workspace_ready, stream);
 }
 

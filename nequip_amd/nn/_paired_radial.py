@@ -1,0 +1,84 @@
+"""Radial MLP + tensor-product scatter with *paired* radial weights (inference).
+
+``InteractionBlock.forward`` evaluates ``edge_mlp`` on every directed edge and hands the ``[E, W]`` result to
+``tp_scatter`` (``nequip/nn/interaction_block.py:190-199``).  The MLP's input is a function of the edge length only
+(``nequip/nn/embedding/_edge.py:136-150``) and a neighbour list holds every interaction in both directions with bitwise
+identical lengths, so half of those rows -- half of the only dense GEMM on the edge side -- are duplicates.  When the list
+pairs up (``EdgeTopology.pairing``, ``csrc/edge_pairs.hip``) this Function evaluates the MLP once per pair and lets the
+tensor-product kernels read the shared row through the pair index (``nqa_tp_scatter_*_paired``); in the backward the two
+directed edges of a pair write their weight-gradient halves to rows ``p`` and ``p + P`` and the MLP backward adds the two
+streams while loading them (``nqa_radial_mlp_bwd_paired``).  Same numbers as the per-edge evaluation up to the order of
+one fp32 addition in the backward.  First order only (eval mode); training keeps the per-edge modules.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import _lib
+from . import mlp as _mlp
+from ._tp_scatter_base import _Kernels
+from ._topology import EdgePairing, EdgeTopology
+
+
+class _PairedRadialTPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb_half, x, y, w0, w1, alpha0: float, alpha1: float, mode: int, cache, k: _Kernels,
+                topo: EdgeTopology, pairing: EdgePairing):
+        emb_half, x, y = emb_half.contiguous(), x.contiguous(), y.contiguous()
+        w_half = _mlp._launch_fwd(emb_half, w0, w1, alpha0, alpha1, mode, cache)
+        out = k.fwd(x, y, w_half, topo, pairing)
+        ctx.save_for_backward(emb_half, x, y, w_half, w0, w1)
+        ctx.args = (alpha0, alpha1, mode, cache, k, topo, pairing)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        emb_half, x, y, w_half, w0, w1 = ctx.saved_tensors
+        alpha0, alpha1, mode, cache, k, topo, pairing = ctx.args
+        need_emb, need_x, need_y = ctx.needs_input_grad[:3]
+        g = g.contiguous()
+        P = pairing.num_pairs
+        gx = gy = G = None
+        fused = None
+        if need_emb and need_x and need_y and k.prefer_fused_bwd and os.environ.get("NQA_NO_FUSED_BWD", "") in ("", "0"):
+            fused = k.bwd_fused(x, y, w_half, g, topo, pairing=pairing)
+        if fused is not None:
+            gx, G, gy = fused
+        else:
+            if need_x:
+                gx = k.bwd_x(y, w_half, g, topo, pairing)
+            G, gy = k.bwd_edge(x, y, w_half, g, topo, need_gw=need_emb, need_gy=need_y, pairing=pairing)
+        g_emb = None
+        if need_emb:
+            g_emb = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
+        return (g_emb, gx, gy) + (None,) * 9
+
+
+def available(edge_mlp, tp_scatter, x: torch.Tensor, emb: torch.Tensor) -> bool:
+    """Eval-mode float32 GPU evaluation with the fused split-bf16 MLP and structure-specialised TP kernels."""
+    if edge_mlp.training or not x.is_cuda or x.dtype != torch.float32 or emb.dtype != torch.float32:
+        return False
+    if os.environ.get("NQA_NO_PAIRED", "") not in ("", "0"):
+        return False
+    if not edge_mlp._fused_ok(emb) or _mlp.radial_mlp_mode() != _lib.NQA_MLP_BF16X6:
+        return False
+    if tp_scatter.use_dispatcher_ops or tp_scatter.model_dtype != torch.float32:
+        return False
+    return tp_scatter._get_kernels().has_spec(torch.float32)
+
+
+def paired_radial_tp(edge_mlp, tp_scatter, emb, x, edge_attr, topo: EdgeTopology, pairing: EdgePairing):
+    """``tp_scatter(x, edge_attr, edge_mlp(emb), ...)`` with the MLP evaluated on the pairs' representative edges."""
+    cache = getattr(edge_mlp, "_weight_images", None)
+    if cache is None:
+        cache = edge_mlp._weight_images = _mlp._WeightImages()
+    cache.validate(edge_mlp.mlp[2].weight)
+    emb_half = emb.index_select(0, pairing.rep_edge)
+    return _PairedRadialTPFn.apply(
+        emb_half, x, edge_attr, edge_mlp.mlp[0].weight.detach(), edge_mlp.mlp[2].weight.detach(),
+        edge_mlp._alphas[0], edge_mlp._alphas[1], _mlp.radial_mlp_mode(), cache, tp_scatter._get_kernels(), topo, pairing,
+    )

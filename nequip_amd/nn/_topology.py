@@ -76,6 +76,40 @@ class EdgeTopology:
             raise RuntimeError("edge index out of range [0, num_nodes)")
         return rowptr, eid, oth
 
+    def pairing(self, shifts: Optional[torch.Tensor]):
+        """Reverse-edge pairing of this list (``nqa_edge_pairs``): ``None`` when some edge has no unique reverse
+        partner, else an ``EdgePairing`` with the weight rows in the slot order of both CSRs.  Computed once per
+        topology (one device synchronisation to read the verdict)."""
+        key = None if shifts is None else (shifts.data_ptr(), shifts._version, tuple(shifts.shape))
+        cached = getattr(self, "_pairing", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        result = None
+        E = self.num_edges
+        if E > 0 and E % 2 == 0 and os.environ.get("NQA_NO_PAIRED", "") in ("", "0"):
+            lib = _lib.load()
+            dev = self.device
+            sh = None
+            if shifts is not None:
+                sh = shifts.detach()
+                if sh.dtype not in (torch.float32, torch.float64):
+                    sh = sh.to(torch.float64)
+                sh = sh.contiguous()
+            rows = torch.empty(E, dtype=torch.int32, device=dev)
+            rep = torch.empty(E // 2, dtype=torch.int64, device=dev)
+            ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws_bytes = lib.nqa_edge_pairs_workspace_bytes(E)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            sdt = _lib.NQA_F32 if (sh is not None and sh.dtype == torch.float32) else _lib.NQA_F64
+            with torch.cuda.device(dev):
+                rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, E, self.num_nodes, _ptr(ws),
+                                        ws_bytes, _ptr(rows), _ptr(rep), _ptr(ok), current_stream_ptr(dev))
+            _lib.check(rc, "nqa_edge_pairs")
+            if int(ok.item()) == 1:
+                result = EdgePairing(self, rows, rep)
+        self._pairing = (key, result)
+        return result
+
     @property
     def by_dst(self):
         if self._by_dst is None:
@@ -87,6 +121,33 @@ class EdgeTopology:
         if self._by_src is None:
             self._by_src = self._build(self._src, self._dst)
         return self._by_src
+
+
+class EdgePairing:
+    """Weight rows of a paired edge list: ``rows[e]`` (see include/nequip_amd.h ``nqa_edge_pairs``), gathered into the
+    slot order of the two CSRs on first use, and the representative edge of every pair."""
+
+    def __init__(self, topo: EdgeTopology, rows: torch.Tensor, rep_edge: torch.Tensor):
+        self.rows = rows
+        self.rep_edge = rep_edge
+        self.num_pairs = int(rep_edge.numel())
+        self._topo = weakref.ref(topo)
+        self._slots_dst: Optional[torch.Tensor] = None
+        self._slots_src: Optional[torch.Tensor] = None
+
+    @property
+    def slots_dst(self) -> torch.Tensor:
+        if self._slots_dst is None:
+            eid = self._topo().by_dst[1][: self.rows.numel()]
+            self._slots_dst = self.rows.index_select(0, eid.to(torch.int64)).contiguous()
+        return self._slots_dst
+
+    @property
+    def slots_src(self) -> torch.Tensor:
+        if self._slots_src is None:
+            eid = self._topo().by_src[1][: self.rows.numel()]
+            self._slots_src = self.rows.index_select(0, eid.to(torch.int64)).contiguous()
+        return self._slots_src
 
 
 class _TopologyCache:

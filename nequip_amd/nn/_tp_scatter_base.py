@@ -53,19 +53,25 @@ class _Kernels:
         # a per-edge row of grad_x contributions written and read once (2 * dim_in1): worth it for wide outputs only.
         self.prefer_fused_bwd = (self.weight_numel + self.dim_out) >= 3 * self.dim_in1
 
-    def _check(self, x, y, w, topo: EdgeTopology):
+    def has_spec(self, dtype: torch.dtype) -> bool:
+        """Structure-specialised kernels available (float32, uniform-mul NequIP shapes)?"""
+        return _lib.load().nqa_tp_bwd_fused_workspace_bytes(self.plan.handle, _nqa_dtype(dtype), 0) >= 0
+
+    def _check(self, x, y, w, topo: EdgeTopology, pairing=None):
         N, E = topo.num_nodes, topo.num_edges
         if x is not None:
             assert x.shape == (N, self.dim_in1), f"x has shape {tuple(x.shape)}, expected {(N, self.dim_in1)}"
         if y is not None:
             assert y.shape == (E, self.dim_in2), f"edge_attr has shape {tuple(y.shape)}, expected {(E, self.dim_in2)}"
         if w is not None:
-            assert w.shape == (E, self.weight_numel), (
-                f"edge_weight has shape {tuple(w.shape)}, expected {(E, self.weight_numel)}"
+            rows = E if pairing is None else pairing.num_pairs
+            assert w.shape == (rows, self.weight_numel), (
+                f"edge_weight has shape {tuple(w.shape)}, expected {(rows, self.weight_numel)}"
             )
 
-    def fwd(self, x, y, w, topo: EdgeTopology) -> torch.Tensor:
-        self._check(x, y, w, topo)
+    def fwd(self, x, y, w, topo: EdgeTopology, pairing=None) -> torch.Tensor:
+        """``pairing`` (``EdgePairing``): ``w`` holds one row per reverse-edge pair (``nqa_tp_scatter_fwd_paired``)."""
+        self._check(x, y, w, topo, pairing)
         lib = _lib.load()
         alloc = torch.zeros if self.out_needs_zero else torch.empty
         out = alloc((topo.num_nodes, self.dim_out), dtype=x.dtype, device=x.device)
@@ -75,19 +81,28 @@ class _Kernels:
             self.dim_in1 + self.dim_out
         )
         with torch.cuda.device(x.device), ktimer.region("tp_fwd", nbytes):
-            rc = lib.nqa_tp_scatter_fwd(
-                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w),
-                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(out), topo.num_nodes, topo.num_edges,
-                current_stream_ptr(x.device),
-            )  # fmt: skip
+            if pairing is None:
+                rc = lib.nqa_tp_scatter_fwd(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(out), topo.num_nodes, topo.num_edges,
+                    current_stream_ptr(x.device),
+                )  # fmt: skip
+            else:
+                rc = lib.nqa_tp_scatter_fwd_paired(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(out), topo.num_nodes, topo.num_edges,
+                    _ptr(pairing.slots_dst), pairing.num_pairs, current_stream_ptr(x.device),
+                )  # fmt: skip
         _lib.check(rc, "nqa_tp_scatter_fwd")
         return out
 
-    def bwd_edge(self, x, y, w, g, topo: EdgeTopology, need_gw: bool, need_gy: bool):
-        self._check(x, y, w, topo)
+    def bwd_edge(self, x, y, w, g, topo: EdgeTopology, need_gw: bool, need_gy: bool, pairing=None):
+        """With ``pairing``: ``gw`` is ``[2 * num_pairs, weight_numel]`` (the two halves of every pair's gradient)."""
+        self._check(x, y, w, topo, pairing)
         lib = _lib.load()
         E = topo.num_edges
-        gw = torch.empty((E, self.weight_numel), dtype=x.dtype, device=x.device) if need_gw else None
+        gw_rows = E if pairing is None else 2 * pairing.num_pairs
+        gw = torch.empty((gw_rows, self.weight_numel), dtype=x.dtype, device=x.device) if need_gw else None
         gy = torch.empty((E, self.dim_in2), dtype=x.dtype, device=x.device) if need_gy else None
         if not (need_gw or need_gy):
             return None, None
@@ -102,15 +117,22 @@ class _Kernels:
         )
         nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
         with torch.cuda.device(x.device), ktimer.region("tp_bwd_edge", nbytes):
-            rc = lib.nqa_tp_scatter_bwd_edge(
-                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
-                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gw), _ptr(gy), _ptr(ws), ws_bytes,
-                topo.num_nodes, E, current_stream_ptr(x.device),
-            )  # fmt: skip
+            if pairing is None:
+                rc = lib.nqa_tp_scatter_bwd_edge(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gw), _ptr(gy), _ptr(ws), ws_bytes,
+                    topo.num_nodes, E, current_stream_ptr(x.device),
+                )  # fmt: skip
+            else:
+                rc = lib.nqa_tp_scatter_bwd_edge_paired(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gw), _ptr(gy), _ptr(ws), ws_bytes,
+                    topo.num_nodes, E, _ptr(pairing.slots_dst), pairing.num_pairs, current_stream_ptr(x.device),
+                )  # fmt: skip
         _lib.check(rc, "nqa_tp_scatter_bwd_edge")
         return gw, gy
 
-    def bwd_fused(self, x, y, w, g, topo: EdgeTopology, need_gw: bool = True, need_gy: bool = True):
+    def bwd_fused(self, x, y, w, g, topo: EdgeTopology, need_gw: bool = True, need_gy: bool = True, pairing=None):
         """(gx, gw, gy) in one pass over ``g`` (``nqa_tp_scatter_bwd_fused``), or None when the plan has no
         structure-specialised float32 kernel (the caller then uses bwd_x + bwd_edge)."""
         lib = _lib.load()
@@ -118,9 +140,10 @@ class _Kernels:
         ws_bytes = lib.nqa_tp_bwd_fused_workspace_bytes(self.plan.handle, _nqa_dtype(x.dtype), E)
         if ws_bytes < 0:
             return None
-        self._check(x, y, w, topo)
+        self._check(x, y, w, topo, pairing)
         gx = torch.empty((N, self.dim_in1), dtype=x.dtype, device=x.device)
-        gw = torch.empty((E, self.weight_numel), dtype=x.dtype, device=x.device) if need_gw else None
+        gw_rows = E if pairing is None else 2 * pairing.num_pairs
+        gw = torch.empty((gw_rows, self.weight_numel), dtype=x.dtype, device=x.device) if need_gw else None
         gy = torch.empty((E, self.dim_in2), dtype=x.dtype, device=x.device) if need_gy else None
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
         rowptr, eid, nbr = topo.by_dst
@@ -131,16 +154,24 @@ class _Kernels:
         nbytes = E * (es * (self.weight_numel + self.dim_in2) + 24) + N * es * (2 * self.dim_in1 + self.dim_out)
         nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
         with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused", nbytes):
-            rc = lib.nqa_tp_scatter_bwd_fused(
-                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
-                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(rowptr_s), _ptr(eid_s), _ptr(gw), _ptr(gy), _ptr(gx),
-                _ptr(ws), ws_bytes, N, E, current_stream_ptr(x.device),
-            )  # fmt: skip
+            if pairing is None:
+                rc = lib.nqa_tp_scatter_bwd_fused(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(rowptr_s), _ptr(eid_s), _ptr(gw), _ptr(gy), _ptr(gx),
+                    _ptr(ws), ws_bytes, N, E, current_stream_ptr(x.device),
+                )  # fmt: skip
+            else:
+                rc = lib.nqa_tp_scatter_bwd_fused_paired(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(rowptr_s), _ptr(eid_s), _ptr(gw), _ptr(gy), _ptr(gx),
+                    _ptr(ws), ws_bytes, N, E, _ptr(pairing.slots_dst), pairing.num_pairs,
+                    current_stream_ptr(x.device),
+                )  # fmt: skip
         _lib.check(rc, "nqa_tp_scatter_bwd_fused")
         return gx, gw, gy
 
-    def bwd_x(self, y, w, g, topo: EdgeTopology) -> torch.Tensor:
-        self._check(None, y, w, topo)
+    def bwd_x(self, y, w, g, topo: EdgeTopology, pairing=None) -> torch.Tensor:
+        self._check(None, y, w, topo, pairing)
         lib = _lib.load()
         gx = torch.empty((topo.num_nodes, self.dim_in1), dtype=g.dtype, device=g.device)
         rowptr, eid, nbr = topo.by_src
@@ -149,11 +180,18 @@ class _Kernels:
             self.dim_in1 + self.dim_out
         )
         with torch.cuda.device(g.device), ktimer.region("tp_bwd_x", nbytes):
-            rc = lib.nqa_tp_scatter_bwd_x(
-                self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(g),
-                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gx), topo.num_nodes, topo.num_edges,
-                current_stream_ptr(g.device),
-            )  # fmt: skip
+            if pairing is None:
+                rc = lib.nqa_tp_scatter_bwd_x(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(g),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gx), topo.num_nodes, topo.num_edges,
+                    current_stream_ptr(g.device),
+                )  # fmt: skip
+            else:
+                rc = lib.nqa_tp_scatter_bwd_x_paired(
+                    self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(g),
+                    _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gx), topo.num_nodes, topo.num_edges,
+                    _ptr(pairing.slots_src), pairing.num_pairs, current_stream_ptr(g.device),
+                )  # fmt: skip
         _lib.check(rc, "nqa_tp_scatter_bwd_x")
         return gx
 

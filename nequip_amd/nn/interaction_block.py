@@ -12,7 +12,9 @@ import torch
 from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
 from ..o3.modules import FullyConnectedTensorProduct, Linear
+from . import _paired_radial
 from ._graph_mixin import GraphModuleMixin
+from ._topology import topology_cache
 from ._tp_scatter_base import TensorProductScatter
 from .mlp import ScalarMLPFunction
 from .norm import AvgNumNeighborsNorm
@@ -105,13 +107,26 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             data = norm(data)
             x = data[AtomicDataDict.NODE_FEATURES_KEY]
 
-        x = self.tp_scatter(
-            x=x,
-            edge_attr=data[AtomicDataDict.EDGE_ATTRS_KEY],
-            edge_weight=self.edge_mlp(data[AtomicDataDict.EDGE_EMBEDDING_KEY]),
-            edge_dst=data[AtomicDataDict.EDGE_INDEX_KEY][0],
-            edge_src=data[AtomicDataDict.EDGE_INDEX_KEY][1],
-        )[:num_local_nodes]
+        emb = data[AtomicDataDict.EDGE_EMBEDDING_KEY]
+        edge_index = data[AtomicDataDict.EDGE_INDEX_KEY]
+        pairing = None
+        if _paired_radial.available(self.edge_mlp, self.tp_scatter, x, emb):
+            # inference: the radial MLP depends on the edge length only, and the list holds both directions of every
+            # interaction -- evaluate it once per pair (nn/_paired_radial.py); None if the list does not pair up
+            topo = topology_cache.get(edge_index[0], edge_index[1], x.size(0))
+            pairing = topo.pairing(data.get(AtomicDataDict.EDGE_CELL_SHIFT_KEY))
+        if pairing is not None:
+            x = _paired_radial.paired_radial_tp(
+                self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY], topo, pairing
+            )[:num_local_nodes]
+        else:
+            x = self.tp_scatter(
+                x=x,
+                edge_attr=data[AtomicDataDict.EDGE_ATTRS_KEY],
+                edge_weight=self.edge_mlp(emb),
+                edge_dst=edge_index[0],
+                edge_src=edge_index[1],
+            )[:num_local_nodes]
 
         # linear_2 with the residual `+ sc` fused into the same launch
         x = self.linear_2(x, addend=sc if self.sc is not None else None)

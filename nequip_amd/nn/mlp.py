@@ -122,6 +122,26 @@ def _launch_fwd_tangent(emb, cot, w0, w1, alpha0: float, alpha1: float, mode: in
     return out
 
 
+def _launch_bwd_paired(emb, w0, w1, alpha0: float, alpha1: float, g_a, g_b, mode: int, cache: _WeightImages):
+    """``_launch_bwd`` for a gradient given as two row streams ``g_a + g_b`` (``nqa_radial_mlp_bwd_paired``)."""
+    from ._topology import _ptr, current_stream_ptr
+
+    lib = _lib.load()
+    E, nb = emb.shape
+    H, W = w1.shape
+    assert g_a.shape == (E, W) and g_b.shape == (E, W) and g_a.is_contiguous() and g_b.is_contiguous()
+    g_emb = torch.empty_like(emb)
+    flops = 2.0 * E * (nb * H * 2 + H * W)
+    ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
+    ws, ready = cache.get(w1, mode, 1, ws_bytes)
+    with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + 2 * W), flops):
+        rc = lib.nqa_radial_mlp_bwd_paired(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, _ptr(g_a),
+                                           _ptr(g_b), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes, int(ready),
+                                           current_stream_ptr(emb.device))
+    _lib.check(rc, "nqa_radial_mlp_bwd_paired")
+    return g_emb
+
+
 def _launch_wgrad(a, b):
     """``a^T b`` reduced over the edge rows (``nqa_wgrad``): [E, M], [E, N] -> [M, N]."""
     from ..utils import wgrad as _wg

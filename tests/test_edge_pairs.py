@@ -1,0 +1,102 @@
+"""Reverse-edge pairing (nqa_edge_pairs, csrc/edge_pairs.hip) and the paired radial-MLP / tensor-product evaluation
+(nn/_paired_radial.py): the reference evaluates InteractionBlock.edge_mlp on every directed edge
+(nequip/nn/interaction_block.py:190-192); evaluating it once per (i <- j, S) / (j <- i, -S) pair must give the same
+energies, forces and stress."""
+import numpy as np
+import pytest
+import torch
+
+
+def _pairing_of(data, device):
+    from nequip_amd.nn._topology import EdgeTopology
+
+    ei = data["edge_index"].to(device)
+    topo = EdgeTopology(ei[0].contiguous(), ei[1].contiguous(), data["pos"].shape[0])
+    sh = data["edge_cell_shift"].to(device) if "edge_cell_shift" in data else None
+    return topo, topo.pairing(sh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("system", ["water", "si_small_cell", "molecule"])
+def test_pairing_is_a_reverse_edge_matching(device, system):
+    from nequip_amd.utils import synthetic as syn
+
+    if system == "water":
+        pos, types, cell, names = syn.water_box(n_side=3, seed=1)
+        data = syn.make_data(pos, types, 4.5, cell)
+    elif system == "si_small_cell":  # cell thinner than 2 r_max: several images of the same (i, j), self images
+        pos, types, cell, names = syn.silicon_box(reps=1, seed=2)
+        data = syn.make_data(pos, types, 4.5, cell)
+    else:
+        pos, types, cell, names = syn.water_box(n_side=2, seed=3)
+        data = syn.make_data(pos, types, 4.5, None, pbc=False)
+    topo, pr = _pairing_of(data, device)
+    assert pr is not None
+    E = data["edge_index"].shape[1]
+    P = E // 2
+    rows = pr.rows.cpu().numpy()
+    rep = pr.rep_edge.cpu().numpy()
+    dst, src = data["edge_index"][0].numpy(), data["edge_index"][1].numpy()
+    sh = data["edge_cell_shift"].numpy() if "edge_cell_shift" in data else np.zeros((E, 3))
+    assert sorted(rows.tolist()) == list(range(2 * P))  # every row of the [2P, W] gradient buffer is written once
+    other = np.empty(P, dtype=np.int64)
+    other[rows[rows >= P] - P] = np.nonzero(rows >= P)[0]
+    assert np.array_equal(rows[rep], np.arange(P))
+    assert np.array_equal(dst[rep], src[other]) and np.array_equal(src[rep], dst[other])
+    assert np.array_equal(sh[rep], -sh[other])
+    # slot-order copies follow the CSR permutations
+    eid_d = topo.by_dst[1][:E].cpu().numpy()
+    assert np.array_equal(pr.slots_dst.cpu().numpy(), rows[eid_d])
+    eid_s = topo.by_src[1][:E].cpu().numpy()
+    assert np.array_equal(pr.slots_src.cpu().numpy(), rows[eid_s])
+
+
+@pytest.mark.gpu
+def test_unpairable_lists_are_rejected(device):
+    from nequip_amd.nn._topology import EdgeTopology
+
+    dst = torch.tensor([0, 1, 2, 0], device=device)
+    src = torch.tensor([1, 0, 0, 2], device=device)
+    assert EdgeTopology(dst, src, 3).pairing(None) is not None
+    assert EdgeTopology(dst[:3].contiguous(), src[:3].contiguous(), 3).pairing(None) is None          # odd count
+    assert EdgeTopology(torch.tensor([0, 1, 2, 2], device=device), torch.tensor([1, 0, 0, 1], device=device),
+                        3).pairing(None) is None                                                       # no reverse
+    assert EdgeTopology(torch.tensor([0, 0, 1, 1], device=device), torch.tensor([1, 1, 0, 0], device=device),
+                        2).pairing(None) is None                                                       # duplicates
+    sh = torch.tensor([[1.0, 0, 0], [1.0, 0, 0]], device=device, dtype=torch.float64)
+    assert EdgeTopology(torch.tensor([0, 1], device=device), torch.tensor([1, 0], device=device), 2).pairing(sh) is None
+    sh[1, 0] = -1.0
+    assert EdgeTopology(torch.tensor([0, 1], device=device), torch.tensor([1, 0], device=device), 2).pairing(sh) is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodic", [True, False])
+def test_paired_evaluation_matches_per_edge_evaluation(device, periodic, monkeypatch):
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn import _paired_radial
+    from nequip_amd.nn._topology import topology_cache
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=4, seed=5)
+    model = NequIPGNNModel(seed=2, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
+                           avg_num_neighbors=30.0).to(device).eval()
+    data = AtomicDataDict.to_device(syn.make_data(pos, types, 4.5, cell if periodic else None, pbc=periodic), device)
+    calls = []
+    orig = _paired_radial._PairedRadialTPFn.forward
+    monkeypatch.setattr(_paired_radial._PairedRadialTPFn, "forward",
+                        staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1]))
+    out_p = model(dict(data))
+    assert len(calls) == 3, "the paired path must be taken in all three layers"
+    monkeypatch.setenv("NQA_NO_PAIRED", "1")
+    topology_cache.clear()
+    out_e = model(dict(data))
+    assert len(calls) == 3
+    e_p, e_e = out_p["total_energy"].detach(), out_e["total_energy"].detach()
+    torch.testing.assert_close(e_p, e_e, rtol=1e-6, atol=1e-5)
+    f_p, f_e = out_p["forces"].detach(), out_e["forces"].detach()
+    torch.testing.assert_close(f_p, f_e, rtol=0, atol=2e-6 * max(1.0, float(f_e.abs().max())))
+    if periodic:
+        torch.testing.assert_close(out_p["stress"].detach(), out_e["stress"].detach(), rtol=0,
+                                   atol=2e-6 * max(1e-3, float(out_e["stress"].abs().max())))
