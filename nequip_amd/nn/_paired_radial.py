@@ -8,7 +8,8 @@ pairs up (``EdgeTopology.pairing``, ``csrc/edge_pairs.hip``) this Function evalu
 tensor-product kernels read the shared row through the pair index (``nqa_tp_scatter_*_paired``); in the backward the two
 directed edges of a pair write their weight-gradient halves to rows ``p`` and ``p + P`` and the MLP backward adds the two
 streams while loading them (``nqa_radial_mlp_bwd_paired``).  Same numbers as the per-edge evaluation up to the order of
-one fp32 addition in the backward.  First order only (eval mode); training keeps the per-edge modules.
+one fp32 addition in the backward.  The fused Function below is first order (eval mode); in training the same pairing
+feeds the twice-differentiable per-module Functions (``paired_radial_tp``).
 """
 
 from __future__ import annotations
@@ -59,8 +60,8 @@ class _PairedRadialTPFn(torch.autograd.Function):
 
 
 def available(edge_mlp, tp_scatter, x: torch.Tensor, emb: torch.Tensor) -> bool:
-    """Eval-mode float32 GPU evaluation with the fused split-bf16 MLP and structure-specialised TP kernels."""
-    if edge_mlp.training or not x.is_cuda or x.dtype != torch.float32 or emb.dtype != torch.float32:
+    """float32 GPU evaluation with the fused split-bf16 MLP and structure-specialised TP kernels."""
+    if not x.is_cuda or x.dtype != torch.float32 or emb.dtype != torch.float32:
         return False
     if os.environ.get("NQA_NO_PAIRED", "") not in ("", "0"):
         return False
@@ -78,6 +79,11 @@ def paired_radial_tp(edge_mlp, tp_scatter, emb, x, edge_attr, topo: EdgeTopology
         cache = edge_mlp._weight_images = _mlp._WeightImages()
     cache.validate(edge_mlp.mlp[2].weight)
     emb_half = emb.index_select(0, pairing.rep_edge)
+    if edge_mlp.training:
+        # training: the per-module twice-differentiable Functions, on P rows instead of E (the weight gradient of the
+        # pair is the sum of its two halves, folded inside the tensor-product backward)
+        w_half = edge_mlp(emb_half)
+        return tp_scatter(x, edge_attr, w_half, topo._dst, topo._src, topology=topo, pairing=pairing)
     return _PairedRadialTPFn.apply(
         emb_half, x, edge_attr, edge_mlp.mlp[0].weight.detach(), edge_mlp.mlp[2].weight.detach(),
         edge_mlp._alphas[0], edge_mlp._alphas[1], _mlp.radial_mlp_mode(), cache, tp_scatter._get_kernels(), topo, pairing,

@@ -196,39 +196,50 @@ class _Kernels:
         return gx
 
 
+def _fold(G, pairing):
+    """Gradient w.r.t. paired weights: the two directed edges of pair p wrote rows p and p + P."""
+    if G is None or pairing is None:
+        return G
+    P = pairing.num_pairs
+    return G[:P] + G[P:]
+
+
 class _TPScatterFn(torch.autograd.Function):
+    """``pairing`` (``EdgePairing`` or None): ``w`` holds one row per reverse-edge pair instead of one per edge."""
+
     @staticmethod
-    def forward(ctx, x, y, w, k: _Kernels, topo: EdgeTopology):
+    def forward(ctx, x, y, w, k: _Kernels, topo: EdgeTopology, pairing=None):
         x, y, w = x.contiguous(), y.contiguous(), w.contiguous()
-        out = k.fwd(x, y, w, topo)
+        out = k.fwd(x, y, w, topo, pairing)
         ctx.save_for_backward(x, y, w)
-        ctx.k, ctx.topo = k, topo
+        ctx.k, ctx.topo, ctx.pairing = k, topo, pairing
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, y, w = ctx.saved_tensors
         need = tuple(ctx.needs_input_grad[:3])
-        gx, gy, gw = _TPScatterBwdFn.apply(g, x, y, w, ctx.k, ctx.topo, need)
-        return gx, gy, gw, None, None
+        gx, gy, gw = _TPScatterBwdFn.apply(g, x, y, w, ctx.k, ctx.topo, need, ctx.pairing)
+        return gx, gy, gw, None, None, None
 
 
 class _TPScatterBwdFn(torch.autograd.Function):
     """(g, x, y, w) -> (gx, gy, gw); itself differentiable once more (force-matching training)."""
 
     @staticmethod
-    def forward(ctx, g, x, y, w, k: _Kernels, topo: EdgeTopology, need: Tuple[bool, bool, bool]):
+    def forward(ctx, g, x, y, w, k: _Kernels, topo: EdgeTopology, need: Tuple[bool, bool, bool], pairing=None):
         g = g.contiguous()
         fused = None
         if need[0] and need[1] and need[2] and k.prefer_fused_bwd and os.environ.get("NQA_NO_FUSED_BWD", "") in ("", "0"):
-            fused = k.bwd_fused(x, y, w, g, topo, need_gw=need[2], need_gy=need[1])
+            fused = k.bwd_fused(x, y, w, g, topo, need_gw=need[2], need_gy=need[1], pairing=pairing)
         if fused is not None:
             gx, gw, gy = fused
         else:
-            gx = k.bwd_x(y, w, g, topo) if need[0] else None
-            gw, gy = k.bwd_edge(x, y, w, g, topo, need_gw=need[2], need_gy=need[1])
+            gx = k.bwd_x(y, w, g, topo, pairing) if need[0] else None
+            gw, gy = k.bwd_edge(x, y, w, g, topo, need_gw=need[2], need_gy=need[1], pairing=pairing)
+        gw = _fold(gw, pairing)
         ctx.save_for_backward(g, x, y, w)
-        ctx.k, ctx.topo = k, topo
+        ctx.k, ctx.topo, ctx.pairing = k, topo, pairing
         ctx.mark_non_differentiable(*[t for t, n in zip((gx, gy, gw), need) if not n and t is not None])
         return gx, gy, gw
 
@@ -236,7 +247,7 @@ class _TPScatterBwdFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, c_x, c_y, c_w):
         g, x, y, w = ctx.saved_tensors
-        k, topo = ctx.k, ctx.topo
+        k, topo, pr = ctx.k, ctx.topo, ctx.pairing
         need_g, need_x, need_y, need_w = ctx.needs_input_grad[:4]
         c_x = c_x.contiguous() if c_x is not None else None
         c_y = c_y.contiguous() if c_y is not None else None
@@ -248,27 +259,27 @@ class _TPScatterBwdFn(torch.autograd.Function):
         gg = gxx = gyy = gww = None
         if need_g:
             if c_x is not None:
-                gg = add(gg, k.fwd(c_x, y, w, topo))
+                gg = add(gg, k.fwd(c_x, y, w, topo, pr))
             if c_y is not None:
-                gg = add(gg, k.fwd(x, c_y, w, topo))
+                gg = add(gg, k.fwd(x, c_y, w, topo, pr))
             if c_w is not None:
-                gg = add(gg, k.fwd(x, y, c_w, topo))
+                gg = add(gg, k.fwd(x, y, c_w, topo, pr))
         if need_x:
             if c_y is not None:
-                gxx = add(gxx, k.bwd_x(c_y, w, g, topo))
+                gxx = add(gxx, k.bwd_x(c_y, w, g, topo, pr))
             if c_w is not None:
-                gxx = add(gxx, k.bwd_x(y, c_w, g, topo))
+                gxx = add(gxx, k.bwd_x(y, c_w, g, topo, pr))
         if c_x is not None and (need_y or need_w):
             # one pass yields both Bw(c_x, y, g) and By(c_x, g, w)
-            a_w, a_y = k.bwd_edge(c_x, y, w, g, topo, need_gw=need_w, need_gy=need_y)
-            gww, gyy = add(gww, a_w), add(gyy, a_y)
+            a_w, a_y = k.bwd_edge(c_x, y, w, g, topo, need_gw=need_w, need_gy=need_y, pairing=pr)
+            gww, gyy = add(gww, _fold(a_w, pr)), add(gyy, a_y)
         if c_y is not None and need_w:
-            a_w, _ = k.bwd_edge(x, c_y, w, g, topo, need_gw=True, need_gy=False)
-            gww = add(gww, a_w)
+            a_w, _ = k.bwd_edge(x, c_y, w, g, topo, need_gw=True, need_gy=False, pairing=pr)
+            gww = add(gww, _fold(a_w, pr))
         if c_w is not None and need_y:
-            _, a_y = k.bwd_edge(x, y, c_w, g, topo, need_gw=False, need_gy=True)
+            _, a_y = k.bwd_edge(x, y, c_w, g, topo, need_gw=False, need_gy=True, pairing=pr)
             gyy = add(gyy, a_y)
-        return gg, gxx, gyy, gww, None, None, None
+        return gg, gxx, gyy, gww, None, None, None, None
 
 
 class TensorProductScatter(torch.nn.Module):
@@ -315,7 +326,9 @@ class TensorProductScatter(torch.nn.Module):
             self._kernels = k
         return k
 
-    def forward(self, x, edge_attr, edge_weight, edge_dst, edge_src, topology: Optional[EdgeTopology] = None):
+    def forward(self, x, edge_attr, edge_weight, edge_dst, edge_src, topology: Optional[EdgeTopology] = None,
+                pairing=None):
+        """``pairing`` (extension, ``EdgeTopology.pairing``): ``edge_weight`` has one row per reverse-edge pair."""
         if not x.is_cuda:
             raise RuntimeError(
                 "nequip_amd.nn.TensorProductScatter runs on the GPU only (HIP kernels); no CPU fallback exists"
@@ -326,6 +339,10 @@ class TensorProductScatter(torch.nn.Module):
         x = x.to(self.model_dtype)
         edge_attr = edge_attr.to(self.model_dtype)
         edge_weight = edge_weight.to(self.model_dtype)
+        if pairing is not None:
+            if topology is None:
+                topology = topology_cache.get(edge_dst, edge_src, x.size(0))
+            return _TPScatterFn.apply(x, edge_attr, edge_weight, self._get_kernels(), topology, pairing)
         if self.use_dispatcher_ops or torch.compiler.is_compiling():
             from ._tp_scatter_ops import tp_scatter
 

@@ -100,3 +100,36 @@ def test_paired_evaluation_matches_per_edge_evaluation(device, periodic, monkeyp
     if periodic:
         torch.testing.assert_close(out_p["stress"].detach(), out_e["stress"].detach(), rtol=0,
                                    atol=2e-6 * max(1e-3, float(out_e["stress"].abs().max())))
+
+
+@pytest.mark.gpu
+def test_paired_training_step_matches_per_edge(device, monkeypatch):
+    """Force-matching loss and all parameter gradients (double backward) with and without pairing."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn._topology import topology_cache
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=11)
+    model = NequIPGNNModel(seed=4, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
+                           avg_num_neighbors=30.0).to(device).train()
+    data = AtomicDataDict.to_device(syn.make_data(pos, types, 4.5, cell), device)
+    gen = torch.Generator().manual_seed(0)
+    f_t = torch.randn(len(pos), 3, generator=gen, dtype=torch.float64).to(device)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = model(dict(data))
+        loss = (out["forces"] - f_t).square().mean() + out["total_energy"].square().mean() / len(pos) ** 2
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    loss_p, grads_p = run()
+    monkeypatch.setenv("NQA_NO_PAIRED", "1")
+    topology_cache.clear()
+    loss_e, grads_e = run()
+    torch.testing.assert_close(loss_p, loss_e, rtol=1e-5, atol=1e-6)
+    for k in grads_e:
+        scale = max(1e-6, float(grads_e[k].abs().max()))
+        torch.testing.assert_close(grads_p[k], grads_e[k], rtol=0, atol=3e-4 * scale, msg=lambda m, k=k: f"{k}: {m}")
