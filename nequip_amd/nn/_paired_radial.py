@@ -72,13 +72,16 @@ def available(edge_mlp, tp_scatter, x: torch.Tensor, emb: torch.Tensor) -> bool:
     return tp_scatter._get_kernels().has_spec(torch.float32)
 
 
-def paired_radial_tp(edge_mlp, tp_scatter, emb, x, edge_attr, topo: EdgeTopology, pairing: EdgePairing):
-    """``tp_scatter(x, edge_attr, edge_mlp(emb), ...)`` with the MLP evaluated on the pairs' representative edges."""
+def paired_radial_tp(edge_mlp, tp_scatter, emb, x, edge_attr, topo: EdgeTopology, pairing: EdgePairing,
+                     emb_half=None):
+    """``tp_scatter(x, edge_attr, edge_mlp(emb), ...)`` with the MLP evaluated on the pairs' representative edges
+    (``emb_half = emb[pairing.rep_edge]``, shared by the layers of one evaluation when the caller passes it)."""
     cache = getattr(edge_mlp, "_weight_images", None)
     if cache is None:
         cache = edge_mlp._weight_images = _mlp._WeightImages()
     cache.validate(edge_mlp.mlp[2].weight)
-    emb_half = emb.index_select(0, pairing.rep_edge)
+    if emb_half is None:
+        emb_half = emb.index_select(0, pairing.rep_edge)
     if edge_mlp.training:
         # training: the per-module twice-differentiable Functions, on P rows instead of E (the weight gradient of the
         # pair is the sum of its two halves, folded inside the tensor-product backward)

@@ -84,6 +84,8 @@ class EdgeTopology:
         cached = getattr(self, "_pairing", None)
         if cached is not None and cached[0] == key:
             return cached[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None  # reading the verdict needs a synchronisation: not inside a hipGraph capture (not cached)
         result = None
         E = self.num_edges
         if E > 0 and E % 2 == 0 and os.environ.get("NQA_NO_PAIRED", "") in ("", "0"):

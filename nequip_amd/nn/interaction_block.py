@@ -116,8 +116,13 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             topo = topology_cache.get(edge_index[0], edge_index[1], x.size(0))
             pairing = topo.pairing(data.get(AtomicDataDict.EDGE_CELL_SHIFT_KEY))
         if pairing is not None:
+            # the representative rows of the embedding are the same for every layer: gathered once per evaluation
+            emb_half = data.get("_nqa_edge_embedding_pairs")
+            if emb_half is None or emb_half.shape[0] != pairing.num_pairs:
+                emb_half = emb.index_select(0, pairing.rep_edge)
+                data["_nqa_edge_embedding_pairs"] = emb_half
             x = _paired_radial.paired_radial_tp(
-                self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY], topo, pairing
+                self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY], topo, pairing, emb_half
             )[:num_local_nodes]
         else:
             x = self.tp_scatter(
