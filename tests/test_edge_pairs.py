@@ -133,3 +133,61 @@ def test_paired_training_step_matches_per_edge(device, monkeypatch):
     for k in grads_e:
         scale = max(1e-6, float(grads_e[k].abs().max()))
         torch.testing.assert_close(grads_p[k], grads_e[k], rtol=0, atol=3e-4 * scale, msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.gpu
+def test_paired_tp_kernels_match_expanded_weights(device):
+    """nqa_tp_scatter_*_paired with w = [P, W] against the plain entry points with the rows expanded to [E, W]:
+    identical outputs / feature and edge-attr gradients, weight gradient = the per-edge gradient scattered to rows
+    p / p + P."""
+    from nequip_amd.nn import TensorProductScatter
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=2)
+    data = syn.make_data(pos, types, 4.5, cell)
+    topo, pr = _pairing_of(data, device)
+    assert pr is not None
+    N, E, P = len(pos), data["edge_index"].shape[1], pr.num_pairs
+    from nequip_amd.model import NequIPGNNModel
+
+    model = NequIPGNNModel(seed=2, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
+                           avg_num_neighbors=30.0).to(device).eval()
+    tps = [m for m in model.modules() if isinstance(m, TensorProductScatter)][1]  # the middle layer's structure
+    k = tps._get_kernels()
+    assert k.has_spec(torch.float32)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, k.dim_in1, generator=g).to(device)
+    y = torch.randn(E, k.dim_in2, generator=g).to(device)
+    w_half = torch.randn(P, k.weight_numel, generator=g).to(device)
+    go = torch.randn(N, k.dim_out, generator=g).to(device)
+    rows = pr.rows.long()
+    w_full = w_half[rows % P].contiguous()
+
+    out_p, out_e = k.fwd(x, y, w_half, topo, pr), k.fwd(x, y, w_full, topo)
+    assert torch.equal(out_p, out_e)
+    gx_p, gx_e = k.bwd_x(y, w_half, go, topo, pr), k.bwd_x(y, w_full, go, topo)
+    assert torch.equal(gx_p, gx_e)
+    (G, gy_p), (gw_e, gy_e) = k.bwd_edge(x, y, w_half, go, topo, True, True, pairing=pr), k.bwd_edge(x, y, w_full, go, topo, True, True)
+    assert G.shape == (2 * P, k.weight_numel) and torch.equal(gy_p, gy_e) and torch.equal(G[rows], gw_e)
+    fx, fG, fy = k.bwd_fused(x, y, w_half, go, topo, pairing=pr)
+    ex, eG, ey = k.bwd_fused(x, y, w_full, go, topo)
+    assert torch.equal(fx, ex) and torch.equal(fy, ey) and torch.equal(fG[rows], eG)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E,H,W", [(1000, 128, 704), (77, 64, 64), (4133, 128, 192)])
+def test_paired_mlp_backward_adds_the_two_streams(device, E, H, W):
+    from nequip_amd.nn import mlp as M
+
+    torch.manual_seed(E)
+    mod = M.ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=1, hidden_layers_width=H).to(device).eval()
+    emb = (torch.randn(E, 8) * 0.7).to(device)
+    assert mod._fused_ok(emb)
+    ga, gb = torch.randn(E, W, device=device), torch.randn(E, W, device=device)
+    cache = M._WeightImages()
+    cache.validate(mod.mlp[2].weight)
+    args = (emb, mod.mlp[0].weight.detach(), mod.mlp[2].weight.detach(), mod._alphas[0], mod._alphas[1])
+    got = M._launch_bwd_paired(*args, ga, gb, M._lib.NQA_MLP_BF16X6, cache)
+    ref = M._launch_bwd(*args, (ga + gb).contiguous(), M._lib.NQA_MLP_BF16X6, cache)
+    assert torch.equal(got, ref)
