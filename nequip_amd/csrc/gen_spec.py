@@ -178,6 +178,7 @@ def _emit(st: Structure) -> str:
 
     # ------------------------------------------------------------------ forward
     A("template <typename T, int WPN>")
+    # (four wavefronts per SIMD would need 128 registers: 19-48 spills in the pipelined loop, measured 2.2x slower)
     A(f"__global__ {lb} void fwd_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -303,7 +304,14 @@ def _emit(st: Structure) -> str:
     # gy_j += w_p B^p_j.  FUSED additionally forms A^p_i = sum_jk C^p_ijk y_j g_k and emits the edge's contribution
     # w_p A^p_i to grad_x[src] (grad_out[dst] is already in registers), summed per source node afterwards.
     A("template <typename T, int WPN, bool FUSED, bool GW, bool GY>")
-    A("__global__ __launch_bounds__(256) void bwd_edge_kernel(const SpecArgs<T> a) {")  # (256, 2) spills here: slower
+    # l_max <= 2 structures sit at ~130 VGPRs: asking for four wavefronts per SIMD (128 registers) costs a couple of
+    # spills and buys a third more loads in flight; the big l_max = 3 structures spill heavily under any bound
+    # generator switch (build time): pipe3 = two operand sets at three wavefronts per SIMD (default; same-box cfg-3:
+    # fused backward 0.80 ms vs 0.86 for occ4 = plain loop at four wavefronts and 0.91 for plain = plain loop at three)
+    be_mode = os.environ.get("NQA_GEN_BWD_EDGE", "pipe3")
+    be_pipelined = (not big) and be_mode == "pipe3"
+    be_lb = "__launch_bounds__(256)" if (big or be_mode == "plain") else ("__launch_bounds__(256, 3)" if be_pipelined else "__launch_bounds__(256, 4)")
+    A(f"__global__ {be_lb} void bwd_edge_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
     A("  const int mul = a.mul;")
@@ -328,70 +336,102 @@ def _emit(st: Structure) -> str:
             A(f"    gv[{opre[s_] + k}] = act ? T({c!r}) * gb[(int64_t)mul * {opre[s_]} + (int64_t)u * {d3} + {k}] : T(0);")
     A("  }")
     L.extend(lane_offsets("  "))
+
+    def be_loads(sfx, e, sv, rg):
+        out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
+               f"      const T* __restrict__ yr = a.y + (int64_t){e} * kS;",
+               f"      const T* __restrict__ wr = a.w + (int64_t)spec_wrow_of(a, {rg}) * a.wn;"]
+        out += load_x("      ", "xr", sfx=sfx, decl=False)
+        out.append("      if (GY || FUSED) {")
+        out += load_w("        ", "wr", sfx=sfx, decl=False)
+        out.append("      }")
+        out.append("      if (GW || FUSED) {")
+        out += load_y("        ", "yr", sfx=sfx, decl=False)
+        out.append("      }")
+        out.append("    }")
+        return out
+
+    def be_compute(sfx, e, rg):
+        out = ["    {", "    T rr[kNP];", "    T q[kS];", "#pragma unroll", "    for (int j = 0; j < kS; ++j) q[j] = T(0);"]
+        for p, (b_, j, s_) in enumerate(st.instr):
+            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
+            d2 = 2 * l2 + 1
+            out.append(f"    {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b_}{sfx}, gv + {opre[s_]}, t);")
+            terms = " + ".join(f"t[{i}] * yb{j}{sfx}[{i}]" for i in range(d2))
+            out.append(f"      if (GW) rr[{p}] = {terms};")
+            out.append("      if (GY) {")
+            for i in range(d2):
+                out.append(f"        q[{ypre[j] + i}] += wv{sfx}[{p}] * t[{i}];")
+            out.append("      }")
+            out.append("    }")
+        out.append("    if (FUSED) {")
+        out.append("      T gxa[kXD];")
+        out.append("#pragma unroll")
+        out.append("      for (int i = 0; i < kXD; ++i) gxa[i] = T(0);")
+        for p, (b_, j, s_) in enumerate(st.instr):
+            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
+            d1 = 2 * l1 + 1
+            out.append(f"      {{ T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}{sfx}, gv + {opre[s_]}, t);")
+            for i in range(d1):
+                out.append(f"        gxa[{xpre[b_] + i}] += wv{sfx}[{p}] * t[{i}];")
+            out.append("      }")
+        out.append("      if (act) {")
+        out.append(f"        T* __restrict__ gxr = a.gxe + (int64_t){e} * a.din;")
+        for i in range(XD):
+            out.append(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = gxa[{i}];")
+        out.append("      }")
+        out.append("    }")
+        out.append("    if (GW) {")
+        out.append("      if (act) {")
+        out.append(f"        T* __restrict__ gwr = a.gw + (int64_t){rg} * a.wn;")
+        for p in range(NP):
+            out.append(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
+        out.append("      }")
+        out.append("    }")
+        out.append("    if (GY) {")
+        out.append(f"      T* __restrict__ gyr = a.gy + (int64_t){e} * a.gy_stride + chunk * kS;")
+        out.append("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")
+        out.append("    }")
+        out.append("    }")
+        return out
+
     A("  int idx = beg + wsub;")
-    A("  int e = spec_uniform(a.eid[idx]), s = spec_uniform(a.nbr[idx]);")
-    A("  int rg = spec_gwrow(a, idx);  // row of grad_w written by this edge; its weights are row spec_wrow_of(a, rg)")
-    A("  while (idx < end) {")
-    A("    const int nidx = idx + WPN;")
-    A("    int e_n = 0, s_n = 0, rg_n = 0;")
-    A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); rg_n = spec_gwrow(a, nidx); }")
-    A("    const T* __restrict__ xr = a.x + (int64_t)s * a.din;")
-    A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
-    A("    const T* __restrict__ wr = a.w + (int64_t)spec_wrow_of(a, rg) * a.wn;")
-    L.extend(load_x("    ", "xr"))
-    A("    T wv[kNP];")
-    A("    if (GY || FUSED) {")
-    L.extend(load_w("      ", "wr", decl=False))
-    A("    }")
-    L.extend(decl_y("    "))
-    A("    if (GW || FUSED) {")
-    L.extend(load_y("      ", "yr", decl=False))
-    A("    }")
-    A("    T rr[kNP];")
-    A("    T q[kS];")
-    A("#pragma unroll")
-    A("    for (int j = 0; j < kS; ++j) q[j] = T(0);")
-    for p, (b, j, s_) in enumerate(st.instr):
-        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s_]
-        d2 = 2 * l2 + 1
-        A(f"    {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b}, gv + {opre[s_]}, t);")
-        terms = " + ".join(f"t[{i}] * yb{j}[{i}]" for i in range(d2))
-        A(f"      if (GW) rr[{p}] = {terms};")
-        A("      if (GY) {")
-        for i in range(d2):
-            A(f"        q[{ypre[j] + i}] += wv[{p}] * t[{i}];")
-        A("      }")
+    if be_pipelined:
+        A("  // Two operand sets (A/B) as in the forward kernel: the rows of edge i+1 are requested before edge i is")
+        A("  // evaluated and its gradients stored, so every wavefront keeps two edges' worth of loads in flight.")
+        L.extend(["  T wvA[kNP], wvB[kNP];"] + decl_x("  ", "A") + decl_x("  ", "B") + decl_y("  ", "A") + decl_y("  ", "B"))
+        A("  int e0 = spec_uniform(a.eid[idx]), s0 = spec_uniform(a.nbr[idx]), r0 = spec_gwrow(a, idx);")
+        A("  int e1 = 0, s1 = 0, r1 = 0;")
+        L.extend(be_loads("A", "e0", "s0", "r0"))
+        A("  while (idx < end) {")
+        A("    int nidx = idx + WPN;")
+        A("    if (nidx < end) {")
+        A("      e1 = spec_uniform(a.eid[nidx]); s1 = spec_uniform(a.nbr[nidx]); r1 = spec_gwrow(a, nidx);")
+        L.extend(be_loads("B", "e1", "s1", "r1"))
         A("    }")
-    A("    if (FUSED) {")
-    A("      T gxa[kXD];")
-    A("#pragma unroll")
-    A("      for (int i = 0; i < kXD; ++i) gxa[i] = T(0);")
-    for p, (b, j, s_) in enumerate(st.instr):
-        l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s_]
-        d1 = 2 * l1 + 1
-        A(f"      {{ T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}, gv + {opre[s_]}, t);")
-        for i in range(d1):
-            A(f"        gxa[{xpre[b] + i}] += wv[{p}] * t[{i}];")
-        A("      }")
-    A("      if (act) {")
-    A("        T* __restrict__ gxr = a.gxe + (int64_t)e * a.din;")
-    for i in range(XD):
-        A(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = gxa[{i}];")
-    A("      }")
-    A("    }")
-    A("    if (GW) {")
-    A("      if (act) {")
-    A("        T* __restrict__ gwr = a.gw + (int64_t)rg * a.wn;")
-    for p in range(NP):
-        A(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
-    A("      }")
-    A("    }")
-    A("    if (GY) {")
-    A("      T* __restrict__ gyr = a.gy + (int64_t)e * a.gy_stride + chunk * kS;")
-    A("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")
-    A("    }")
-    A("    idx = nidx; e = e_n; s = s_n; rg = rg_n;")
-    A("  }")
+        L.extend(be_compute("A", "e0", "r0"))
+        A("    idx = nidx;")
+        A("    if (idx >= end) break;")
+        A("    nidx = idx + WPN;")
+        A("    if (nidx < end) {")
+        A("      e0 = spec_uniform(a.eid[nidx]); s0 = spec_uniform(a.nbr[nidx]); r0 = spec_gwrow(a, nidx);")
+        L.extend(be_loads("A", "e0", "s0", "r0"))
+        A("    }")
+        L.extend(be_compute("B", "e1", "r1"))
+        A("    idx = nidx;")
+        A("  }")
+    else:
+        L.extend(["  T wvA[kNP];"] + decl_x("  ", "A") + decl_y("  ", "A"))
+        A("  int e = spec_uniform(a.eid[idx]), s = spec_uniform(a.nbr[idx]);")
+        A("  int rg = spec_gwrow(a, idx);  // row of grad_w written by this edge; its weights are row spec_wrow_of(a, rg)")
+        A("  while (idx < end) {")
+        A("    const int nidx = idx + WPN;")
+        A("    int e_n = 0, s_n = 0, rg_n = 0;")
+        A("    if (nidx < end) { e_n = spec_uniform(a.eid[nidx]); s_n = spec_uniform(a.nbr[nidx]); rg_n = spec_gwrow(a, nidx); }")
+        L.extend(be_loads("A", "e", "s", "rg"))
+        L.extend(be_compute("A", "e", "rg"))
+        A("    idx = nidx; e = e_n; s = s_n; rg = rg_n;")
+        A("  }")
     A("}")
 
     # ------------------------------------------------------------------ backward (node features)
