@@ -336,6 +336,13 @@ int64_t nqa_edge_pairs_workspace_bytes(int64_t num_edges);
 int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void* edge_cell_shift, int32_t shift_dtype,
                    int64_t num_edges, int64_t num_nodes, void* workspace, int64_t workspace_bytes,
                    int32_t* weight_rows, int64_t* rep_edge, int32_t* ok, nqa_stream stream);
+/* nqa_pair_gather: rows_out[p, :] = rows_in[rep_edge[p], :] (the per-pair rows of a per-edge float32 array, e.g. the
+ *   edge embedding fed to the radial MLP); nqa_pair_expand is its adjoint: edge_rows[e, :] = pair_rows[weight_rows[e], :]
+ *   for representative edges and 0 for the reverse ones (every row written).  width = 32-bit words per row. */
+int nqa_pair_gather(const void* rows_in, const int64_t* rep_edge, int64_t num_pairs, int32_t width, void* rows_out,
+                    nqa_stream stream);
+int nqa_pair_expand(const void* pair_rows, const int32_t* weight_rows, int64_t num_edges, int64_t num_pairs,
+                    int32_t width, void* edge_rows, nqa_stream stream);
 int nqa_tp_scatter_fwd_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
                               const void* w, const int32_t* rowptr_dst, const int32_t* edge_id_dst,
                               const int32_t* src_sorted, void* out, int64_t num_nodes, int64_t num_edges,

@@ -83,6 +83,8 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
          c_void_p],
     ),
+    "nqa_pair_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "nqa_pair_expand": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nqa_tp_scatter_fwd_paired": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -104,6 +104,29 @@ __global__ __launch_bounds__(256) void edge_pairs_assign_kernel(const int64_t* _
   rep_edge[p] = (int64_t)rep;
 }
 
+// out[p, :] = src[rep_edge[p], :]  (rows of `width` 32-bit words)
+__global__ __launch_bounds__(256) void pair_gather_kernel(const uint32_t* __restrict__ src,
+                                                          const int64_t* __restrict__ rep_edge, int64_t P, int width,
+                                                          uint32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * width) return;
+  const int64_t p = i / width;
+  const int c = (int)(i - p * width);
+  out[i] = src[rep_edge[p] * width + c];
+}
+
+// adjoint: out[e, :] = weight_rows[e] < P ? g[weight_rows[e], :] : 0   (every row of out is written: no memset)
+__global__ __launch_bounds__(256) void pair_expand_kernel(const uint32_t* __restrict__ g,
+                                                          const int32_t* __restrict__ weight_rows, int64_t E, int64_t P,
+                                                          int width, uint32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E * width) return;
+  const int64_t e = i / width;
+  const int c = (int)(i - e * width);
+  const int32_t r = weight_rows[e];
+  out[i] = r < P ? g[(int64_t)r * width + c] : 0u;
+}
+
 static size_t ep_cub_bytes(int64_t E) {
   size_t bytes = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
@@ -178,6 +201,45 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_edge_pairs: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_pair_gather(const void* rows_in, const int64_t* rep_edge, int64_t num_pairs, int32_t width, void* rows_out,
+                    nqa_stream stream) {
+  if (num_pairs < 0 || width <= 0 || (num_pairs > 0 && (!rows_in || !rep_edge || !rows_out))) {
+    set_error("nqa_pair_gather: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  if (num_pairs == 0) return NQA_OK;
+  const int64_t n = num_pairs * width;
+  hipLaunchKernelGGL(pair_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(rows_in), rep_edge, num_pairs,
+                     width, static_cast<uint32_t*>(rows_out));
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_pair_gather: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_pair_expand(const void* pair_rows, const int32_t* weight_rows, int64_t num_edges, int64_t num_pairs,
+                    int32_t width, void* edge_rows, nqa_stream stream) {
+  if (num_edges < 0 || num_pairs < 0 || width <= 0 ||
+      (num_edges > 0 && (!weight_rows || !edge_rows || (num_pairs > 0 && !pair_rows)))) {
+    set_error("nqa_pair_expand: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  if (num_edges == 0) return NQA_OK;
+  const int64_t n = num_edges * width;
+  hipLaunchKernelGGL(pair_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(pair_rows), weight_rows, num_edges,
+                     num_pairs, width, static_cast<uint32_t*>(edge_rows));
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_pair_expand: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

@@ -59,6 +59,52 @@ class _PairedRadialTPFn(torch.autograd.Function):
         return (g_emb, gx, gy) + (None,) * 9
 
 
+class _PairRowsFn(torch.autograd.Function):
+    """``emb[pairing.rep_edge]`` (``nqa_pair_gather``); backward: the per-pair gradient goes to the representative edge,
+    zero to its reverse (``nqa_pair_expand``).  Differentiable again (the two maps are adjoint, both linear)."""
+
+    @staticmethod
+    def forward(ctx, emb, pairing: EdgePairing):
+        from ._topology import _ptr, current_stream_ptr
+
+        emb = emb.contiguous()
+        assert emb.dim() == 2 and emb.element_size() == 4
+        out = torch.empty((pairing.num_pairs, emb.shape[1]), dtype=emb.dtype, device=emb.device)
+        with torch.cuda.device(emb.device):
+            rc = _lib.load().nqa_pair_gather(_ptr(emb), _ptr(pairing.rep_edge), pairing.num_pairs, emb.shape[1],
+                                             _ptr(out), current_stream_ptr(emb.device))
+        _lib.check(rc, "nqa_pair_gather")
+        ctx.pairing, ctx.num_edges = pairing, emb.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PairExpandFn.apply(g, ctx.pairing, ctx.num_edges), None
+
+
+class _PairExpandFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, pairing: EdgePairing, num_edges: int):
+        from ._topology import _ptr, current_stream_ptr
+
+        g = g.contiguous()
+        out = torch.empty((num_edges, g.shape[1]), dtype=g.dtype, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().nqa_pair_expand(_ptr(g), _ptr(pairing.rows), num_edges, pairing.num_pairs, g.shape[1],
+                                             _ptr(out), current_stream_ptr(g.device))
+        _lib.check(rc, "nqa_pair_expand")
+        ctx.pairing = pairing
+        return out
+
+    @staticmethod
+    def backward(ctx, c):
+        return _PairRowsFn.apply(c, ctx.pairing), None, None
+
+
+def pair_rows(emb: torch.Tensor, pairing: EdgePairing) -> torch.Tensor:
+    return _PairRowsFn.apply(emb, pairing)
+
+
 def available(edge_mlp, tp_scatter, x: torch.Tensor, emb: torch.Tensor) -> bool:
     """float32 GPU evaluation with the fused split-bf16 MLP and structure-specialised TP kernels."""
     if not x.is_cuda or x.dtype != torch.float32 or emb.dtype != torch.float32:
@@ -81,7 +127,7 @@ def paired_radial_tp(edge_mlp, tp_scatter, emb, x, edge_attr, topo: EdgeTopology
         cache = edge_mlp._weight_images = _mlp._WeightImages()
     cache.validate(edge_mlp.mlp[2].weight)
     if emb_half is None:
-        emb_half = emb.index_select(0, pairing.rep_edge)
+        emb_half = pair_rows(emb, pairing)
     if edge_mlp.training:
         # training: the per-module twice-differentiable Functions, on P rows instead of E (the weight gradient of the
         # pair is the sum of its two halves, folded inside the tensor-product backward)

@@ -83,13 +83,15 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         num_local_nodes = AtomicDataDict.num_nodes(data)
         x = data[AtomicDataDict.NODE_FEATURES_KEY]
-        if not self.is_first_layer:
+        # (`[:num_local_nodes]` as in the reference, interaction_block.py:166-168,199 -- only when there are ghost rows:
+        # a no-op slice still records a SliceBackward whose backward is a zero fill + copy of the whole gradient)
+        if not self.is_first_layer and x.shape[0] != num_local_nodes:
             x = x[:num_local_nodes]
 
         sc = None
         if self.sc is not None:
             node_attrs = data[AtomicDataDict.NODE_ATTRS_KEY]
-            if not self.is_first_layer:
+            if not self.is_first_layer and node_attrs.shape[0] != num_local_nodes:
                 node_attrs = node_attrs[:num_local_nodes]
             table = data.get("_nqa_node_attrs_table")
             if table is not None and table.shape[0] <= 16:
@@ -119,11 +121,11 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             # the representative rows of the embedding are the same for every layer: gathered once per evaluation
             emb_half = data.get("_nqa_edge_embedding_pairs")
             if emb_half is None or emb_half.shape[0] != pairing.num_pairs:
-                emb_half = emb.index_select(0, pairing.rep_edge)
+                emb_half = _paired_radial.pair_rows(emb, pairing)
                 data["_nqa_edge_embedding_pairs"] = emb_half
             x = _paired_radial.paired_radial_tp(
                 self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY], topo, pairing, emb_half
-            )[:num_local_nodes]
+            )
         else:
             x = self.tp_scatter(
                 x=x,
@@ -131,7 +133,9 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
                 edge_weight=self.edge_mlp(emb),
                 edge_dst=edge_index[0],
                 edge_src=edge_index[1],
-            )[:num_local_nodes]
+            )
+        if x.shape[0] != num_local_nodes:
+            x = x[:num_local_nodes]
 
         # linear_2 with the residual `+ sc` fused into the same launch
         x = self.linear_2(x, addend=sc if self.sc is not None else None)
