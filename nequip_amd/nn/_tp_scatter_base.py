@@ -55,7 +55,10 @@ class _Kernels:
 
     def has_spec(self, dtype: torch.dtype) -> bool:
         """Structure-specialised kernels available (float32, uniform-mul NequIP shapes)?"""
-        return _lib.load().nqa_tp_bwd_fused_workspace_bytes(self.plan.handle, _nqa_dtype(dtype), 0) >= 0
+        cache = self.__dict__.setdefault("_has_spec", {})
+        if dtype not in cache:
+            cache[dtype] = _lib.load().nqa_tp_bwd_fused_workspace_bytes(self.plan.handle, _nqa_dtype(dtype), 0) >= 0
+        return cache[dtype]
 
     def _check(self, x, y, w, topo: EdgeTopology, pairing=None):
         N, E = topo.num_nodes, topo.num_edges
