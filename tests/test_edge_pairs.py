@@ -7,6 +7,17 @@ import pytest
 import torch
 
 
+@pytest.fixture(autouse=True)
+def default_switches(monkeypatch):
+    """These tests assert that the paired path IS taken: run them with the switches that disable it at their defaults."""
+    import os
+
+    if os.environ.get("NQA_FORCE_GENERIC", "") not in ("", "0"):
+        pytest.skip("NQA_FORCE_GENERIC is read once per process by the library: no specialised kernels, no pairing")
+    monkeypatch.delenv("NQA_NO_PAIRED", raising=False)
+    monkeypatch.delenv("NQA_MLP_EXACT_FP32", raising=False)
+
+
 def _pairing_of(data, device):
     from nequip_amd.nn._topology import EdgeTopology
 
