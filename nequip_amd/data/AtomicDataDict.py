@@ -12,7 +12,14 @@ Type = Dict[str, torch.Tensor]
 
 
 def num_nodes(data: Type) -> int:
-    return data[_keys.POSITIONS_KEY].size(0)
+    # edge-vector based callers (LAMMPS ML-IAP) pass no positions (nequip/data/AtomicDataDict.py:252-262)
+    if _keys.POSITIONS_KEY in data:
+        return data[_keys.POSITIONS_KEY].size(0)
+    if _keys.ATOM_TYPE_KEY in data:
+        return data[_keys.ATOM_TYPE_KEY].size(0)
+    raise RuntimeError(
+        f"No basic input node variable found, expecting either {_keys.POSITIONS_KEY} or {_keys.ATOM_TYPE_KEY}"
+    )
 
 
 def num_edges(data: Type) -> int:

@@ -191,3 +191,31 @@ def test_no_edges(device, periodic):
         assert float(out[K.VIRIAL_KEY].abs().max()) == 0.0
     single = [_eval(model, pos[i : i + 1], types[i : i + 1], device, cell)[K.TOTAL_ENERGY_KEY].item() for i in range(3)]
     assert abs(sum(single) - out[K.TOTAL_ENERGY_KEY].item()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_edge_vector_inputs_give_edge_forces(device):
+    """LAMMPS ML-IAP style call (nequip/nn/grad_output.py:276-296, lmp_mliap_wrapper.py:202-233): edge vectors instead
+    of positions in, `edge_forces = dE/d edge_vectors` out (no sign flip).  Consistency with the position path:
+    same energy, and the edge forces scattered onto the two atoms of every edge give the forces."""
+    from nequip_amd.data import AtomicDataDict as K
+
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, names = _molecule(seed=5, n=20)
+    data = syn.make_data(pos, types, 4.0, None, pbc=False)
+    model = _model(device, names)
+    ref = model(K.to_device(dict(data), device))
+    ei = data[K.EDGE_INDEX_KEY]
+    P = data[K.POSITIONS_KEY]
+    edge_vec = (P[ei[1]] - P[ei[0]]).to(device)
+    out = model({K.EDGE_VECTORS_KEY: edge_vec, K.EDGE_INDEX_KEY: ei.to(device), K.ATOM_TYPE_KEY: data[K.ATOM_TYPE_KEY].to(device)})
+    assert K.EDGE_FORCE_KEY in out and K.FORCE_KEY not in out
+    torch.testing.assert_close(out[K.TOTAL_ENERGY_KEY].detach(), ref[K.TOTAL_ENERGY_KEY].detach(), rtol=1e-6, atol=1e-5)
+    ef = out[K.EDGE_FORCE_KEY].detach().double()
+    assert ef.shape == edge_vec.shape
+    grad_pos = torch.zeros_like(ref[K.FORCE_KEY].detach().double())
+    grad_pos.index_add_(0, ei[1].to(device), ef)
+    grad_pos.index_add_(0, ei[0].to(device), -ef)
+    f_ref = ref[K.FORCE_KEY].detach().double()
+    torch.testing.assert_close(-grad_pos, f_ref, rtol=0, atol=2e-5 * max(1.0, float(f_ref.abs().max())))
