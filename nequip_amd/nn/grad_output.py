@@ -7,6 +7,7 @@ import torch
 from ..data import AtomicDataDict
 from ..utils.wgrad import inputs_only_backward
 from ._graph_mixin import GraphModuleMixin
+from .model_modifier_utils import model_modifier, replace_submodules
 
 
 class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
@@ -88,6 +89,19 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         if not did_pos_req_grad:
             pos.requires_grad_(False)
         return data
+
+    # the reference's persistent modifiers of this class (nequip/nn/grad_output.py:300-320)
+    @model_modifier(persistent=True, private=False)
+    @classmethod
+    def enable_ForceStressOutput(cls, model):
+        """Enable force and stress computation."""
+        return replace_submodules(model, cls, lambda old: cls(func=old.func, do_derivatives=True))
+
+    @model_modifier(persistent=True, private=False)
+    @classmethod
+    def disable_ForceStressOutput(cls, model):
+        """Disable force and stress computation."""
+        return replace_submodules(model, cls, lambda old: cls(func=old.func, do_derivatives=False))
 
     def _forward_inference(self, data, pos, batch, num_batch: int, has_cell: bool):
         """First-order (eval mode) evaluation of the same quantities without the strain bookkeeping.
