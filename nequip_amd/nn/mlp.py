@@ -271,7 +271,6 @@ class ScalarLinearLayer(torch.nn.Module):
     def __init__(self, in_features: int, out_features: int, alpha: float = 1.0, bias: bool = False,
                  init_mode: str = "uniform") -> None:
         super().__init__()
-        assert not bias, "the hot-path MLPs are bias-free (nequip/nn/interaction_block.py:125)"
         self.in_features = in_features
         self.out_features = out_features
         self.register_buffer("alpha", torch.tensor(alpha), persistent=False)
@@ -281,10 +280,17 @@ class ScalarLinearLayer(torch.nn.Module):
         elif init_mode == "normal":
             torch.nn.init.normal_(self.weight, mean=0.0, std=1.0)
         else:
-            raise ValueError(f"Unknown init_mode: {init_mode}")
+            raise ValueError(f"Unknown init_mode: {init_mode}. Must be 'uniform' or 'normal'.")
+        # bias (zeros) as in the reference (mlp.py:252-256); the hot-path MLPs are bias-free (interaction_block.py:125)
+        if bias:
+            self.bias = torch.nn.Parameter(torch.zeros(out_features))
+        else:
+            self.register_parameter("bias", None)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         w = self.weight * self.alpha
+        if self.bias is not None:
+            return torch.addmm(self.bias, input, w)
         if self.out_features == 1 and self.training and input.is_cuda:
             # single-column layer (the per-atom energy readout): its weight-side backward as a library GEMM is a
             # [in, N] x [N, 1] product that runs on one workgroup (0.12 ms at 8k atoms); as multiply + row sum both
@@ -293,7 +299,8 @@ class ScalarLinearLayer(torch.nn.Module):
         return torch.mm(input, w)
 
     def extra_repr(self) -> str:
-        return f"in_features={self.in_features}, out_features={self.out_features}, alpha={float(self.alpha):.6f}"
+        return (f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, "
+                f"alpha={float(self.alpha):.6f}")
 
 
 class ScalarMLPFunction(torch.nn.Module):
@@ -305,6 +312,7 @@ class ScalarMLPFunction(torch.nn.Module):
         assert forward_weight_init
         if hidden_layers_depth != 0:
             assert hidden_layers_depth > 0 and hidden_layers_width > 0
+        self.has_bias = bool(bias)
         self.dims = [input_dim] + hidden_layers_depth * [hidden_layers_width] + [output_dim]
         self.num_layers = len(self.dims) - 1
         self.is_nonlinear = False
@@ -318,7 +326,7 @@ class ScalarMLPFunction(torch.nn.Module):
         self.mlp = mlp
 
     def _fused_ok(self, x: torch.Tensor) -> bool:
-        if not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear:
+        if not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear or self.has_bias:
             return False
         ok = getattr(self, "_fused_supported", None)
         if ok is None:
