@@ -1,31 +1,57 @@
-"""Field names of the ``AtomicDataDict`` data model -- the same strings as the reference
-(``nequip/data/_keys.py:12-115``) so that data dicts are interchangeable with nequip's."""
+"""Field names of the ``AtomicDataDict`` data model.
 
-from typing import Final
+The *strings* are the reference's (``nequip/data/_keys.py:12-115``): data dicts built for nequip can be fed to these
+modules and vice versa.  Only the fields the hot path reads or writes are listed, grouped by who produces them; each
+group is one table ``CONSTANT_NAME -> field string`` that is exported into the module namespace below.
+"""
 
-POSITIONS_KEY: Final[str] = "pos"
-ATOM_TYPE_KEY: Final[str] = "atom_types"
-EDGE_INDEX_KEY: Final[str] = "edge_index"  # [0] = dst (centre), [1] = src (neighbour)
-EDGE_TRANSPOSE_PERM_KEY: Final[str] = "edge_transpose_perm"
-CELL_KEY: Final[str] = "cell"
-EDGE_CELL_SHIFT_KEY: Final[str] = "edge_cell_shift"
-BATCH_KEY: Final[str] = "batch"
-NUM_NODES_KEY: Final[str] = "num_atoms"
-PBC_KEY: Final[str] = "pbc"
-EDGE_VECTORS_KEY: Final[str] = "edge_vectors"
-EDGE_LENGTH_KEY: Final[str] = "edge_lengths"
-NORM_LENGTH_KEY: Final[str] = "normed_edge_lengths"
-EDGE_TYPE_KEY: Final[str] = "edge_type_flat"
-EDGE_CUTOFF_KEY: Final[str] = "edge_cutoff"
-EDGE_ATTRS_KEY: Final[str] = "edge_attrs"
-EDGE_EMBEDDING_KEY: Final[str] = "edge_embedding"
-NODE_ATTRS_KEY: Final[str] = "node_attrs"
-NODE_FEATURES_KEY: Final[str] = "node_features"
-FEATURE_NORM_FACTOR_KEY: Final[str] = "feature_norm_factor"
-PER_ATOM_ENERGY_KEY: Final[str] = "atomic_energy"
-TOTAL_ENERGY_KEY: Final[str] = "total_energy"
-FORCE_KEY: Final[str] = "forces"
-EDGE_FORCE_KEY: Final[str] = "edge_forces"
-STRESS_KEY: Final[str] = "stress"
-VIRIAL_KEY: Final[str] = "virial"
-LMP_MLIAP_DATA_KEY: Final[str] = "lmp_mliap_data"
+from typing import Dict
+
+# what the caller provides: geometry, species, graph (row 0 of edge_index = convolution centre / destination,
+# row 1 = neighbour / source), frame bookkeeping of a batch
+_INPUTS: Dict[str, str] = dict(
+    POSITIONS_KEY="pos",
+    ATOM_TYPE_KEY="atom_types",
+    CELL_KEY="cell",
+    PBC_KEY="pbc",
+    EDGE_INDEX_KEY="edge_index",
+    EDGE_CELL_SHIFT_KEY="edge_cell_shift",
+    EDGE_TRANSPOSE_PERM_KEY="edge_transpose_perm",
+    BATCH_KEY="batch",
+    NUM_NODES_KEY="num_atoms",
+    LMP_MLIAP_DATA_KEY="lmp_mliap_data",
+)
+
+# per-edge quantities written by the embedding modules (an edge-vector based caller provides `edge_vectors` itself)
+_EDGE_FIELDS: Dict[str, str] = dict(
+    EDGE_VECTORS_KEY="edge_vectors",
+    EDGE_LENGTH_KEY="edge_lengths",
+    NORM_LENGTH_KEY="normed_edge_lengths",
+    EDGE_TYPE_KEY="edge_type_flat",
+    EDGE_CUTOFF_KEY="edge_cutoff",
+    EDGE_ATTRS_KEY="edge_attrs",
+    EDGE_EMBEDDING_KEY="edge_embedding",
+)
+
+# per-node quantities flowing through the convolution layers
+_NODE_FIELDS: Dict[str, str] = dict(
+    NODE_ATTRS_KEY="node_attrs",
+    NODE_FEATURES_KEY="node_features",
+    FEATURE_NORM_FACTOR_KEY="feature_norm_factor",
+)
+
+# model outputs
+_OUTPUTS: Dict[str, str] = dict(
+    PER_ATOM_ENERGY_KEY="atomic_energy",
+    TOTAL_ENERGY_KEY="total_energy",
+    FORCE_KEY="forces",
+    EDGE_FORCE_KEY="edge_forces",
+    STRESS_KEY="stress",
+    VIRIAL_KEY="virial",
+)
+
+ALL_KEYS: Dict[str, str] = {**_INPUTS, **_EDGE_FIELDS, **_NODE_FIELDS, **_OUTPUTS}
+assert len(set(ALL_KEYS.values())) == len(ALL_KEYS), "field strings must be unique"
+globals().update(ALL_KEYS)
+
+__all__ = sorted(ALL_KEYS)

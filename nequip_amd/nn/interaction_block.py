@@ -20,6 +20,22 @@ from .mlp import ScalarMLPFunction
 from .norm import AvgNumNeighborsNorm
 
 
+def uvu_paths(features_in: Irreps, edge_attr: Irreps, features_out: Irreps):
+    """The 'uvu' paths of one convolution and the irreps they produce (semantics of
+    ``nequip/nn/interaction_block.py:89-109``): every (input block a, edge-attr block b) pair contributes one path per
+    irrep of ``ir_a x ir_b`` that the layer's output wants; each path gets its own output slot with the input block's
+    multiplicity.  The slots are then ordered like ``Irreps.sort()`` (so that ``linear_2`` can simplify them), while
+    the paths -- and with them the columns of the radial MLP's output -- keep their creation order.
+
+    Returns ``(irreps_mid sorted, [(a, b, slot, "uvu", True), ...])``."""
+    created = []
+    for a, (mul, ir_a) in enumerate(features_in):
+        for b, (_, ir_b) in enumerate(edge_attr):
+            created.extend((a, b, (mul, ir)) for ir in ir_a * ir_b if ir in features_out)
+    mid_sorted, slot_of, _ = Irreps([blk for _, _, blk in created]).sort()
+    return mid_sorted, [(a, b, slot_of[n], "uvu", True) for n, (a, b, _) in enumerate(created)]
+
+
 class InteractionBlock(GraphModuleMixin, torch.nn.Module):
     use_sc: bool
 
@@ -45,19 +61,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
 
         self.linear_1 = Linear(irreps_in=feature_irreps_in, irreps_out=feature_irreps_in)
 
-        # instruction list exactly as nequip/nn/interaction_block.py:89-109
-        irreps_mid = []
-        instructions = []
-        for i, (mul, ir_in) in enumerate(feature_irreps_in):
-            for j, (_, ir_edge) in enumerate(irreps_edge_attr):
-                for ir_out in ir_in * ir_edge:
-                    if ir_out in feature_irreps_out:
-                        k = len(irreps_mid)
-                        irreps_mid.append((mul, ir_out))
-                        instructions.append((i, j, k, "uvu", True))
-        irreps_mid = Irreps(irreps_mid)
-        irreps_mid, p, _ = irreps_mid.sort()
-        instructions = [(i_in1, i_in2, p[i_out], mode, train) for i_in1, i_in2, i_out, mode, train in instructions]
+        irreps_mid, instructions = uvu_paths(feature_irreps_in, irreps_edge_attr, feature_irreps_out)
 
         self.tp_scatter = TensorProductScatter(feature_irreps_in, irreps_edge_attr, irreps_mid, instructions)
 
