@@ -240,13 +240,20 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # NQA_BENCH_SHARE_DEVICE=1 (testing the N > 1 control flow on a one-GPU box): every rank uses device 0 and the
+    # barriers / max-reduction go over gloo, since RCCL refuses two ranks on one device.  Not a measurement mode.
+    share = distributed and os.environ.get("NQA_BENCH_SHARE_DEVICE", "") not in ("", "0")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from nequip_amd.data import AtomicDataDict
     from nequip_amd.nn import topology_cache
