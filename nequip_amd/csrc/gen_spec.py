@@ -67,7 +67,9 @@ def nequip_structure(feature_irreps_in: str, lmax_sh: int, feature_irreps_out: s
     return Structure([ir.l for _, ir in f_in], [ir.l for _, ir in e_at], [ir.l for _, ir in mid_sorted], ins, name)
 
 
-def baseline_structures() -> List[Structure]:
+def baseline_irreps() -> List[Tuple[str, str, int, str]]:
+    """(name, feature_irreps_in, lmax_sh, feature_irreps_out) of every prebuilt structure, with ``1x`` multiplicities
+    (the kernels take ``mul`` at run time; tests substitute 32 / 64 / 128)."""
     out = []
     for lmax in (1, 2, 3):
         for parity in (False, True):
@@ -78,22 +80,26 @@ def baseline_structures() -> List[Structure]:
             )
             tag = f"l{lmax}{'p' if parity else 'n'}"
             # conv output irreps = scalars (+ gate scalars) + gated, simplified -> same set of (l,p) as hidden
-            first = nequip_structure("1x0e", lmax, hidden, f"{tag}_first")
-            out.append(first)
+            out.append((f"{tag}_first", "1x0e", lmax, hidden))
             if parity:
                 # second layer of a parity model sees only what layer 0 could produce: 0e, 1o, 2e, ...
                 reach = "+".join(f"1x{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lmax + 1))
-                out.append(nequip_structure(reach, lmax, hidden, f"{tag}_second"))
+                out.append((f"{tag}_second", reach, lmax, hidden))
                 # layer >= 2 input = what the second layer produced (every hidden irrep reachable from `reach`)
-                out.append(nequip_structure(hidden, lmax, hidden, f"{tag}_mid"))
-                out.append(nequip_structure(hidden, lmax, "1x0e", f"{tag}_last"))
-                out.append(nequip_structure(reach, lmax, "1x0e", f"{tag}_last2"))
+                out.append((f"{tag}_mid", hidden, lmax, hidden))
+                out.append((f"{tag}_last", hidden, lmax, "1x0e"))
+                out.append((f"{tag}_last2", reach, lmax, "1x0e"))
             else:
-                out.append(nequip_structure(hidden, lmax, hidden, f"{tag}_mid"))
-                out.append(nequip_structure(hidden, lmax, "1x0e", f"{tag}_last"))
+                out.append((f"{tag}_mid", hidden, lmax, hidden))
+                out.append((f"{tag}_last", hidden, lmax, "1x0e"))
+    return out
+
+
+def baseline_structures() -> List[Structure]:
     # de-duplicate by key
     seen, uniq = set(), []
-    for s in out:
+    for name, f_in, lmax, f_out in baseline_irreps():
+        s = nequip_structure(f_in, lmax, f_out, name)
         if s.key() not in seen and s.instr:
             seen.add(s.key())
             uniq.append(s)

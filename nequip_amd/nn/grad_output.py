@@ -130,7 +130,7 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         data[K.EDGE_VECTORS_KEY] = edge_vec
         data = self.func(data)
         with inputs_only_backward():
-            g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].contiguous()
+            g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].to(torch.float64).contiguous()
         num_nodes = pos.shape[0]
         topo = topology_cache.get(edge_index[0], edge_index[1], num_nodes)
         rp_d, eid_d, _ = topo.by_dst
@@ -140,7 +140,7 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         part = torch.empty((num_nodes, 9), dtype=torch.float64, device=pos.device)
         virial = torch.empty((num_batch, 3, 3), dtype=torch.float64, device=pos.device)
         stress = torch.empty((num_batch, 3, 3), dtype=torch.float64, device=pos.device) if has_cell else None
-        cell_c = cell.contiguous() if has_cell else None
+        cell_c = cell.detach().to(torch.float64).contiguous() if has_cell else None
         stream = current_stream_ptr(pos.device)
         with torch.cuda.device(pos.device):
             # the kernel's generic per-edge left factor (the cell shift in the autograd adjoint) is the edge vector here:

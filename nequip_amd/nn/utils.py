@@ -32,6 +32,10 @@ def tp_path_exists(irreps_in1, irreps_in2, ir_out) -> bool:
     return False
 
 
+def _as_f64(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().to(torch.float64).contiguous()
+
+
 class _EdgeVectorsFn(torch.autograd.Function):
     """(pos, cell) -> edge_vec on the GPU (``nqa_edge_vectors_fwd``); linear, so its adjoint ``_EdgeVectorsAdjFn``
     and the adjoint's adjoint (this forward again) close the family for double backward."""
@@ -42,11 +46,19 @@ class _EdgeVectorsFn(torch.autograd.Function):
         from ._topology import _ptr, current_stream_ptr
 
         lib = _lib.load()
-        pos_c = pos.contiguous()
+        # the kernel reads float64 / int64 through raw pointers: normalise here (the reference's with_edge_vectors_
+        # accepts any floating dtype, nequip/nn/utils.py:88-114; float32 positions or an integer shift tensor must not be
+        # reinterpreted).  autograd casts the float64 gradient back to the input dtype.
+        if edge_index.dtype != torch.int64:
+            raise TypeError(f"edge_index must be int64, got {edge_index.dtype}")
+        pos_c = _as_f64(pos)
         E = edge_index.shape[1]
         dst, src = edge_index[0].contiguous(), edge_index[1].contiguous()
         vec = torch.empty((E, 3), dtype=torch.float64, device=pos.device)
-        cell_c = cell.contiguous() if cell is not None else None
+        cell_c = _as_f64(cell)
+        shift = _as_f64(shift)
+        if batch is not None and batch.dtype != torch.int64:
+            batch = batch.to(torch.int64)
         with torch.cuda.device(pos.device):
             rc = lib.nqa_edge_vectors_fwd(_ptr(pos_c), _ptr(dst), _ptr(src), _ptr(shift), _ptr(cell_c), _ptr(batch),
                                           E, _ptr(vec), current_stream_ptr(pos.device))
@@ -72,7 +84,8 @@ class _EdgeVectorsAdjFn(torch.autograd.Function):
         from ._topology import _ptr, current_stream_ptr, topology_cache
 
         lib = _lib.load()
-        g = g_vec.contiguous()
+        g = _as_f64(g_vec)
+        shift = _as_f64(shift)
         topo = topology_cache.get(edge_index[0], edge_index[1], num_nodes)
         rp_d, eid_d, _ = topo.by_dst
         rp_s, eid_s, _ = topo.by_src

@@ -107,3 +107,61 @@ def test_batched_molecules_no_cell(device):
     fscale = float(ref["forces"].abs().max())
     torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=2e-4, rtol=5e-5)
     torch.testing.assert_close(ref["forces"], out["forces"].cpu(), atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+
+
+# ---- the BASELINE.json model shapes themselves (the kernels bench.py times: 64 / 128 features, radial MLP 8-128-W) ----
+def _baseline_case(device, data, names, cfg, what):
+    """Energy within 5e-5 per atom abs/rel, forces within 1e-4 eV/A *absolute* (BASELINE.json north_star) and 5e-5
+    relative to the largest force, virial within 5e-5 x atoms."""
+    out, ref = _run_both(cfg, data, names, device)
+    n = data["pos"].shape[0]
+    f_ref, f_out = ref["forces"], out["forces"].cpu()
+    fscale = float(f_ref.abs().max())
+    df = float((f_ref - f_out).abs().max())
+    de = float((ref["total_energy"] - out["total_energy"].cpu()).abs().max())
+    print(f"[{what}] N={n} E={data['edge_index'].shape[1]} |dE|={de:.3e} max|dF|={df:.3e} eV/A (max|F|={fscale:.3e})")
+    torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=5e-5 * n, rtol=5e-5)
+    assert df < 1e-4, f"forces differ from the oracle by {df:.3e} eV/A (bar 1e-4)"
+    torch.testing.assert_close(f_ref, f_out, atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+    torch.testing.assert_close(ref["virial"], out["virial"].cpu(), atol=5e-5 * n * max(1.0, fscale), rtol=5e-4)
+
+
+@pytest.mark.gpu
+def test_cfg2_model_si_1000_atoms(device):
+    """BASELINE config 2 at full size: 1000-atom periodic Si box, l_max=2, 64 features, r_cut 4.5 A."""
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.silicon_box(reps=5, seed=1)
+    data = syn.make_data(pos, types, 4.5, cell)
+    assert len(pos) == 1000
+    n, e = len(pos), data["edge_index"].shape[1]
+    cfg = _cfg(num_features=64, radial_mlp_width=128, avg_num_neighbors=e / n)
+    _baseline_case(device, data, names, cfg, "cfg-2 si1k")
+
+
+@pytest.mark.gpu
+def test_cfg3_model_water_1029_atoms(device):
+    """BASELINE config 3's model (l_max=2, 64 features, 3 layers, two species) on a 7^3-molecule water box (1029 atoms,
+    same density / r_max as the 10 125-atom bench box, which would cost the oracle minutes)."""
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=7, seed=1)
+    data = syn.make_data(pos, types, 4.5, cell)
+    n, e = len(pos), data["edge_index"].shape[1]
+    assert n >= 1000
+    cfg = _cfg(num_features=64, radial_mlp_width=128, avg_num_neighbors=e / n)
+    _baseline_case(device, data, names, cfg, "cfg-3 water1k")
+
+
+@pytest.mark.gpu
+def test_cfg5_model_cu_108_atoms(device):
+    """BASELINE config 5's model (l_max=3, 128 features: two 64-channel chunks per node, 23-path middle layer) on a
+    108-atom fcc Cu box."""
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.copper_box(reps=(3, 3, 3), seed=1)
+    data = syn.make_data(pos, types, 4.5, cell)
+    n, e = len(pos), data["edge_index"].shape[1]
+    assert n == 108
+    cfg = _cfg(l_max=3, num_features=128, radial_mlp_width=128, avg_num_neighbors=e / n)
+    _baseline_case(device, data, names, cfg, "cfg-5 cu108")

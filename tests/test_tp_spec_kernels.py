@@ -1,0 +1,177 @@
+"""Op-level parity of the float32 *structure-specialised* TensorProductScatter kernels -- the ones bench.py times --
+against the CPU oracle (``oracle/tp.py``), for every structure ``gen_spec.baseline_structures()`` prebuilds, at the
+benchmarked channel counts mul = 32 / 64 / 128 (128 = two 64-lane chunks per node: per-chunk ``grad_y`` partials,
+``tp_spec.h``), on ragged neighbourhoods (isolated nodes, degree 1 .. 13, unsorted edge list).
+
+Recipe of the reference's own boundary test (``tests/unit/nn/test_tp_scatter_kernel.py:34-179``: instructions built
+as InteractionBlock builds them, forward and the gradient w.r.t. each operand, atol = rtol = 1e-5), applied to each
+native entry point separately: ``fwd``, ``bwd_x``, ``bwd_edge``, ``bwd_fused`` and their ``_paired`` forms
+(one weight row per reverse-edge pair).  atol is scaled by max(1, max|ref|): sums over up to 13 edges x up to 6
+paths of O(1) products reach O(30).
+"""
+
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import tp as otp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "nequip_amd", "csrc"))
+import gen_spec  # noqa: E402
+
+TOL = 1e-5
+
+
+def _unique_structures():
+    seen, out = set(), []
+    for name, f_in, lmax, f_out in gen_spec.baseline_irreps():
+        st = gen_spec.nequip_structure(f_in, lmax, f_out, name)
+        if st.instr and st.key() not in seen:
+            seen.add(st.key())
+            out.append((name, f_in, lmax, f_out))
+    return out
+
+
+STRUCTS = _unique_structures()
+
+
+def _graph(n_nodes, seed, symmetric):
+    """Ragged random graph.  symmetric=True: every (i <- j) has its (j <- i) (a pairable list), edges shuffled."""
+    g = torch.Generator().manual_seed(seed)
+    pairs = set()
+    deg_target = torch.randint(0, 7, (n_nodes,), generator=g).tolist()
+    deg_target[0] = 0  # an isolated node
+    for i in range(1, n_nodes):
+        for _ in range(deg_target[i]):
+            j = int(torch.randint(1, n_nodes, (1,), generator=g))
+            if j != i:
+                pairs.add((min(i, j), max(i, j)))
+    pairs = sorted(pairs)
+    if symmetric:
+        dst = [a for a, b in pairs] + [b for a, b in pairs]
+        src = [b for a, b in pairs] + [a for a, b in pairs]
+    else:  # directed, with repeated edges (the reference's test draws dst / src independently)
+        dst = [a for a, b in pairs] + [a for a, b in pairs[::3]]
+        src = [b for a, b in pairs] + [b for a, b in pairs[::3]]
+    perm = torch.randperm(len(dst), generator=g)
+    return torch.tensor(dst)[perm].contiguous(), torch.tensor(src)[perm].contiguous()
+
+
+def _module(f_in_1x, lmax, f_out_1x, mul, device):
+    from nequip_amd.nn import TensorProductScatter
+    from nequip_amd.o3 import Irreps
+
+    f_in = f_in_1x.replace("1x", f"{mul}x")
+    f_out = f_out_1x.replace("1x", f"{mul}x")
+    e_at = str(Irreps.spherical_harmonics(lmax))
+    mid, instructions = otp.build_instructions(f_in, e_at, f_out)
+    mid_s = "+".join(f"{m}x{l}{'e' if p == 1 else 'o'}" for m, l, p in mid)
+    tps = TensorProductScatter(Irreps(f_in), Irreps(e_at), Irreps(mid_s), instructions).to(device)
+    return tps, f_in, e_at, mid_s, instructions
+
+
+def _close(ref, got, what):
+    scale = max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(got.cpu(), ref, atol=TOL * scale, rtol=TOL, msg=lambda m: f"{what}: {m}")
+
+
+def _cases():
+    for name, f_in, lmax, f_out in STRUCTS:
+        for mul in (32, 64, 128):
+            yield pytest.param(name, f_in, lmax, f_out, mul, id=f"{name}-mul{mul}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,f_in_1x,lmax,f_out_1x,mul", list(_cases()))
+def test_spec_kernels_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul):
+    from nequip_amd.nn._topology import EdgeTopology
+
+    if os.environ.get("NQA_FORCE_GENERIC", "") not in ("", "0"):
+        pytest.skip("specialised kernels switched off")
+    tps, f_in, e_at, mid_s, instructions = _module(f_in_1x, lmax, f_out_1x, mul, device)
+    k = tps._get_kernels()
+    assert k.has_spec(torch.float32), f"structure {name} has no specialised kernel"
+    N = 19
+    for symmetric in (False, True):
+        dst, src = _graph(N, seed=1000 * lmax + mul + int(symmetric), symmetric=symmetric)
+        E = dst.numel()
+        g = torch.Generator().manual_seed(17 + mul)
+        x = torch.randn(N, k.dim_in1, generator=g)
+        y = torch.randn(E, k.dim_in2, generator=g)
+        go = torch.randn(N, k.dim_out, generator=g)
+        topo = EdgeTopology(dst.to(device), src.to(device), N)
+        pr = topo.pairing(None) if symmetric else None
+        assert (pr is not None) == symmetric
+        if symmetric:
+            P = pr.num_pairs
+            w_rows = torch.randn(P, k.weight_numel, generator=g)
+            rows = pr.rows.long().cpu()
+            w = w_rows[rows % P].contiguous()  # the per-edge weights the oracle sees
+        else:
+            w_rows = w = torch.randn(E, k.weight_numel, generator=g)
+
+        xr, yr, wr = (t.clone().requires_grad_(True) for t in (x, y, w))
+        ref = otp.tp_scatter(xr, yr, wr, dst, src, f_in, e_at, mid_s, instructions)
+        rgx, rgy, rgw = torch.autograd.grad(ref, (xr, yr, wr), go)
+        ref = ref.detach()
+
+        d = lambda t: t.to(device)  # noqa: E731
+        xd, yd, wd, god = d(x), d(y), d(w_rows), d(go)
+        tag = f"{name} mul={mul} {'paired' if symmetric else 'plain'}"
+        _close(ref, k.fwd(xd, yd, wd, topo, pr), f"fwd {tag}")
+        _close(rgx, k.bwd_x(yd, wd, god, topo, pr), f"bwd_x {tag}")
+        gw, gy = k.bwd_edge(xd, yd, wd, god, topo, True, True, pairing=pr)
+        if symmetric:
+            gw = gw[d(rows)]
+        _close(rgw, gw, f"bwd_edge gw {tag}")
+        _close(rgy, gy, f"bwd_edge gy {tag}")
+        # single-output instantiations of the edge backward
+        gw1, none_y = k.bwd_edge(xd, yd, wd, god, topo, True, False, pairing=pr)
+        none_w, gy1 = k.bwd_edge(xd, yd, wd, god, topo, False, True, pairing=pr)
+        assert none_y is None and none_w is None
+        _close(rgw, gw1[d(rows)] if symmetric else gw1, f"bwd_edge<gw only> {tag}")
+        _close(rgy, gy1, f"bwd_edge<gy only> {tag}")
+        fused = k.bwd_fused(xd, yd, wd, god, topo, pairing=pr)
+        assert fused is not None
+        fx, fw, fy = fused
+        if symmetric:
+            fw = fw[d(rows)]
+        _close(rgx, fx, f"bwd_fused gx {tag}")
+        _close(rgw, fw, f"bwd_fused gw {tag}")
+        _close(rgy, fy, f"bwd_fused gy {tag}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mul", [64, 128])
+def test_spec_kernels_large_degree_and_wave_split(device, mul):
+    """The launch heuristics split a node's edges over four wavefronts on small graphs (LDS tree reduction) and use one
+    wavefront per node on large ones; exercise both with 60-neighbour nodes (the cfg-5 Cu box has ~38-78)."""
+    from nequip_amd.nn._topology import EdgeTopology
+
+    name, f_in_1x, lmax, f_out_1x = next(s for s in STRUCTS if s[0] == ("l2n_mid" if mul == 64 else "l3n_mid"))
+    tps, f_in, e_at, mid_s, instructions = _module(f_in_1x, lmax, f_out_1x, mul, device)
+    k = tps._get_kernels()
+    assert k.has_spec(torch.float32)
+    N = 7
+    g = torch.Generator().manual_seed(5)
+    dst = torch.cat([torch.full((60,), 3), torch.full((1,), 5), torch.full((33,), 6)])
+    src = torch.randint(0, N, (dst.numel(),), generator=g)
+    E = dst.numel()
+    x = torch.randn(N, k.dim_in1, generator=g)
+    y = torch.randn(E, k.dim_in2, generator=g)
+    w = torch.randn(E, k.weight_numel, generator=g) / 4
+    go = torch.randn(N, k.dim_out, generator=g)
+    xr, yr, wr = (t.clone().requires_grad_(True) for t in (x, y, w))
+    ref = otp.tp_scatter(xr, yr, wr, dst, src, f_in, e_at, mid_s, instructions)
+    rgx, rgy, rgw = torch.autograd.grad(ref, (xr, yr, wr), go)
+    topo = EdgeTopology(dst.to(device), src.to(device), N)
+    d = lambda t: t.to(device)  # noqa: E731
+    _close(ref.detach(), k.fwd(d(x), d(y), d(w), topo), "fwd")
+    _close(rgx, k.bwd_x(d(y), d(w), d(go), topo), "bwd_x")
+    fx, fw, fy = k.bwd_fused(d(x), d(y), d(w), d(go), topo)
+    _close(rgx, fx, "fused gx")
+    _close(rgw, fw, "fused gw")
+    _close(rgy, fy, "fused gy")
