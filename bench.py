@@ -31,7 +31,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), same guide
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")  # HBM bytes per launch from rocprofv3 --pmc
+# committed PMC summary (scripts/profile.sh): only used for `roofline.traffic` when the live measurement below is
+# unavailable, and then labelled as static in `traffic_source`
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
 
 TRAIN_WORKLOADS = {
     # BASELINE config 4: DDP training on synthetic 5-species 256-atom frames, l_max=2, batch=32 per rank
@@ -101,18 +103,19 @@ def build_model(cfg, names, device, seed=0):
     return model.to(device).eval()
 
 
-def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
-    """Time the CPU oracle (reference op order, PyTorch CPU ops) on a bounded sample of the same workload."""
+def cpu_baseline(workload_name: str, max_seconds: float = 30.0):
+    """Time the CPU oracle (reference op order, PyTorch CPU ops) on a bounded sample of the same workload: a box of
+    >= 1000 atoms at the workload's density / r_max / model (one evaluation of the full 10 125-atom box costs the
+    oracle about a minute; a 108-atom l_max = 3 / 128-feature Cu box already 5 s)."""
     from oracle import model as omodel
 
     w = dict(WORKLOADS[workload_name])
-    # bounded sample: same density / r_max / model, smaller box
     if w["box"] == "water":
-        w["n_side"] = min(w["n_side"], 5)
+        w["n_side"] = min(w["n_side"], 7)  # 7^3 molecules = 1029 atoms
     elif w["box"] == "si":
-        w["reps"] = min(w["reps"], 3)
+        w["reps"] = min(w["reps"], 5)  # 1000 atoms
     elif w["box"] == "cu":
-        w["reps"] = (3, 3, 3)
+        w["reps"] = (4, 4, 4)  # 256 atoms (l_max = 3, 128 features)
     # (aspirin5 is small enough to be timed whole)
     data, names = build_box(w, seed=1)
     n_atoms = data["pos"].shape[0]
@@ -121,23 +124,22 @@ def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
     model = build_model(cfg, names, torch.device("cpu"))
     weights = {k.replace("model.func.", ""): v.detach() for k, v in model.state_dict().items()}
     specs = omodel.build_specs(cfg)
-    # thread count: the oracle is a chain of small ATen ops -- all host cores (256 on the GPU box) oversubscribe it by
-    # orders of magnitude, so a few moderate settings are tried once each and the fastest is used (and reported)
+    # thread count: the oracle is a chain of ATen ops on [E, ...] tensors -- all host cores (256 on the GPU box)
+    # oversubscribe it, so two moderate settings are tried once each and the faster one is used (and reported)
     ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
     best = None
-    for nthreads in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+    for nthreads in sorted({min(ncpu, c) for c in (16, 32)}):
         torch.set_num_threads(nthreads)
-        omodel.energy_forces(data, cfg, weights, specs)  # warm-up
         t0 = time.perf_counter()
-        omodel.energy_forces(data, cfg, weights, specs)
+        omodel.energy_forces(data, cfg, weights, specs)  # (the first call also builds the cached CG tables)
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, nthreads)
     cores = best[1]
     torch.set_num_threads(cores)
     times = []
-    t_start = time.perf_counter()
-    while len(times) < 10 and (time.perf_counter() - t_start) < max_seconds:
+    while len(times) < 5 and (len(times) < 2 or (time.perf_counter() - t_start) < max_seconds):
         t0 = time.perf_counter()
         omodel.energy_forces(data, cfg, weights, specs)
         times.append(time.perf_counter() - t0)
@@ -149,8 +151,152 @@ def cpu_baseline(workload_name: str, max_seconds: float = 25.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{n_atoms}-atom {w['box']} box ({n_edges} edges), same density/r_max/model as the workload, "
-        f"median of {len(times)} energy+forces evaluations of the torch-CPU oracle (e3nn unavailable: restatement)",
+        f"median of {len(times)} energy+forces evaluations ({med:.2f} s each) of the torch-CPU oracle "
+        "(e3nn unavailable: restatement)",
     }
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def relaunch_distributed(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this very command line under torch.distributed.run with N
+    ranks on this node (one process per GPU, RCCL), exactly as the driver's own launch line does."""
+    import subprocess
+
+    share = os.environ.get("NQA_BENCH_SHARE_DEVICE", "") not in ("", "0")
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (one rank per GPU; "
+                         "NQA_BENCH_SHARE_DEVICE=1 exercises the N > 1 control flow on one device, not a measurement)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- roofline bookkeeping ---------------------------------------------------------------------------------------
+TP_REGIONS = ("tp_fwd", "tp_bwd_edge", "tp_bwd_x", "tp_bwd_fused", "tp_fwd_mlp", "tp_bwd_mlp")
+
+
+def kernel_roofline(kname, ks, kernel_steps):
+    launches = ks["calls"] / max(kernel_steps, 1)
+    if ks.get("flops_per_call", 0) > 0 and kname.startswith("radial_mlp"):
+        # GEMM on the matrix cores.  `achieved` = algorithmic fp32 FLOP/s against the dense fp32-MFMA peak (the path's
+        # arithmetic type); the default kernels execute 6 bf16 MFMA partial products per fp32 product (split operands,
+        # fp32-accurate), reported against the bf16 peak as well.
+        split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
+        r = {
+            "bound": "mfma", "kernel": kname, "achieved": ks["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
+            "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],
+            "algorithmic_bytes_per_launch": ks["bytes_per_call"], "hbm_gbps": ks["gbps"],
+            "launches_per_step": launches,
+        }
+        if split:
+            r["executed_bf16_tflops"] = 6.0 * ks["tflops"]
+            r["frac_of_bf16_peak"] = 6.0 * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS
+        return r
+    return {
+        "bound": "hbm", "kernel": kname, "achieved": ks["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": ks["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ks["avg_ms"],
+        "algorithmic_bytes_per_launch": ks["bytes_per_call"], "launches_per_step": launches,
+    }
+
+
+def measure_traffic_live(workload: str, timeout_s: float = 240.0):
+    """HBM bytes per launch of every hand-written kernel region, measured now: two `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE each in its own run, as MI355X_MICROARCH.md prescribes; no trace domains besides the
+    kernel trace) over a short eager run of this very workload (`--pmc-child`), condensed by
+    scripts/summarize_profile.py (gfx950 correction: bytes = (2 FETCH_SIZE + WRITE_SIZE) KB).
+    Returns (bench_kernels dict or None, source label)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if os.environ.get("NQA_BENCH_NO_PMC", "") not in ("", "0"):
+        return None, "disabled (NQA_BENCH_NO_PMC)"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "already running under a profiler"
+    out = tempfile.mkdtemp(prefix="nqa_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            left = timeout_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None, "live PMC passes timed out"
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d",
+                   os.path.join(out, f"pmc_{name}"), "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--workload", workload]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            if res.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), out, "live"],
+                             capture_output=True, text=True, timeout=60)
+        summ = json.load(open(os.path.join(out, "live_pmc_summary.json")))
+        if not summ.get("bench_kernels"):
+            return None, "live PMC passes produced no counters"
+        return summ["bench_kernels"], ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
+                                       f"over 2 eager steps of the workload ({time.perf_counter() - t0:.0f} s)")
+    except Exception as exc:  # pragma: no cover
+        return None, f"live PMC measurement failed ({type(exc).__name__}: {exc})"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def static_traffic():
+    try:
+        summ = json.load(open(PMC_SUMMARY))
+        return summ["bench_kernels"], f"static: {os.path.relpath(PMC_SUMMARY, ROOT)} ({summ.get('commit', 'commit n/a')})"
+    except Exception:
+        return {}, "unavailable"
+
+
+def roofline_objects(kernels, kernel_steps, ms_per_step, workload, live_pmc):
+    """`roofline` (dominant hand-written kernel + the other hot ones) and `step_roofline` (whole step: the
+    TensorProductScatter boundary bytes of SURVEY.md 8(d), forward + backward of every layer, against the HBM peak)."""
+    if not kernels:
+        return None, None
+    pmc, source = (None, "")
+    if live_pmc:
+        pmc, source = measure_traffic_live(workload)
+    if pmc is None:
+        why = source
+        pmc, source = static_traffic()
+        if why:
+            source += f" [live measurement: {why}]"
+    name, s = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
+    roofline = kernel_roofline(name, s, kernel_steps)
+    roofline["traffic"] = pmc.get(name, {}).get("hbm_bytes_per_launch")
+    roofline["traffic_source"] = source
+    others = {}
+    for kname, ks in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])[:8]:
+        if kname != name:
+            others[kname] = kernel_roofline(kname, ks, kernel_steps)
+            others[kname]["traffic"] = pmc.get(kname, {}).get("hbm_bytes_per_launch")
+    roofline["other_kernels"] = others
+    tp_bytes = sum(v["bytes_per_call"] * v["calls"] for k, v in kernels.items() if k in TP_REGIONS) / max(kernel_steps, 1)
+    step = {
+        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_step": tp_bytes,
+        "definition": "SURVEY.md 8(d): operands and results of the gather -> tensor product -> scatter boundary of "
+                      "every layer, forward + backward, each counted once (edge_weight / grad_weight rows included)",
+        "achieved": tp_bytes / 1e9 / (ms_per_step / 1e3),
+        "frac": tp_bytes / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBPS,
+        "kernel_ms_per_step_sum": sum(v["total_ms"] for v in kernels.values()) / max(kernel_steps, 1),
+    }
+    return roofline, step
 
 
 def train_bench(args, world, rank, device, distributed):
@@ -161,6 +307,7 @@ def train_bench(args, world, rank, device, distributed):
     from nequip_amd.data import AtomicDataDict
     from nequip_amd.model import NequIPGNNModel
     from nequip_amd.train import SimpleDDPStrategy
+    from nequip_amd.utils import ktimer
     from nequip_amd.utils import synthetic as syn
 
     w = TRAIN_WORKLOADS[args.workload]
@@ -207,6 +354,18 @@ def train_bench(args, world, rank, device, distributed):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    roofline = step_roofline = None
+    kernels = {}
+    if rank == 0 and args.kernel_steps > 0:
+        ktimer.reset()
+        ktimer.enable(True)
+        for _ in range(args.kernel_steps):
+            step()
+        torch.cuda.synchronize()
+        ktimer.enable(False)
+        kernels = ktimer.summary()
+        roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, elapsed / args.steps * 1e3,
+                                                   args.workload, live_pmc=False)
     if rank == 0:
         print(json.dumps({
             "metric": "atom-optimizer-steps/s (DDP force-matching training)",
@@ -216,7 +375,10 @@ def train_bench(args, world, rank, device, distributed):
             "config": {"workload": f"{args.workload}: {w['batch']} frames x {w['n_atoms']} atoms per rank "
                        f"({n_edges} edges), {w['n_species']} species, l_max={w['l_max']}, {w['num_features']} features, "
                        "energy+force MSE loss, Adam, flat gradient all-reduce (SimpleDDP)",
-                       "parallelism": f"dp{world}", "final_loss": float(loss)},
+                       "parallelism": f"dp{world}", "final_loss": float(loss),
+                       "collective": ("RCCL all-reduce of one flat fp32 gradient buffer per step" if distributed else "none (1 rank)")},
+            "roofline": roofline, "step_roofline": step_roofline,
+            "kernels_ms_per_step": {k: v["total_ms"] / max(args.kernel_steps, 1) for k, v in kernels.items()},
         }))
     if distributed:
         dist.barrier()
@@ -225,24 +387,32 @@ def train_bench(args, world, rank, device, distributed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); without a launcher bench.py starts them itself")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="water10k", choices=sorted(WORKLOADS) + sorted(TRAIN_WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind `roofline.traffic`")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # 1 warm-up + 2 eager steps, no output
     ap.add_argument("--kernel-steps", type=int, default=3, help="eager steps instrumented with HIP events for `roofline`")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        raise SystemExit(relaunch_distributed(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # NQA_BENCH_SHARE_DEVICE=1 (testing the N > 1 control flow on a one-GPU box): every rank uses device 0 and the
     # barriers / max-reduction go over gloo, since RCCL refuses two ranks on one device.  Not a measurement mode.
     share = distributed and os.environ.get("NQA_BENCH_SHARE_DEVICE", "") not in ("", "0")
+    if distributed and not share and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -277,6 +447,12 @@ def main():
         out = model(d)
         # detach: nothing of the autograd graph must outlive the step (and be alive during hipGraph capture)
         return out["total_energy"].detach(), out["forces"].detach()
+
+    if args.pmc_child:  # counter-collection run for measure_traffic_live: eager launches only
+        for _ in range(3):
+            step_eager()
+        torch.cuda.synchronize()
+        return
 
     # ---- warm-up (also builds CSR, allocator pools, hipBLASLt heuristics) -------------------------------
     for _ in range(max(args.warmup, 1)):
@@ -336,11 +512,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
 
     # ---- per-kernel HIP-event timing of the hand-written kernels (eager, on the launching stream) ------
-    roofline = None
+    roofline = step_roofline = None
     kernels = {}
-    if rank == 0:
+    if rank == 0 and args.kernel_steps > 0:
         ktimer.reset()
         ktimer.enable(True)
         for _ in range(args.kernel_steps):
@@ -348,52 +525,10 @@ def main():
         torch.cuda.synchronize()
         ktimer.enable(False)
         kernels = ktimer.summary()
-        if kernels:
-            dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
-            name, s = dom
-            traffic, pmc = None, {}
-            try:  # per-launch HBM bytes of this kernel from the committed PMC passes (scripts/profile.sh), if present
-                pmc = json.load(open(PMC_SUMMARY))["bench_kernels"]
-                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic, pmc = None, {}
-
-            def kernel_roofline(kname, ks):
-                launches = ks["calls"] / max(args.kernel_steps, 1)
-                if ks.get("flops_per_call", 0) > 0 and kname.startswith("radial_mlp"):
-                    # GEMM on the matrix cores.  `achieved` = algorithmic fp32 FLOP/s against the dense fp32-MFMA peak
-                    # (the path's arithmetic type); the default kernels execute 6 bf16 MFMA partial products per
-                    # fp32 product (split operands, fp32-accurate), reported against the bf16 peak as well.
-                    split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
-                    r = {
-                        "bound": "mfma", "kernel": kname, "achieved": ks["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
-                        "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],
-                        "algorithmic_bytes_per_launch": ks["bytes_per_call"], "hbm_gbps": ks["gbps"],
-                        "launches_per_step": launches,
-                    }
-                    if split:
-                        r["executed_bf16_tflops"] = 6.0 * ks["tflops"]
-                        r["frac_of_bf16_peak"] = 6.0 * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS
-                    return r
-                return {
-                    "bound": "hbm", "kernel": kname, "achieved": ks["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": ks["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ks["avg_ms"],
-                    "algorithmic_bytes_per_launch": ks["bytes_per_call"], "launches_per_step": launches,
-                }
-
-            roofline = kernel_roofline(name, s)
-            roofline["traffic"] = traffic
-            # the other hot hand-written kernels, same definition (algorithmic bytes or flops / measured duration)
-            others = {}
-            for kname, ks in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])[:8]:
-                if kname != name:
-                    others[kname] = kernel_roofline(kname, ks)
-                    others[kname]["traffic"] = pmc.get(kname, {}).get("hbm_bytes_per_launch")
-            roofline["other_kernels"] = others
+        roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, ms_per_step, args.workload,
+                                                   live_pmc=(world == 1 and not args.no_pmc))
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
         value = world * n_atoms * args.steps / elapsed
         result = {
             "metric": baseline_metric() if args.workload == "water10k" else "atom-steps/s (energy+forces)",
@@ -419,6 +554,7 @@ def main():
                 "launch": "hipGraph replay" if graph is not None else "eager",
             },
             "roofline": roofline,
+            "step_roofline": step_roofline,
             "kernels_ms_per_step": {k: v["total_ms"] / max(args.kernel_steps, 1) for k, v in kernels.items()},
             "kernels_gbps": {k: v["gbps"] for k, v in kernels.items()},
             "kernels_tflops": {k: v["tflops"] for k, v in kernels.items() if v.get("tflops", 0) > 0},

@@ -70,3 +70,23 @@ def test_sh_properties(device):
     torch.testing.assert_close(Y[:, 4], math.sqrt(15) * x * z, atol=1e-13, rtol=0)
     torch.testing.assert_close(Y[:, 6], math.sqrt(5) * (y * y - 0.5 * (x * x + z * z)), atol=1e-13, rtol=0)
     torch.testing.assert_close(Y[:, 8], math.sqrt(15) / 2 * (z * z - x * x), atol=1e-13, rtol=0)
+
+
+@pytest.mark.gpu
+def test_sh_kernel_equals_standard_real_spherical_harmonics(device):
+    """The HIP kernel's real spherical harmonics against sympy's Ynm directly (no oracle in between): sqrt(4 pi) x the
+    textbook real harmonics with y as the polar axis, plus sign for every (l, m), l <= 4 (see tests/test_oracle.py)."""
+    import numpy as np
+
+    from nequip_amd.nn.embedding._edge import _EdgeEmbedFn
+    from tests.test_oracle import _standard_real_sh
+
+    vec = _vectors(80, seed=21)
+    cfg = dict(dtype=torch.float64, lmax=4, want_sh=True, want_emb=False, nb=0, rmax_recip=1.0, p=6.0, factor=1.0)
+    Y = _EdgeEmbedFn.apply(vec.to(device), torch.ones(1, dtype=torch.float64, device=device), cfg).cpu().numpy()
+    u = torch.nn.functional.normalize(vec, dim=1).numpy()
+    theta, phi = np.arccos(u[:, 1]), np.arctan2(u[:, 0], u[:, 2])
+    for l in range(5):
+        for m in range(-l, l + 1):
+            ref = math.sqrt(4 * math.pi) * np.broadcast_to(_standard_real_sh(l, m)(theta, phi), theta.shape)
+            np.testing.assert_allclose(Y[:, l * l + l + m], ref, atol=1e-12, err_msg=f"l={l} m={m}")

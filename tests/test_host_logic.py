@@ -202,3 +202,23 @@ def test_force_stress_modifiers():
     assert K.FORCE_KEY in model(dict(batch))
     with pytest.raises(RuntimeError, match="is not a registered model modifier"):
         modify(model, [{"modifier": "enable_Nothing"}])
+
+
+def test_bench_gpus_flag_is_honoured_without_a_launcher():
+    """`python bench.py --gpus N` must start N ranks itself (or fail loudly) -- never run one rank and report it as N;
+    a launcher-provided WORLD_SIZE that contradicts --gpus is an error too."""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)

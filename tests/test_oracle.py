@@ -230,3 +230,165 @@ def test_oracle_force_smoothness_at_cutoff():
     p = np.array([[0.0, 0.0, 0.0], [cfg["r_max"] * (1 - 1e-6), 0.0, 0.0]])
     out = _eval(p, np.array([0, 1]), None, cfg, weights, pbc=False)
     assert abs(float(out["total_energy"]) - e_far) < 1e-8 and float(out["forces"].abs().max()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Outside pins for the e3nn-computed rows (e3nn itself is not installable here): sympy's spherical
+# harmonics, real Gaunt coefficients and SU(2) Clebsch-Gordan coefficients are implementations written by other
+# people from the published definitions; e3nn documents its conventions as "real spherical harmonics, polar axis y,
+# component normalisation" and its 3j tensors as the normalised real-basis coupling coefficients.
+# ---------------------------------------------------------------------------------------------------------------
+def _standard_real_sh(l, m):
+    """The textbook real spherical harmonic S_lm(theta, phi) (no Condon-Shortley phase):
+    sqrt2 (-1)^m Re Y_l^|m| for m > 0, Y_l^0, sqrt2 (-1)^m Im Y_l^|m| for m < 0 -- built from sympy's complex Ynm."""
+    import sympy as sp
+
+    th, ph = sp.symbols("theta phi", real=True)
+    Y = sp.Ynm(l, abs(m), th, ph).expand(func=True)
+    if m == 0:
+        expr = Y
+    elif m > 0:
+        expr = sp.sqrt(2) * (-1) ** m * sp.re(Y)
+    else:
+        expr = sp.sqrt(2) * (-1) ** m * sp.im(Y)
+    return sp.lambdify((th, ph), expr, "numpy")
+
+
+def test_sh_equal_standard_real_spherical_harmonics_l_le_4():
+    """Y^{e3nn}_{lm}(x, y, z) = sqrt(4 pi) S_lm evaluated with y as the polar axis ((x,y,z)_std = (z,x,y)), with a plus
+    sign for every (l, m), l <= 4: pins signs, component order and normalisation of row a2 to sympy's Ynm."""
+    g = torch.Generator().manual_seed(0)
+    v = torch.nn.functional.normalize(torch.randn(64, 3, generator=g, dtype=torch.float64), dim=-1)
+    Y = spherical_harmonics(v, 4).numpy()
+    xs, ys, zs = v[:, 2].numpy(), v[:, 0].numpy(), v[:, 1].numpy()
+    theta, phi = np.arccos(zs), np.arctan2(ys, xs)
+    for l in range(5):
+        for m in range(-l, l + 1):
+            ref = math.sqrt(4 * math.pi) * np.broadcast_to(_standard_real_sh(l, m)(theta, phi), theta.shape)
+            np.testing.assert_allclose(Y[:, l * l + l + m], ref, atol=1e-13, err_msg=f"l={l} m={m}")
+
+
+def test_sh_closed_forms_l3():
+    """SURVEY.md A.4 closed forms of the l = 3 components (polynomials in x, y, z on the unit sphere)."""
+    g = torch.Generator().manual_seed(1)
+    v = torch.nn.functional.normalize(torch.randn(32, 3, generator=g, dtype=torch.float64), dim=-1)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    Y = spherical_harmonics(v, 3)
+    y20 = math.sqrt(15) * x * z
+    y24 = math.sqrt(15) / 2 * (z * z - x * x)
+    s168 = math.sqrt(168) / 8
+    ref = torch.stack([
+        math.sqrt(42) / 6 * (y20 * z + y24 * x),
+        math.sqrt(7) * y20 * y,
+        s168 * (4 * y * y - x * x - z * z) * x,
+        math.sqrt(7) / 2 * y * (2 * y * y - 3 * (x * x + z * z)),
+        s168 * z * (4 * y * y - x * x - z * z),
+        math.sqrt(7) * y24 * y,
+        math.sqrt(42) / 6 * (y24 * z - y20 * x),
+    ], dim=1)
+    torch.testing.assert_close(Y[:, 9:16], ref, atol=1e-13, rtol=0)
+
+
+EVEN_TRIPLES = [t for t in TRIPLES if sum(t) % 2 == 0]
+
+
+@pytest.mark.parametrize("l1,l2,l3", EVEN_TRIPLES)
+def test_real_3j_equal_sympy_real_gaunt(l1, l2, l3):
+    """Every even-(l1+l2+l3) tensor -- all paths of the parity=False BASELINE models -- is the Frobenius-normalised
+    *real Gaunt* tensor int S_{l1 m1} S_{l2 m2} S_{l3 m3} dOmega with a PLUS sign, entry by entry, against
+    sympy.physics.wigner.real_gaunt (Homeier & Steinborn's definition, an outside implementation)."""
+    from sympy.physics.wigner import real_gaunt
+
+    G = np.array([[[float(real_gaunt(l1, l2, l3, m1, m2, m3)) for m3 in range(-l3, l3 + 1)]
+                   for m2 in range(-l2, l2 + 1)] for m1 in range(-l1, l1 + 1)])
+    assert np.linalg.norm(G) > 0
+    np.testing.assert_allclose(wigner_3j(l1, l2, l3).numpy(), G / np.linalg.norm(G), atol=1e-13)
+
+
+def test_real_3j_gaunt_by_quadrature_uses_the_oracle_sh():
+    """The same statement through the oracle's own spherical harmonics (ties rows a2 and a8 together with the sign):
+    int Y_i Y_j Y_k dOmega = kappa C_ijk with kappa > 0 for even sums and = 0 for odd sums (Gauss-Legendre x uniform
+    quadrature, exact for these polynomial degrees)."""
+    n, nphi = 16, 32
+    xg, wg = np.polynomial.legendre.leggauss(n)
+    phis = np.arange(nphi) * 2 * np.pi / nphi
+    ct, ph = np.meshgrid(xg, phis, indexing="ij")
+    st = np.sqrt(1 - ct**2)
+    w = (np.repeat(wg[:, None], nphi, 1) * 2 * np.pi / nphi).ravel()
+    pts = np.stack([st * np.sin(ph), ct, st * np.cos(ph)], -1).reshape(-1, 3)
+    Y = spherical_harmonics(torch.tensor(pts), 3).numpy()
+    for l1, l2, l3 in TRIPLES:
+        C = wigner_3j(l1, l2, l3).numpy()
+        G = np.einsum("z,zi,zj,zk->ijk", w, Y[:, l1 * l1:(l1 + 1) ** 2], Y[:, l2 * l2:(l2 + 1) ** 2],
+                      Y[:, l3 * l3:(l3 + 1) ** 2])
+        if (l1 + l2 + l3) % 2:
+            assert np.abs(G).max() < 1e-12
+        else:
+            kappa = float((G * C).sum())
+            assert kappa > 0
+            np.testing.assert_allclose(G, kappa * C, atol=1e-11)
+
+
+def test_real_3j_from_sympy_clebsch_gordan_all_triples():
+    """All triples l <= 3 (odd sums included): the float Racah evaluation against sympy's exact Clebsch-Gordan
+    coefficients pushed through the published real <-> complex basis change.  For the odd-sum tensors
+    (parity=True models only) the overall sign rests on that basis change and on C^{111} = +epsilon/sqrt(6)."""
+    import sympy as sp
+    from sympy.physics.wigner import clebsch_gordan
+
+    def Q(l):
+        q = sp.zeros(2 * l + 1, 2 * l + 1)
+        r2 = 1 / sp.sqrt(2)
+        for m in range(-l, 0):
+            q[l + m, l + abs(m)] = r2
+            q[l + m, l - abs(m)] = -sp.I * r2
+        q[l, l] = 1
+        for m in range(1, l + 1):
+            q[l + m, l + abs(m)] = (-1) ** m * r2
+            q[l + m, l - abs(m)] = sp.I * (-1) ** m * r2
+        return (-sp.I) ** l * q
+
+    for l1, l2, l3 in TRIPLES:
+        cg = np.zeros((2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1), dtype=complex)
+        for m1 in range(-l1, l1 + 1):
+            for m2 in range(-l2, l2 + 1):
+                if abs(m1 + m2) <= l3:
+                    cg[l1 + m1, l2 + m2, l3 + m1 + m2] = complex(clebsch_gordan(l1, l2, l3, m1, m2, m1 + m2))
+        q1, q2, q3 = (np.array(Q(l).tolist(), dtype=complex) for l in (l1, l2, l3))
+        c = np.einsum("ij,kl,mn,ikn->jlm", q1, q2, np.conj(q3.T), cg)
+        assert np.abs(c.imag).max() < 1e-12
+        c = c.real / np.linalg.norm(c.real)
+        np.testing.assert_allclose(wigner_3j(l1, l2, l3).numpy(), c, atol=1e-12, err_msg=f"{(l1, l2, l3)}")
+
+
+def test_uvu_hand_computed_known_answers():
+    """One 'uvu' path at mul = 1, vector (x) vector, worked by hand from SURVEY.md A.2 (component normalisation, each
+    path alone in its output slot so c = sqrt(2 l3 + 1)):
+        1 (x) 1 -> 0 :  w (a . b) / sqrt(3)
+        1 (x) 1 -> 1 :  w (a x b) / sqrt(2)
+        1 (x) 1 -> 2 :  w sqrt(5) M_k : (a b^T) / sqrt(5), M_k the orthonormal symmetric traceless basis in the
+                        component order (xz, xy, 2y^2-x^2-z^2, yz, z^2-x^2)."""
+    a = torch.tensor([[0.3, -1.2, 0.7]], dtype=torch.float64)
+    b = torch.tensor([[-0.5, 0.4, 2.0]], dtype=torch.float64)
+    w = torch.tensor([[1.7]], dtype=torch.float64)
+    ax, ay, az = a[0]
+    bx, by, bz = b[0]
+    out0 = otp.tensor_product_uvu(a, b, w, "1x1o", "1x1o", "1x0e", [(0, 0, 0, "uvu", True)])
+    torch.testing.assert_close(out0, w * (a * b).sum() / math.sqrt(3))
+    out1 = otp.tensor_product_uvu(a, b, w, "1x1o", "1x1o", "1x1e", [(0, 0, 0, "uvu", True)])
+    torch.testing.assert_close(out1, w * torch.linalg.cross(a, b) / math.sqrt(2))
+    out2 = otp.tensor_product_uvu(a, b, w, "1x1o", "1x1o", "1x2e", [(0, 0, 0, "uvu", True)])
+    r2, r6 = math.sqrt(2), math.sqrt(6)
+    ref2 = torch.stack([
+        (ax * bz + az * bx) / r2,
+        (ax * by + ay * bx) / r2,
+        (2 * ay * by - ax * bx - az * bz) / r6,
+        (ay * bz + az * by) / r2,
+        (az * bz - ax * bx) / r2,
+    ]).view(1, 5) * w
+    torch.testing.assert_close(out2, ref2)
+    # two paths into one slot: alpha = (2 l3 + 1) / 2 each
+    bb = torch.cat([b, 2 * b], dim=1)
+    out = otp.tensor_product_uvu(a, bb, torch.tensor([[1.7, -0.4]], dtype=torch.float64), "1x1o", "1x1o+1x1o", "1x0e",
+                                 [(0, 0, 0, "uvu", True), (0, 1, 0, "uvu", True)])
+    torch.testing.assert_close(out, (1.7 - 0.8) * (a * b).sum().view(1, 1) / math.sqrt(3) / math.sqrt(2))
