@@ -37,6 +37,15 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libnequip_amd.so (set HIPCC or install ROCm)")
 
 
+def _extra_flags(src: str) -> list:
+    """Per-source flags.  generated_spec/*: no SLP vectorisation -- in the forward tensor-product kernels the packed
+    fp32 ops it forms (v_pk_mul/fma_f32) cost more register shuffles (294 v_mov of 775 VALU instructions in the cfg-3
+    middle layer) than they save, and 146 instead of 107 VGPRs, i.e. three instead of four wavefronts per SIMD."""
+    if os.path.basename(os.path.dirname(src)) == "generated_spec" and os.environ.get("NQA_SPEC_SLP", "") in ("", "0"):
+        return ["-fno-slp-vectorize"]
+    return []
+
+
 def _flags() -> list:
     return [
         f"--offload-arch={ARCH}",
@@ -97,10 +106,10 @@ def _compile_one(src: str, force: bool) -> str:
     src_path = os.path.join(HERE, src)
     obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
     stamp = obj + ".stamp"
-    want = _digest([src_path] + _headers())
+    want = _digest([src_path] + _headers()) + "|" + " ".join(_extra_flags(src_path))
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return obj
-    cmd = [_hipcc()] + _flags() + ["-c", src_path, "-o", obj]
+    cmd = [_hipcc()] + _flags() + _extra_flags(src_path) + ["-c", src_path, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
