@@ -560,17 +560,18 @@ struct GateArgs {
   int64_t N;
 };
 
-constexpr int kGateAtoms = 16;  // atoms per workgroup: a thread keeps its column's table record in registers for all of them
+constexpr int kGateAtoms = 2;  // atoms per thread (unrolled: all their loads in flight at once).  16 serial atoms per
+// thread left the launch latency-bound (12 / 32 us for the 10 125-atom cfg-3 rows, 51 MB of traffic)
 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateArgs<T> a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // output column
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;  // output column
   if (c >= a.dout) return;
   const GateCol t = a.cols[c];
   const T cst = (T)t.cst;
-  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z0 = (int64_t)blockIdx.x * kGateAtoms;
   const int64_t z1 = min(z0 + kGateAtoms, a.N);
-#pragma unroll 4
+#pragma unroll
   for (int64_t z = z0; z < z1; ++z) {
     const T* __restrict__ row = a.in + z * a.din;
     const T xs = row[t.a];
@@ -580,13 +581,13 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateArgs<T> a) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateArgs<T> a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // input column
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;  // input column
   if (c >= a.din) return;
   const GateCol t = a.cols[c];
   const T cst = (T)t.cst;
-  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z0 = (int64_t)blockIdx.x * kGateAtoms;
   const int64_t z1 = min(z0 + kGateAtoms, a.N);
-#pragma unroll 4
+#pragma unroll
   for (int64_t z = z0; z < z1; ++z) {
     const T* __restrict__ row = a.in + z * a.din;
     const T* __restrict__ g = a.gout + z * a.dout;
@@ -615,13 +616,13 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateArgs<T> a) {
 //       gated v_i:  c_q a'(x_q) g_o
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_bwd_g_kernel(const GateArgs<T> a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // output column
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;  // output column
   if (c >= a.dout) return;
   const GateCol t = a.cols[c];
   const T cst = (T)t.cst;
-  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z0 = (int64_t)blockIdx.x * kGateAtoms;
   const int64_t z1 = min(z0 + kGateAtoms, a.N);
-#pragma unroll 4
+#pragma unroll
   for (int64_t z = z0; z < z1; ++z) {
     const T* __restrict__ row = a.in + z * a.din;
     const T* __restrict__ ct = a.cot + z * a.din;
@@ -638,13 +639,13 @@ __global__ __launch_bounds__(256) void gate_bwd_bwd_g_kernel(const GateArgs<T> a
 
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_bwd_x_kernel(const GateArgs<T> a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // input column
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;  // input column
   if (c >= a.din) return;
   const GateCol t = a.cols[c];
   const T cst = (T)t.cst;
-  const int64_t z0 = (int64_t)blockIdx.y * kGateAtoms;
+  const int64_t z0 = (int64_t)blockIdx.x * kGateAtoms;
   const int64_t z1 = min(z0 + kGateAtoms, a.N);
-#pragma unroll 4
+#pragma unroll
   for (int64_t z = z0; z < z1; ++z) {
     const T* __restrict__ row = a.in + z * a.din;
     const T* __restrict__ g = a.gout + z * a.dout;
@@ -832,7 +833,7 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
     return NQA_ERR_UNSUPPORTED;
   }
   const unsigned bdim = cols >= 256 ? 256u : (unsigned)(((cols + 63) / 64) * 64);
-  const dim3 grid((unsigned)((cols + bdim - 1) / bdim), (unsigned)ny);
+  const dim3 grid((unsigned)ny, (unsigned)((cols + bdim - 1) / bdim));
 #define NQA_GATE_LAUNCH(T)                                                                        \
   {                                                                                               \
     GateArgs<T> a{};                                                                              \

@@ -663,6 +663,186 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
     emit(a1A, a1B, ntiles - 1);
 }
 
+// Balanced forward (inference): the launch is a fixed grid of 2 workgroups per CU, and workgroup g owns the contiguous
+// range [g U / G, (g + 1) U / G) of the U = (128-row blocks) x (32-column tiles) work units in block-major order.
+// With one workgroup per block the 1565 blocks of the cfg-3 pair list run in 3.06 rounds over the 512 slots -- the
+// fourth, almost empty round costs a quarter of the kernel; here every slot gets 67.2 +- 1 tiles.  K is never split
+// (a unit is a complete 128 x 32 output tile), so no fix-up pass is needed; a workgroup that enters a block in the
+// middle recomputes that block's hidden layer (about 0.7 tile-times, at most two extra blocks per workgroup).
+// The tile pipeline (weight tiles two ahead, alternating accumulator sets, epilogue of unit i-1 behind the first
+// k-steps of unit i) runs straight across block boundaries; the next block's embedding row is requested one tile early.
+template <int H>
+__global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const float* __restrict__ emb,
+                                                                        const float* __restrict__ W0,
+                                                                        const u32x4* __restrict__ Wf, float a0, int nb,
+                                                                        int W, int64_t E, float* __restrict__ out) {
+  constexpr int KS = H / 16;
+  constexpr int TILE = KS * 3 * 64;
+  constexpr int NTH = 256;
+  constexpr int NV = TILE / NTH;
+  static_assert(TILE % NTH == 0, "tile must divide evenly over the workgroup");
+  constexpr int kTS = 36;
+  __shared__ float w0s[H * kMaxNb];
+  __shared__ u32x4 as[2][TILE];
+  __shared__ __align__(16) float tbuf[4 * 32 * kTS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int ntiles = (W + 31) / 32;
+  const int64_t nblk = (E + kMlpRows - 1) / kMlpRows;
+  const int64_t U = nblk * ntiles;
+  const int64_t u0 = U * (int64_t)blockIdx.x / gridDim.x;
+  const int64_t u1 = U * ((int64_t)blockIdx.x + 1) / gridDim.x;
+  if (u0 >= u1) return;  // (workgroup-uniform)
+
+  auto load_ev = [&](int64_t blk, float (&ev)[kMaxNb]) __attribute__((always_inline)) {
+    const int64_t row = blk * kMlpRows + wv * 32 + l31;
+    const float* __restrict__ er = emb + (row < E ? row : (E - 1)) * nb;
+    if (nb == kMaxNb) {
+      const float4 e0 = *reinterpret_cast<const float4*>(er);
+      const float4 e1 = *reinterpret_cast<const float4*>(er + 4);
+      ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w;
+      ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < kMaxNb; ++c) ev[c] = er[c < nb ? c : nb - 1];
+#pragma unroll
+      for (int c = 0; c < kMaxNb; ++c) ev[c] = c < nb ? ev[c] : 0.f;
+    }
+  };
+  int64_t blk = u0 / ntiles;
+  int t = (int)(u0 - blk * ntiles);
+  float ev[kMaxNb], evn[kMaxNb];
+  load_ev(blk, ev);
+#pragma unroll
+  for (int c = 0; c < kMaxNb; ++c) evn[c] = 0.f;
+  for (int i = tid; i < H * kMaxNb; i += NTH) {
+    const int k = i / kMaxNb, c = i - k * kMaxNb;
+    w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
+  }
+  u32x4 pre[NV];
+  auto stage_load = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) pre[v] = Wf[(int64_t)tile * TILE + tid + v * NTH];
+  };
+  auto stage_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) as[buf][tid + v * NTH] = pre[v];
+  };
+  auto tile_after = [&](int tt, int k) { return (tt + k) % ntiles; };
+  stage_load(t);
+  stage_store(0);
+  if (u0 + 1 < u1) stage_load(tile_after(t, 1));
+  __syncthreads();
+
+  u32x4 bh[KS], bm[KS], bl[KS];
+  auto hidden = [&](const float (&e)[kMaxNb], bool row_ok) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < H / 32; ++kb) {
+      f32x16 hacc = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];
+        const float bv = half ? e[2 * s2 + 1] : e[2 * s2];
+        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float h0 = row_ok ? silu_f(hacc[r]) : 0.f;
+        const float h1 = row_ok ? silu_f(hacc[r + 1]) : 0.f;
+        uint32_t a, b, c;
+        split_pair(h0, h1, a, b, c);
+        const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
+        bh[s][tp] = a; bm[s][tp] = b; bl[s][tp] = c;
+      }
+    }
+  };
+  hidden(ev, blk * kMlpRows + wv * 32 + l31 < E);
+
+  float* __restrict__ tb = tbuf + wv * (32 * kTS);
+  auto emit = [&](const f32x16& pa, const f32x16& pb, int tile, int64_t wrow0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(tb + l31 * kTS + 8 * g + 4 * half) =
+          make_float4(pa[4 * g] + pb[4 * g], pa[4 * g + 1] + pb[4 * g + 1], pa[4 * g + 2] + pb[4 * g + 2],
+                      pa[4 * g + 3] + pb[4 * g + 3]);
+    const int n0 = tile * 32;
+    const int c4 = lane & 7, rsub = lane >> 3;
+    if (wrow0 + 32 <= E && n0 + 32 <= W) {
+      float* __restrict__ ob = out + (wrow0 + rsub) * W + n0 + 4 * c4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(ob + (int64_t)(8 * i) * W) =
+            *reinterpret_cast<const float4*>(tb + (8 * i + rsub) * kTS + 4 * c4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + rsub;
+        const float4 v = *reinterpret_cast<const float4*>(tb + r * kTS + 4 * c4);
+        if (wrow0 + r < E && n0 + 4 * c4 + 3 < W) *reinterpret_cast<float4*>(out + (wrow0 + r) * W + n0 + 4 * c4) = v;
+      }
+    }
+  };
+  // one work unit; `i` = index of the unit in this workgroup's range (selects the LDS weight buffer)
+  int prev_tile = 0;
+  int64_t prev_row0 = 0;
+  auto unit = [&](int64_t i, f32x16& accA, f32x16& accB, const f32x16& prevA, const f32x16& prevB) __attribute__((always_inline)) {
+    const int64_t left = (u1 - u0) - i;  // units left including this one
+    if (t == 0 && i > 0) {  // entering the next block: its embedding row was requested during the previous tile
+      ++blk;
+#pragma unroll
+      for (int c = 0; c < kMaxNb; ++c) ev[c] = evn[c];
+      hidden(ev, blk * kMlpRows + wv * 32 + l31 < E);
+    }
+    const int buf = (int)(i & 1);
+    if (left > 1) stage_store(buf ^ 1);
+    if (left > 2) stage_load(tile_after(t, 2));
+    if (t == ntiles - 1 && left > 1) load_ev(blk + 1, evn);
+    const u32x4* __restrict__ a = as[buf] + lane;
+    accA = (f32x16){0};
+    accB = (f32x16){0};
+    u32x4 fa[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fa[0][q] = a[q * 64];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[(s + 1) & 1][q] = a[((s + 1) * 3 + q) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
+      accA = mfma_bf16(ah, bh[s], accA);
+      accB = mfma_bf16(am, bm[s], accB);
+      accA = mfma_bf16(ah, bm[s], accA);
+      accB = mfma_bf16(ah, bl[s], accB);
+      accA = mfma_bf16(am, bh[s], accA);
+      accB = mfma_bf16(al, bh[s], accB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 1 && i > 0) {
+        emit(prevA, prevB, prev_tile, prev_row0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    lds_barrier();
+    prev_tile = t;
+    prev_row0 = blk * kMlpRows + wv * 32;
+    if (++t == ntiles) t = 0;
+  };
+  f32x16 a0A, a0B, a1A, a1B;
+  const int64_t n = u1 - u0;
+  for (int64_t i = 0; i < n; i += 2) {
+    unit(i, a0A, a0B, a1A, a1B);
+    if (i + 1 < n) unit(i + 1, a1A, a1B, a0A, a0B);
+  }
+  if (n & 1)
+    emit(a0A, a0B, prev_tile, prev_row0);
+  else
+    emit(a1A, a1B, prev_tile, prev_row0);
+}
+
 // TM (training mode, see nqa_radial_mlp_bwd_train): 0 = inference (g_emb only); 1 = additionally hid_out = silu(P)
 // and the per-workgroup partial of dW0 = emb^T (G_h silu'(P)); 2 = second order with a cotangent row block cemb:
 // Q = cemb W0, hid_out = Q silu'(P), g_emb = (Q G_h silu''(P)) W0^T, dW0 partial = emb^T (Q G_h silu'') + cemb^T (G_h silu').
@@ -1054,6 +1234,28 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
         hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<64, 4, true>), dim3(grid), dim3(256), 0, s, e, a, wf,
                            (float)alpha0, num_basis, out_features, num_edges, o, 0, c);
       return launch_status("nqa_radial_mlp_fwd_tangent");
+    }
+    // default: balanced work-unit ranges over a fixed grid of two workgroups per CU (NQA_MLP_FWD_BALANCED=0 or any
+    // ablation bit: one workgroup per 128-row block)
+    static const bool balanced = [] {
+      const char* v = std::getenv("NQA_MLP_FWD_BALANCED");
+      return v == nullptr || v[0] != '0';
+    }();
+    static const int num_cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    if (balanced && dbg == 0) {
+      const int64_t units = (int64_t)grid * ((out_features + 31) / 32);
+      const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
+      if (hidden == 128)
+        hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_bal_kernel<128>), dim3(gb), dim3(256), 0, s, e, a, wf, (float)alpha0,
+                           num_basis, out_features, num_edges, o);
+      else
+        hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_bal_kernel<64>), dim3(gb), dim3(256), 0, s, e, a, wf, (float)alpha0,
+                           num_basis, out_features, num_edges, o);
+      return launch_status("nqa_radial_mlp_fwd");
     }
     if (hidden == 128 && wide)
       hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_kernel<128, 8>), dim3(g8), dim3(512), 0, s, e, a, wf, (float)alpha0,
