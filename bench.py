@@ -518,12 +518,20 @@ def main():
     roofline = step_roofline = None
     kernels = {}
     if rank == 0 and args.kernel_steps > 0:
+        # (per-kernel durations are taken back to back on one stream: the side-stream overlap of the radial backward
+        # would make concurrent kernels stretch each other's event intervals)
+        prev_ov = os.environ.get("NQA_NO_OVERLAP")
+        os.environ["NQA_NO_OVERLAP"] = "1"
         ktimer.reset()
         ktimer.enable(True)
         for _ in range(args.kernel_steps):
             step_eager()
         torch.cuda.synchronize()
         ktimer.enable(False)
+        if prev_ov is None:
+            del os.environ["NQA_NO_OVERLAP"]
+        else:
+            os.environ["NQA_NO_OVERLAP"] = prev_ov
         kernels = ktimer.summary()
         roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, ms_per_step, args.workload,
                                                    live_pmc=(world == 1 and not args.no_pmc))
@@ -551,7 +559,9 @@ def main():
                 "atoms_per_gpu": n_atoms,
                 "edges_per_gpu": n_edges,
                 "parallelism": f"replicas x{world} (frames independent, no data-path collective)",
-                "launch": "hipGraph replay" if graph is not None else "eager",
+                "launch": ("hipGraph replay" if graph is not None else "eager")
+                + ("" if os.environ.get("NQA_NO_OVERLAP", "") not in ("", "0") else
+                   ", radial-MLP backward on a side stream (parallel graph branch)"),
             },
             "roofline": roofline,
             "step_roofline": step_roofline,

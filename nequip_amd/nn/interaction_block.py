@@ -127,8 +127,16 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             if emb_half is None or emb_half.shape[0] != pairing.num_pairs:
                 emb_half = _paired_radial.pair_rows(emb, pairing)
                 data["_nqa_edge_embedding_pairs"] = emb_half
+            # the layers of one evaluation share a side-stream queue for their radial-MLP backward launches (eval mode,
+            # gradient w.r.t. the embedding requested): see RadialBackwardQueue
+            queue = None
+            if emb_half.requires_grad and not self.training and _paired_radial.RadialBackwardQueue.enabled():
+                queue = data.get("_nqa_radial_queue")
+                if queue is None:
+                    queue = data["_nqa_radial_queue"] = _paired_radial.RadialBackwardQueue(x.device)
             x = _paired_radial.paired_radial_tp(
-                self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY], topo, pairing, emb_half
+                self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY], topo, pairing, emb_half,
+                queue,
             )
         else:
             x = self.tp_scatter(

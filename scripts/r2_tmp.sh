@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_radial_mlp.py tests/test_reference_golden.py tests/test_node_kernels.py -x -q -m gpu 2>&1 | tail -3
-for b in 1 0; do echo "balanced=$b"; E=200279 NQA_MLP_FWD_BALANCED=$b python scripts/bench_mlp.py 2>&1 | sed 's/| rocBLAS.*//'; done
-bash scripts/r2_quick_bench.sh
+for rep in 1 2; do
+for ov in 1 0; do echo "NQA_NO_OVERLAP=$ov"; NQA_NO_OVERLAP=$ov bash scripts/r2_quick_bench.sh; done
+done
+timeout 900 python -m pytest tests/test_model_parity.py tests/test_edge_pairs.py tests/test_model_properties_gpu.py -x -q -m gpu 2>&1 | tail -3
