@@ -315,8 +315,15 @@ def _emit(st: Structure) -> str:
     # generator switch (build time): pipe3 = two operand sets at three wavefronts per SIMD (default; same-box cfg-3:
     # fused backward 0.80 ms vs 0.86 for occ4 = plain loop at four wavefronts and 0.91 for plain = plain loop at three)
     be_mode = os.environ.get("NQA_GEN_BWD_EDGE", "pipe3")
-    be_pipelined = (not big) and be_mode == "pipe3"
-    be_lb = "__launch_bounds__(256)" if (big or be_mode == "plain") else ("__launch_bounds__(256, 3)" if be_pipelined else "__launch_bounds__(256, 4)")
+    # big structures (l_max = 3 middle layer: 99 accumulators, 23 paths) run at one wavefront per SIMD whatever is asked
+    # (forcing two costs 28 spilled registers and 20 % of the kernel, measured), so nothing hides an edge's load latency
+    # but the wavefront itself.  Giving them the two operand sets as well, out of the 512 registers (VGPR + AGPR) a lone
+    # wavefront owns (NQA_GEN_BIG_PIPE=1), was measured too: 357 registers, no gain on cu20k (9.98 vs 9.36 ms), and the
+    # 312-accumulator parity structure then spills 800 registers -- the plain loop stays
+    big_pipe = os.environ.get("NQA_GEN_BIG_PIPE", "0") != "0"
+    be_pipelined = be_mode == "pipe3" and (not big or big_pipe)
+    be_lb = ("__launch_bounds__(256)" if (big or be_mode == "plain")
+             else ("__launch_bounds__(256, 3)" if be_pipelined else "__launch_bounds__(256, 4)"))
     A(f"__global__ {be_lb} void bwd_edge_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -358,13 +365,21 @@ def _emit(st: Structure) -> str:
         return out
 
     def be_compute(sfx, e, rg):
+        # big structures: every path's weight gradient is stored as soon as it is formed (keeps up to kNP values out of
+        # the live set of a kernel that sits at the 256-register limit)
+        early_gw = big
         out = ["    {", "    T rr[kNP];", "    T q[kS];", "#pragma unroll", "    for (int j = 0; j < kS; ++j) q[j] = T(0);"]
+        if early_gw:
+            out.append(f"    T* __restrict__ gwr_e = GW ? a.gw + (int64_t){rg} * a.wn : nullptr;")
         for p, (b_, j, s_) in enumerate(st.instr):
             l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
             d2 = 2 * l2 + 1
             out.append(f"    {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b_}{sfx}, gv + {opre[s_]}, t);")
             terms = " + ".join(f"t[{i}] * yb{j}{sfx}[{i}]" for i in range(d2))
-            out.append(f"      if (GW) rr[{p}] = {terms};")
+            if early_gw:
+                out.append(f"      if (GW) {{ const T r_ = {terms}; if (act) *spec_at(gwr_e + (unsigned)(mul * {p}), ucb) = r_; }}")
+            else:
+                out.append(f"      if (GW) rr[{p}] = {terms};")
             out.append("      if (GY) {")
             for i in range(d2):
                 out.append(f"        q[{ypre[j] + i}] += wv{sfx}[{p}] * t[{i}];")
@@ -387,13 +402,14 @@ def _emit(st: Structure) -> str:
             out.append(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = gxa[{i}];")
         out.append("      }")
         out.append("    }")
-        out.append("    if (GW) {")
-        out.append("      if (act) {")
-        out.append(f"        T* __restrict__ gwr = a.gw + (int64_t){rg} * a.wn;")
-        for p in range(NP):
-            out.append(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
-        out.append("      }")
-        out.append("    }")
+        if not early_gw:
+            out.append("    if (GW) {")
+            out.append("      if (act) {")
+            out.append(f"        T* __restrict__ gwr = a.gw + (int64_t){rg} * a.wn;")
+            for p in range(NP):
+                out.append(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
+            out.append("      }")
+            out.append("    }")
         out.append("    if (GY) {")
         out.append(f"      T* __restrict__ gyr = a.gy + (int64_t){e} * a.gy_stride + chunk * kS;")
         out.append("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")

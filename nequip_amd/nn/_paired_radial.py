@@ -27,6 +27,15 @@ from ._topology import EdgePairing, EdgeTopology
 _side_streams = {}
 
 
+def side_stream(device: torch.device, slot: int = 0) -> torch.cuda.Stream:
+    """Process-wide side HIP streams per device (slot 0: radial-MLP backward queue, slot 1: self-connection branch)."""
+    key = (device.type, device.index, slot)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class RadialBackwardQueue:
     """The radial-MLP backward launches of one model evaluation, on a side HIP stream.
 
@@ -40,11 +49,7 @@ class RadialBackwardQueue:
     (scripts/r2_overlap.py).  Captured by hipGraphs as a parallel branch.  ``NQA_NO_OVERLAP=1`` switches it off."""
 
     def __init__(self, device: torch.device):
-        key = (device.type, device.index)
-        st = _side_streams.get(key)
-        if st is None:
-            st = _side_streams[key] = torch.cuda.Stream(device=device)
-        self.stream = st
+        self.stream = side_stream(device, 0)
         self.layers = 0
         self.acc = None
 

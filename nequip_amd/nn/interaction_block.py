@@ -93,15 +93,25 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             x = x[:num_local_nodes]
 
         sc = None
+        sc_stream = None
         if self.sc is not None:
             node_attrs = data[AtomicDataDict.NODE_ATTRS_KEY]
             if not self.is_first_layer and node_attrs.shape[0] != num_local_nodes:
                 node_attrs = node_attrs[:num_local_nodes]
             table = data.get("_nqa_node_attrs_table")
-            if table is not None and table.shape[0] <= 16:
-                sc = self.sc.forward_typed(x, data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: x.shape[0]], table)
-            else:
-                sc = self.sc(x, node_attrs)
+            # eval mode on the GPU: the self-connection is independent of linear_1 / the tensor product until `+ sc`
+            # after linear_2, so it runs as a parallel branch on a side stream (its backward too: autograd runs a node's
+            # backward on the stream of its forward); both kernels are small and latency-bound at 10k atoms
+            if (not self.training and x.is_cuda and _paired_radial.RadialBackwardQueue.enabled()
+                    and not torch.compiler.is_compiling()):
+                sc_stream = _paired_radial.side_stream(x.device, 1)
+                sc_stream.wait_stream(torch.cuda.current_stream(x.device))
+                x.record_stream(sc_stream)
+            with torch.cuda.stream(sc_stream):  # (None: current stream)
+                if table is not None and table.shape[0] <= 16:
+                    sc = self.sc.forward_typed(x, data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: x.shape[0]], table)
+                else:
+                    sc = self.sc(x, node_attrs)
 
         norm = self.avg_num_neighbors_norm
         if norm.norm_shortcut and x.is_cuda and norm.norm_key not in data:
@@ -149,6 +159,10 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         if x.shape[0] != num_local_nodes:
             x = x[:num_local_nodes]
 
+        if sc_stream is not None:
+            cur = torch.cuda.current_stream(x.device)
+            cur.wait_stream(sc_stream)
+            sc.record_stream(cur)
         # linear_2 with the residual `+ sc` fused into the same launch
         x = self.linear_2(x, addend=sc if self.sc is not None else None)
         data[AtomicDataDict.NODE_FEATURES_KEY] = x
