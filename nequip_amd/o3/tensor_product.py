@@ -56,6 +56,8 @@ class NativePlan:
         lib = _lib.load()
         self._lib = lib
         self._handle = ctypes.c_void_p()
+        # what the native object was built from: copies / pickles rebuild it (a raw handle cannot be shared or saved)
+        self._ctor_args = (irreps_in1, irreps_in2, irreps_out, list(instructions), layout_in1, layout_out)
 
         def arrs(irreps):
             return (
@@ -89,6 +91,10 @@ class NativePlan:
     @property
     def handle(self) -> ctypes.c_void_p:
         return self._handle
+
+    def __reduce__(self):
+        # copy.deepcopy(model), torch.save(model): a fresh native plan from the same description
+        return (NativePlan, self._ctor_args)
 
     def query(self, field: int) -> int:
         return int(self._lib.nqa_plan_query(self._handle, field))

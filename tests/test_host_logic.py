@@ -222,3 +222,27 @@ def test_bench_gpus_flag_is_honoured_without_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_model_survives_deepcopy_and_pickle():
+    """nequip workflows copy and save whole modules (EMA copies, torch.save of a model): the native plan handle is
+    rebuilt from its description."""
+    import copy
+    import io
+
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn.interaction_block import InteractionBlock
+
+    m = NequIPGNNModel(seed=0, model_dtype="float32", r_max=4.5, type_names=["H", "O"], num_layers=3, l_max=2,
+                       parity=False, num_features=8, radial_mlp_depth=1, radial_mlp_width=16, avg_num_neighbors=10.0)
+    m2 = copy.deepcopy(m)
+    blocks = [x for x in m2.modules() if isinstance(x, InteractionBlock)]
+    assert len(blocks) == 3
+    assert m2.state_dict().keys() == m.state_dict().keys()
+    assert len(list(m2.parameters())) == len(list(m.parameters()))
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b), k
