@@ -20,6 +20,7 @@ _INPUTS: Dict[str, str] = dict(
     BATCH_KEY="batch",
     NUM_NODES_KEY="num_atoms",
     LMP_MLIAP_DATA_KEY="lmp_mliap_data",
+    NUM_LOCAL_GHOST_NODES_KEY="num_local_ghost_atoms",
 )
 
 # per-edge quantities written by the embedding modules (an edge-vector based caller provides `edge_vectors` itself)

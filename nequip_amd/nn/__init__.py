@@ -1,4 +1,9 @@
 from ._graph_mixin import GraphModuleMixin, SequentialGraphNetwork  # noqa: F401
+from ._ghost_exchange import (  # noqa: F401
+    GhostExchangeModule,
+    LAMMPSMLIAPGhostExchangeModule,
+    NoOpGhostExchangeModule,
+)
 from ._tp_scatter_base import TensorProductScatter  # noqa: F401
 from ._topology import EdgeTopology, topology_cache  # noqa: F401
 from .atomwise import AtomwiseReduce, PerTypeScaleShift  # noqa: F401

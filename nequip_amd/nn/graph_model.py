@@ -21,6 +21,8 @@ class GraphModel(GraphModuleMixin, torch.nn.Module):
             AtomicDataDict.POSITIONS_KEY, AtomicDataDict.EDGE_INDEX_KEY, AtomicDataDict.ATOM_TYPE_KEY,
             AtomicDataDict.CELL_KEY, AtomicDataDict.EDGE_CELL_SHIFT_KEY, AtomicDataDict.BATCH_KEY,
             AtomicDataDict.NUM_NODES_KEY, AtomicDataDict.EDGE_VECTORS_KEY,
+            # local / ghost bookkeeping of a domain-decomposed caller (nequip/nn/graph_model.py:70-75)
+            AtomicDataDict.LMP_MLIAP_DATA_KEY, AtomicDataDict.NUM_LOCAL_GHOST_NODES_KEY,
         ]  # fmt: skip
         self._init_irreps(irreps_in=self.model.irreps_in, irreps_out=self.model.irreps_out)
 

@@ -13,6 +13,7 @@ from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
 from ..o3.modules import FullyConnectedTensorProduct, Linear
 from . import _paired_radial
+from ._ghost_exchange import NoOpGhostExchangeModule
 from ._graph_mixin import GraphModuleMixin
 from ._topology import topology_cache
 from ._tp_scatter_base import TensorProductScatter
@@ -82,10 +83,17 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             self.sc = FullyConnectedTensorProduct(
                 feature_irreps_in, self.irreps_in[AtomicDataDict.NODE_ATTRS_KEY], feature_irreps_out
             )
+        # ghost rows of a domain-decomposed caller are fetched here (no-op unless enable_LAMMPSMLIAPGhostExchange ran)
+        self.ghost_exchange = NoOpGhostExchangeModule(
+            field=AtomicDataDict.NODE_FEATURES_KEY, irreps_in={AtomicDataDict.NODE_FEATURES_KEY: feature_irreps_in}
+        )
         self.is_first_layer = is_first_layer
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
-        num_local_nodes = AtomicDataDict.num_nodes(data)
+        if AtomicDataDict.LMP_MLIAP_DATA_KEY in data:
+            num_local_nodes = int(data[AtomicDataDict.LMP_MLIAP_DATA_KEY].nlocal)
+        else:
+            num_local_nodes = AtomicDataDict.num_nodes(data)
         x = data[AtomicDataDict.NODE_FEATURES_KEY]
         # (`[:num_local_nodes]` as in the reference, interaction_block.py:166-168,199 -- only when there are ghost rows:
         # a no-op slice still records a SliceBackward whose backward is a zero fill + copy of the whole gradient)
@@ -121,6 +129,13 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             x = self.linear_1(x)
             data[AtomicDataDict.NODE_FEATURES_KEY] = x
             data = norm(data)
+            x = data[AtomicDataDict.NODE_FEATURES_KEY]
+
+        # ghost exchange (interaction_block.py:184-190): later layers hold local rows only, the tensor product gathers from
+        # ghosts too.  (The first layer's input is the type embedding, which already covers the ghosts.)
+        if not self.is_first_layer and not isinstance(self.ghost_exchange, NoOpGhostExchangeModule):
+            data[AtomicDataDict.NODE_FEATURES_KEY] = x
+            data = self.ghost_exchange(data, ghost_included=False)
             x = data[AtomicDataDict.NODE_FEATURES_KEY]
 
         emb = data[AtomicDataDict.EDGE_EMBEDDING_KEY]

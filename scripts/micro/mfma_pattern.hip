@@ -1,0 +1,63 @@
+// The radial-MLP forward's MFMA issue pattern in isolation (no memory, no LDS): per 32-column tile 8 k-steps x 6 split
+// products alternating two accumulators, B fragments from 96 resident VGPRs, A fragments from a rotating register set.
+// Tells how much of the kernel's distance from the bf16 MFMA ceiling is the issue pattern itself.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ f32x16 mf(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k(float* out, int tiles) {
+  u32x4 bh[8], bm[8], bl[8], fa[2][3];
+  for (int s = 0; s < 8; ++s) {
+    bh[s] = (u32x4){0x3f803f80u + threadIdx.x + s, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    bm[s] = (u32x4){0x3c003c00u + s, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    bl[s] = (u32x4){0x38003800u + s, 0x38003800u, 0x38003800u, 0x38003800u};
+  }
+  for (int q = 0; q < 3; ++q) { fa[0][q] = (u32x4){0x3f803f80u + q, 1, 2, 3}; fa[1][q] = (u32x4){0x3f003f00u + q, 1, 2, 3}; }
+  float sum = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    f32x16 accA = {0}, accB = {0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (MODE >= 1) __builtin_amdgcn_sched_barrier(0);
+      const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
+      accA = mf(ah, bh[s], accA);
+      accB = mf(am, bm[s], accB);
+      accA = mf(ah, bm[s], accA);
+      accB = mf(ah, bl[s], accB);
+      accA = mf(am, bh[s], accA);
+      accB = mf(al, bh[s], accB);
+      if (MODE >= 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE >= 2) {  // the epilogue's register read-out (sum of the two sets), as the real kernel does per tile
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += accA[r] + accB[r];
+    } else {
+      sum += accA[0] + accB[0];
+    }
+  }
+  if (sum == 12345.f) out[0] = sum;
+}
+template <typename K>
+static double run(K kern, int blocks, int tiles) {
+  float* d; hipMalloc(&d, 4);
+  hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, tiles); hipDeviceSynchronize();
+  hipEventRecord(s);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, tiles);
+  hipEventRecord(e); hipEventSynchronize(e);
+  float ms; hipEventElapsedTime(&ms, s, e); hipFree(d);
+  return (double)blocks * 4 * tiles * 48 * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12;
+}
+int main() {
+  for (int wps : {1, 2}) {
+    const int blocks = 256 * wps;
+    printf("%d wave/SIMD: plain %.0f TF  sched_barrier %.0f TF  + per-tile read-out %.0f TF\n", wps,
+           run(k<0>, blocks, 2000), run(k<1>, blocks, 2000), run(k<2>, blocks, 2000));
+  }
+  return 0;
+}
