@@ -25,7 +25,10 @@ from typing import List, Sequence, Tuple
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
 
+import numpy as np  # noqa: E402
+
 from nequip_amd.o3.irreps import Irreps  # noqa: E402
+from nequip_amd.o3.wigner import wigner_3j  # noqa: E402
 
 
 class Structure:
@@ -322,8 +325,9 @@ def _emit(st: Structure) -> str:
     # 312-accumulator parity structure then spills 800 registers -- the plain loop stays
     big_pipe = os.environ.get("NQA_GEN_BIG_PIPE", "0") != "0"
     be_pipelined = be_mode == "pipe3" and (not big or big_pipe)
+    fused_occ = os.environ.get("NQA_GEN_FUSED_OCC", "3")  # wavefronts per SIMD asked for the fused instantiation
     be_lb = ("__launch_bounds__(256)" if (big or be_mode == "plain")
-             else ("__launch_bounds__(256, 3)" if be_pipelined else "__launch_bounds__(256, 4)"))
+             else (f"__launch_bounds__(256, FUSED ? {fused_occ} : 3)" if be_pipelined else "__launch_bounds__(256, 4)"))
     A(f"__global__ {be_lb} void bwd_edge_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -339,16 +343,28 @@ def _emit(st: Structure) -> str:
     A("  const bool act = u < mul;")
     A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
     A("  if (beg + wsub >= end) return;")
+    L.extend(lane_offsets("  ", want_x=True, want_g=True))
     A("  T gv[kOD];")
     A("  {")
+    A("    // unpredicated loads from the clamped channel (all requests in flight at once, contiguous components merge into")
+    A("    // wide loads), masked afterwards: `act ? load : 0` per element compiles into one branch + load + wait per value,")
+    A("    // i.e. kOD serial memory round trips before the first edge")
     A("    const T* __restrict__ gb = a.g + (int64_t)node * a.dout;")
     for s_ in range(NS):
         d3 = 2 * st.out_ls[s_] + 1
-        c = slot_coeff[s_] if slot_coeff[s_] is not None else 0.0
+        if slot_coeff[s_] is None:
+            for k in range(d3):
+                A(f"    gv[{opre[s_] + k}] = T(0);")
+            continue
         for k in range(d3):
-            A(f"    gv[{opre[s_] + k}] = act ? T({c!r}) * gb[(int64_t)mul * {opre[s_]} + (int64_t)u * {d3} + {k}] : T(0);")
+            A(f"    gv[{opre[s_] + k}] = spec_at(gb, go{s_})[{k}];")
+    for s_ in range(NS):
+        d3 = 2 * st.out_ls[s_] + 1
+        if slot_coeff[s_] is None:
+            continue
+        for k in range(d3):
+            A(f"    gv[{opre[s_] + k}] = act ? T({slot_coeff[s_]!r}) * gv[{opre[s_] + k}] : T(0);")
     A("  }")
-    L.extend(lane_offsets("  "))
 
     def be_loads(sfx, e, sv, rg):
         out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
@@ -365,52 +381,104 @@ def _emit(st: Structure) -> str:
         return out
 
     def be_compute(sfx, e, rg):
-        # big structures: every path's weight gradient is stored as soon as it is formed (keeps up to kNP values out of
-        # the live set of a kernel that sits at the 256-register limit)
-        early_gw = big
+        # every path's weight gradient is stored as soon as it is formed, and an input block's grad_x components as soon
+        # as its last path is done: keeps up to kNP + kXD values out of the live set (the fused form has to fit 168
+        # registers for three wavefronts per SIMD; 28 spilled registers doubled its time)
+        early_gw = True
         out = ["    {", "    T rr[kNP];", "    T q[kS];", "#pragma unroll", "    for (int j = 0; j < kS; ++j) q[j] = T(0);"]
         if early_gw:
-            out.append(f"    T* __restrict__ gwr_e = GW ? a.gw + (int64_t){rg} * a.wn : nullptr;")
+            out.append(f"    T* __restrict__ gwr_e = (GW || FUSED) ? a.gw + (int64_t){rg} * a.wn : nullptr;")
+
+        def emit_gw(p, expr, ind):
+            if early_gw:
+                return [f"{ind}{{ const T r_ = {expr}; if (act) *spec_at(gwr_e + (unsigned)(mul * {p}), ucb) = r_; }}"]
+            return [f"{ind}rr[{p}] = {expr};"]
+
+        # ---- fused form (all three gradients): one intermediate serves both contractions.  Per path and input component i,
+        #   T_ij = sum_k C_ijk g_k   (nnz(C) fused multiply-adds with literal coefficients)
+        #   B_j += x_i T_ij          (-> grad_w = sum_j y_j B_j,  grad_y_j += w B_j)
+        #   A_i  = sum_j y_j T_ij    (-> grad_x_i += w A_i)
+        # i.e. nnz + 2 |{(i,j)}| operations per path instead of 2 nnz + |{(i,k)}| + |{(j,k)}| for two separate
+        # contractions of C with (x, g) and (y, g): 346 instead of 429 per edge for the l_max = 2 middle layer, 1272
+        # instead of 1625 for l_max = 3 -- the kernel is bound by its vector-ALU work.
+        out.append("    if (FUSED) {")
+        out.append(f"      T* __restrict__ gxr = a.gxe + (int64_t){e} * a.din;")
+        last_path_of_block = {b_: p for p, (b_, _, _) in enumerate(st.instr)}
+        first_path_of_block = {}
+        for p, (b_, _, _) in enumerate(st.instr):
+            first_path_of_block.setdefault(b_, p)
+        contiguous = all(
+            [bb for bb, _, _ in st.instr][first_path_of_block[b_]:last_path_of_block[b_] + 1] == [b_] * (last_path_of_block[b_] - first_path_of_block[b_] + 1)
+            for b_ in first_path_of_block)
+        assert contiguous, "paths are created input-block major (interaction_block.py:89-109)"
+        out.append("      T gxa[kXD];")
+        for p, (b_, j, s_) in enumerate(st.instr):
+            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
+            d1, d2, d3 = 2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1
+            C = np.array(wigner_3j(l1, l2, l3), dtype=np.float64)
+            if first_path_of_block[b_] == p:
+                for i in range(d1):
+                    out.append(f"      gxa[{xpre[b_] + i}] = T(0);")
+            out.append(f"      {{  // path {p}: {l1} x {l2} -> {l3}")
+            bj_started = [False] * d2
+            for i in range(d1):
+                a_terms = []
+                for jj in range(d2):
+                    ks = [k for k in range(d3) if C[i, jj, k] != 0.0]
+                    if not ks:
+                        continue
+                    expr = " + ".join(f"T({float(C[i, jj, k])!r}) * gv[{opre[s_] + k}]" for k in ks)
+                    out.append(f"        const T t{i}_{jj} = {expr};")
+                    if bj_started[jj]:
+                        out.append(f"        B{jj} += xb{b_}{sfx}[{i}] * t{i}_{jj};")
+                    else:
+                        out.append(f"        T B{jj} = xb{b_}{sfx}[{i}] * t{i}_{jj};")
+                        bj_started[jj] = True
+                    a_terms.append(f"yb{j}{sfx}[{jj}] * t{i}_{jj}")
+                if a_terms:
+                    out.append(f"        gxa[{xpre[b_] + i}] += wv{sfx}[{p}] * ({' + '.join(a_terms)});")
+            live = [jj for jj in range(d2) if bj_started[jj]]
+            gw_expr = " + ".join(f"yb{j}{sfx}[{jj}] * B{jj}" for jj in live) if live else "T(0)"
+            out.extend(emit_gw(p, gw_expr, "        "))
+            for jj in live:
+                out.append(f"        q[{ypre[j] + jj}] += wv{sfx}[{p}] * B{jj};")
+            out.append("      }")
+            if last_path_of_block[b_] == p:
+                out.append("      if (act) {")
+                for i in range(d1):
+                    out.append(f"        *spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb) = gxa[{xpre[b_] + i}];")
+                out.append("      }")
+        unused = [i for b in range(NB) if b not in first_path_of_block for i in range(xpre[b], xpre[b] + 2 * st.in1_ls[b] + 1)]
+        if unused:
+            out.append("      if (act) {")
+            for i in unused:
+                out.append(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
+            out.append("      }")
+        out.append("    } else {")
+        # ---- edge operands only: B^p_j = sum_ik C^p_ijk x_i g_k through the shared pair products of cg_generated.h
         for p, (b_, j, s_) in enumerate(st.instr):
             l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
             d2 = 2 * l2 + 1
             out.append(f"    {{ T t[{d2}]; CGT<{l1},{l2},{l3}>::template ac_b<T>(xb{b_}{sfx}, gv + {opre[s_]}, t);")
             terms = " + ".join(f"t[{i}] * yb{j}{sfx}[{i}]" for i in range(d2))
-            if early_gw:
-                out.append(f"      if (GW) {{ const T r_ = {terms}; if (act) *spec_at(gwr_e + (unsigned)(mul * {p}), ucb) = r_; }}")
-            else:
-                out.append(f"      if (GW) rr[{p}] = {terms};")
+            out.append("      if (GW) {")
+            out.extend(emit_gw(p, terms, "        "))
+            out.append("      }")
             out.append("      if (GY) {")
             for i in range(d2):
                 out.append(f"        q[{ypre[j] + i}] += wv{sfx}[{p}] * t[{i}];")
             out.append("      }")
             out.append("    }")
-        out.append("    if (FUSED) {")
-        out.append("      T gxa[kXD];")
-        out.append("#pragma unroll")
-        out.append("      for (int i = 0; i < kXD; ++i) gxa[i] = T(0);")
-        for p, (b_, j, s_) in enumerate(st.instr):
-            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
-            d1 = 2 * l1 + 1
-            out.append(f"      {{ T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}{sfx}, gv + {opre[s_]}, t);")
-            for i in range(d1):
-                out.append(f"        gxa[{xpre[b_] + i}] += wv{sfx}[{p}] * t[{i}];")
-            out.append("      }")
-        out.append("      if (act) {")
-        out.append(f"        T* __restrict__ gxr = a.gxe + (int64_t){e} * a.din;")
-        for i in range(XD):
-            out.append(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = gxa[{i}];")
-        out.append("      }")
         out.append("    }")
         if not early_gw:
-            out.append("    if (GW) {")
+            out.append("    if (GW || FUSED) {")
             out.append("      if (act) {")
             out.append(f"        T* __restrict__ gwr = a.gw + (int64_t){rg} * a.wn;")
             for p in range(NP):
                 out.append(f"        *spec_at(gwr + (unsigned)(mul * {p}), ucb) = rr[{p}];")
             out.append("      }")
             out.append("    }")
-        out.append("    if (GY) {")
+        out.append("    if (GY || FUSED) {")
         out.append(f"      T* __restrict__ gyr = a.gy + (int64_t){e} * a.gy_stride + chunk * kS;")
         out.append("      spec_wave_reduce_store<T, kS>(q, gyr, lane);")
         out.append("    }")
