@@ -560,6 +560,7 @@ struct GateArgs {
   int64_t N;
 };
 
+constexpr int kGateMaxD = 9;   // 2 l + 1 for l <= 4
 constexpr int kGateAtoms = 2;  // atoms per thread (unrolled: all their loads in flight at once).  16 serial atoms per
 // thread left the launch latency-bound (12 / 32 us for the 10 125-atom cfg-3 rows, 51 MB of traffic)
 
@@ -595,8 +596,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateArgs<T> a) {
     if (t.a == 0) {
       r = g[t.c] * act_grad(t.b, row[c], cst);
     } else if (t.a == 1) {
+      // all 2 * len loads requested at once (a runtime-bounded loop issues load, wait, fma per component: the gate
+      // columns then take len serial memory round trips and the whole launch waits for them)
       T s = T(0);
-      for (int m = 0; m < t.e; ++m) s += g[t.c + m] * row[t.d + m];
+#pragma unroll
+      for (int m = 0; m < kGateMaxD; ++m) {
+        const int mm = m < t.e ? m : 0;
+        const T v = g[t.c + mm] * row[t.d + mm];
+        s += m < t.e ? v : T(0);
+      }
       r = s * act_grad(t.b, row[c], cst);
     } else if (t.a == 2) {
       r = act_eval(t.b, row[t.f], cst) * g[t.c];
@@ -655,9 +663,12 @@ __global__ __launch_bounds__(256) void gate_bwd_bwd_x_kernel(const GateArgs<T> a
       r = ct[c] * g[t.c] * act_grad2(t.b, row[c], cst);
     } else if (t.a == 1) {
       T sgv = T(0), scg = T(0);
-      for (int m = 0; m < t.e; ++m) {
-        sgv += g[t.c + m] * row[t.d + m];
-        scg += ct[t.d + m] * g[t.c + m];
+#pragma unroll
+      for (int m = 0; m < kGateMaxD; ++m) {
+        const int mm = m < t.e ? m : 0;
+        const T gm = g[t.c + mm];
+        sgv += m < t.e ? gm * row[t.d + mm] : T(0);
+        scg += m < t.e ? ct[t.d + mm] * gm : T(0);
       }
       r = ct[c] * act_grad2(t.b, row[c], cst) * sgv + act_grad(t.b, row[c], cst) * scg;
     } else if (t.a == 2) {

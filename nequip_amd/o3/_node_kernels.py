@@ -240,6 +240,7 @@ class GateMeta:
             for u in range(mul):
                 gcol = self.ns + goff + u
                 act, cst = col_act[gcol]
+                assert d <= 9, "nqa_gate unrolls the gated components up to 2 l + 1 = 9 (l <= 4)"
                 bwd[gcol] = rec.pack(1, act, out_off + u * d, in_off + u * d, cst, d, 0)
                 for m in range(d):
                     fwd[out_off + u * d + m] = rec.pack(in_off + u * d + m, gcol, act, 0, cst, 0, 0)

@@ -23,7 +23,7 @@ REGIONS = {  # region: (regexes of the main kernel family, regexes of helper ker
                     [r"spec_gy_reduce_kernel", r"tp_ypart_reduce_kernel"]),
     "tp_bwd_x": ([r"::bwd_x_kernel<", r"tp_bwd_x_kernel"], []),
     "tp_bwd_fused": ([r"::bwd_edge_kernel<float, \d, true"], [r"gx_rows_sum_kernel"]),
-    "radial_mlp_fwd": ([r"radial_mlp_fwd(_bf16x6)?_kernel"], [r"radial_mlp_split_w1_fwd_kernel"]),
+    "radial_mlp_fwd": ([r"radial_mlp_fwd(_bf16x6)?(_bal)?_kernel"], [r"radial_mlp_split_w1_fwd_kernel"]),
     "radial_mlp_bwd": ([r"radial_mlp_bwd(_bf16x6)?_kernel"],
                        [r"radial_mlp_transpose_w1_kernel", r"radial_mlp_split_w1_bwd_kernel"]),
     "node_linear": ([r"node_linear_kernel", r"node_linear_mfma_kernel"], []),
