@@ -33,15 +33,16 @@ REGIONS = {  # region: (regexes of the main kernel family, regexes of helper ker
     "edge_vectors": ([r"edge_vectors_fwd_kernel", r"edge_vectors_bwd_kernel"], []),
 }
 
-stats = glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    rows = list(csv.DictReader(open(stats[0])))
-    keep = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
-            for r in rows[:40]]
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats_top40.csv"), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
-        w.writeheader()
-        w.writerows(keep)
+for sub, suffix in (("trace", ""), ("trace_serial", "_serial")):
+    stats = glob.glob(os.path.join(out_dir, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        keep = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+                for r in rows[:40]]
+        with open(os.path.join(out_dir, f"{tag}{suffix}_kernel_stats_top40.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
+            w.writeheader()
+            w.writerows(keep)
 
 per = defaultdict(lambda: {"dispatches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
 for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
