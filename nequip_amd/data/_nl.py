@@ -26,6 +26,44 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
 
 
+def _complete_cell(cell64: torch.Tensor, pbc: Tuple[bool, bool, bool]) -> torch.Tensor:
+    """Cells with zero lattice vectors along non-periodic directions (ASE slabs / wires / molecules with pbc = (T, T, F)
+    and c = 0): complete them with unit vectors orthogonal to the others, as ``ase.geometry.complete_cell`` does and the
+    reference's backends accept -- the kernel inverts the cell.  A zero (or linearly dependent) vector along a
+    *periodic* direction is an error."""
+    c = cell64.detach().cpu().numpy().copy()
+    import numpy as np
+
+    norms = np.linalg.norm(c, axis=1)
+    missing = [i for i in range(3) if norms[i] < 1e-12]
+    if not missing:
+        if abs(np.linalg.det(c)) < 1e-12 * max(1.0, norms.prod()):
+            raise ValueError("cell vectors are linearly dependent")
+        return cell64
+    for i in missing:
+        if pbc[i]:
+            raise ValueError(f"lattice vector {i} is zero but the direction is periodic")
+    present = [i for i in range(3) if i not in missing]
+    basis = [c[i] / norms[i] for i in present]
+    for i in missing:
+        # a unit vector orthogonal to everything chosen so far (Gram-Schmidt on the coordinate axes)
+        best = None
+        for axis in np.eye(3):
+            v = axis.copy()
+            for b in basis:
+                v -= np.dot(v, b) * b
+            n = np.linalg.norm(v)
+            if best is None or n > best[0]:
+                best = (n, v)
+        v = best[1] / best[0]
+        # orthonormalise the running basis so that later completions stay orthogonal
+        c[i] = v
+        basis.append(v)
+    if abs(np.linalg.det(c)) < 1e-12:
+        raise ValueError("cell vectors are linearly dependent")
+    return torch.as_tensor(c, dtype=torch.float64, device=cell64.device).contiguous()
+
+
 def _compute_neighborlist_single_frame(
     pos: torch.Tensor,
     r_max: float,
@@ -48,6 +86,8 @@ def _compute_neighborlist_single_frame(
     N = pos.shape[0]
     pos64 = pos.detach().to(torch.float64).contiguous()
     cell64 = cell.detach().to(torch.float64).reshape(3, 3).contiguous() if cell is not None else None
+    if cell64 is not None:
+        cell64 = _complete_cell(cell64, pbc)
     pbc_dev = torch.tensor([int(b) for b in pbc], dtype=torch.int32, device=device)
     ws_bytes = lib.nqa_neighbor_list_workspace_bytes(N)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device)

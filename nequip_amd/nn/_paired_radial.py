@@ -179,7 +179,9 @@ def paired_radial_tp(edge_mlp, tp_scatter, emb, x, edge_attr, topo: EdgeTopology
     cache.validate(edge_mlp.mlp[2].weight)
     if emb_half is None:
         emb_half = pair_rows(emb, pairing)
-    if edge_mlp.training:
+    from ..utils.wgrad import differentiable_parameters
+
+    if differentiable_parameters(edge_mlp.training, edge_mlp.mlp[0].weight, edge_mlp.mlp[2].weight):
         # training: the per-module twice-differentiable Functions, on P rows instead of E (the weight gradient of the
         # pair is the sum of its two halves, folded inside the tensor-product backward)
         w_half = edge_mlp(emb_half)

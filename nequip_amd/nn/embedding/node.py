@@ -6,6 +6,7 @@ import torch
 
 from ...data import AtomicDataDict
 from ...o3.irreps import Irreps
+from ...utils.wgrad import differentiable_parameters
 from .._graph_mixin import GraphModuleMixin
 
 
@@ -24,7 +25,8 @@ class NodeTypeEmbed(GraphModuleMixin, torch.nn.Module):
         atom_types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)
         # eval mode: parameters are constants (same convention as o3.Linear) -- keeps autograd from carrying the
         # position-independent embedding through every backward kernel when only forces are requested
-        table = self.embed_module.weight if self.training else self.embed_module.weight.detach()
+        w = self.embed_module.weight
+        table = w if differentiable_parameters(self.training, w) else w.detach()
         embedding = torch.nn.functional.embedding(atom_types, table)
         data[AtomicDataDict.NODE_ATTRS_KEY] = embedding
         # node_attrs == table[types]: lets the self-connection contract its weights per type first

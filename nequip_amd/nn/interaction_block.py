@@ -12,6 +12,7 @@ import torch
 from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
 from ..o3.modules import FullyConnectedTensorProduct, Linear
+from ..utils.wgrad import differentiable_parameters
 from . import _paired_radial
 from ._ghost_exchange import NoOpGhostExchangeModule
 from ._graph_mixin import GraphModuleMixin
@@ -39,6 +40,7 @@ def uvu_paths(features_in: Irreps, edge_attr: Irreps, features_out: Irreps):
 
 class InteractionBlock(GraphModuleMixin, torch.nn.Module):
     use_sc: bool
+    paired_radial_ok: bool = True  # the edge embedding depends on |r| only (see forward)
 
     def __init__(self, irreps_in, irreps_out, radial_mlp_depth: int = 1, radial_mlp_width: int = 8,
                  use_sc: bool = True, is_first_layer: bool = False, type_names: Optional[Sequence[str]] = None,
@@ -110,8 +112,8 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             # eval mode on the GPU: the self-connection is independent of linear_1 / the tensor product until `+ sc`
             # after linear_2, so it runs as a parallel branch on a side stream (its backward too: autograd runs a node's
             # backward on the stream of its forward); both kernels are small and latency-bound at 10k atoms
-            if (not self.training and x.is_cuda and _paired_radial.RadialBackwardQueue.enabled()
-                    and not torch.compiler.is_compiling()):
+            if (not differentiable_parameters(self.training, self.sc.weight) and x.is_cuda
+                    and _paired_radial.RadialBackwardQueue.enabled() and not torch.compiler.is_compiling()):
                 sc_stream = _paired_radial.side_stream(x.device, 1)
                 sc_stream.wait_stream(torch.cuda.current_stream(x.device))
                 x.record_stream(sc_stream)
@@ -141,7 +143,13 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         emb = data[AtomicDataDict.EDGE_EMBEDDING_KEY]
         edge_index = data[AtomicDataDict.EDGE_INDEX_KEY]
         pairing = None
-        if _paired_radial.available(self.edge_mlp, self.tp_scatter, x, emb):
+        # Pairing evaluates the radial MLP once per (i <- j) / (j <- i) pair: valid because this model's edge embedding is
+        # a function of the edge length alone (`paired_radial_ok`; a builder with per-edge-type or otherwise asymmetric
+        # embeddings must set it to False).  Not used when the caller differentiates w.r.t. given edge vectors (LAMMPS
+        # ML-IAP branch, no positions): the pair's radial gradient would be attributed to one of its two edges, and the
+        # per-edge EDGE_FORCE values, unlike their per-atom sums, would differ from the reference's.
+        if (self.paired_radial_ok and AtomicDataDict.POSITIONS_KEY in data
+                and _paired_radial.available(self.edge_mlp, self.tp_scatter, x, emb)):
             # inference: the radial MLP depends on the edge length only, and the list holds both directions of every
             # interaction -- evaluate it once per pair (nn/_paired_radial.py); None if the list does not pair up
             topo = topology_cache.get(edge_index[0], edge_index[1], x.size(0))
@@ -155,7 +163,8 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             # the layers of one evaluation share a side-stream queue for their radial-MLP backward launches (eval mode,
             # gradient w.r.t. the embedding requested): see RadialBackwardQueue
             queue = None
-            if emb_half.requires_grad and not self.training and _paired_radial.RadialBackwardQueue.enabled():
+            if (emb_half.requires_grad and _paired_radial.RadialBackwardQueue.enabled()
+                    and not differentiable_parameters(self.training, self.edge_mlp.mlp[2].weight)):
                 queue = data.get("_nqa_radial_queue")
                 if queue is None:
                     queue = data["_nqa_radial_queue"] = _paired_radial.RadialBackwardQueue(x.device)

@@ -14,6 +14,7 @@ from .. import _lib
 from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
 from ..utils import ktimer
+from ..utils.wgrad import _WeightCacheMixin, differentiable_parameters
 from ._graph_mixin import GraphModuleMixin
 
 
@@ -303,7 +304,7 @@ class ScalarLinearLayer(torch.nn.Module):
                 f"alpha={float(self.alpha):.6f}")
 
 
-class ScalarMLPFunction(torch.nn.Module):
+class ScalarMLPFunction(_WeightCacheMixin, torch.nn.Module):
     def __init__(self, input_dim: int, output_dim: int, hidden_layers_depth: int = 0,
                  hidden_layers_width: Optional[int] = None, nonlinearity: Optional[str] = "silu", bias: bool = False,
                  forward_weight_init: bool = True, init_mode: str = "uniform"):
@@ -345,10 +346,11 @@ class ScalarMLPFunction(torch.nn.Module):
             if cache is None:
                 cache = self._weight_images = _WeightImages()
             cache.validate(self.mlp[2].weight)
-            if self.training and os.environ.get("NQA_MLP_TRAIN_ATEN", "") in ("", "0"):
+            diff = differentiable_parameters(self.training, self.mlp[0].weight, self.mlp[2].weight)
+            if diff and os.environ.get("NQA_MLP_TRAIN_ATEN", "") in ("", "0"):
                 return _RadialMLPTrainFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0],
                                                self._alphas[1], radial_mlp_mode(), cache)
-            if not self.training:
+            if not diff:
                 return _RadialMLPFn.apply(x, self.mlp[0].weight.detach(), self.mlp[2].weight.detach(),
                                           self._alphas[0], self._alphas[1], radial_mlp_mode(), cache)
         return self.mlp(x)

@@ -18,9 +18,10 @@ import torch
 
 from .irreps import Irrep, Irreps
 from ._node_kernels import GateMeta, NodeLinearMeta, gate as _gate_kernel, node_linear as _node_linear
+from ..utils.wgrad import _WeightCacheMixin, differentiable_parameters
 
 
-class Linear(torch.nn.Module):
+class Linear(_WeightCacheMixin, torch.nn.Module):
     """``out[z, i_out, w, m] = sum_{i_in} fan_in(i_out)^-1/2 sum_u x[z, i_in, u, m] W[u, w]`` (no bias)."""
 
     def __init__(self, irreps_in, irreps_out, internal_weights: bool = True, shared_weights: bool = True):
@@ -58,8 +59,9 @@ class Linear(torch.nn.Module):
 
     def forward(self, x: torch.Tensor, addend: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
         if x.is_cuda and x.dtype in (torch.float32, torch.float64) and self.weight_numel > 0:
-            # eval mode: parameter gradients are not produced (inference fast path, as for the radial MLP)
-            if self.training:
+            # eval mode: parameter gradients are not produced (inference fast path, as for the radial MLP) unless
+            # nequip_amd.utils.wgrad.eval_parameter_gradients(True) asks for the reference's behaviour
+            if differentiable_parameters(self.training, self.weight):
                 wp = (self.weight * self._scale_vec).unsqueeze(0)
             else:
                 # constants in eval mode: the packed (and, on first backward, transposed) weights are built once per
@@ -100,7 +102,7 @@ class Linear(torch.nn.Module):
         return f"{self.irreps_in} -> {self.irreps_out} | {self.weight_numel} weights"
 
 
-class FullyConnectedTensorProduct(torch.nn.Module):
+class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
     """Self-connection ``sc(x, node_attrs)`` with scalar (``Nx0e``) second operand.
 
     ``out[z, w, m] = (sum_paths mul1*mul2)^-1/2 sum_{u,v} W[u, v, w] x[z, u, m] a[z, v]``.
@@ -199,7 +201,7 @@ class FullyConnectedTensorProduct(torch.nn.Module):
                 perm, scale = self._contract_index(weight.device, weight.dtype)
                 return torch.mm(table, weight.index_select(0, perm).view(table.shape[1], -1) * scale)
 
-            if self.training:
+            if differentiable_parameters(self.training, self.weight):
                 wp = contract(self.weight, table)
             else:  # constants in eval mode: contracted once per (weight, table) version
                 key = (id(self.weight), self.weight.data_ptr(), self.weight._version, table._version, table.data_ptr(),

@@ -41,8 +41,15 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     """Make every rank start from rank ``src``'s weights (what DDP does at construction)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    # detach() shares the version counter with the parameter (".data" does not): the in-place broadcast then invalidates
+    # the eval-mode weight caches of the fused modules, which are keyed on it
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src=src, group=group)
+    for m in module.modules():
+        inv = getattr(m, "invalidate_weight_cache", None)
+        if inv is not None:
+            inv()
 
 
 class SimpleDDPStrategy:

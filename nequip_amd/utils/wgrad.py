@@ -47,6 +47,48 @@ def inputs_only_backward():
             _inputs_only_depth -= 1
 
 
+_eval_param_grads = False
+
+
+def eval_parameter_gradients(enabled: Optional[bool] = None) -> bool:
+    """Eval-mode modules (radial MLP, ``o3.Linear``, self-connection) treat their weights as constants: packed / split
+    weight images are cached per parameter version and no parameter gradient is produced -- the inference fast path.  The
+    reference produces parameter gradients in eval mode as well; ``eval_parameter_gradients(True)`` makes these modules use
+    their training formulation whenever grad mode is on and the weights require grad.  Returns the current setting."""
+    global _eval_param_grads
+    if enabled is not None:
+        _eval_param_grads = bool(enabled)
+    return _eval_param_grads
+
+
+def differentiable_parameters(module_training: bool, *params: torch.Tensor) -> bool:
+    """Should a module run its parameter-differentiable formulation?  (training mode, or eval with the switch above)"""
+    if module_training:
+        return True
+    return _eval_param_grads and torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
+class _WeightCacheMixin:
+    """Modules that cache derived weights in eval mode: the cache goes when the mode changes or a state dict is loaded
+    (``p.data.copy_()`` style writes bypass the version counter the cache is keyed on -- call
+    ``invalidate_weight_cache()`` after such a write)."""
+
+    _weight_cache_attrs = ("_eval_wp", "_weight_images")
+
+    def invalidate_weight_cache(self) -> None:
+        for name in self._weight_cache_attrs:
+            if name in self.__dict__:
+                del self.__dict__[name]
+
+    def train(self, mode: bool = True):
+        self.invalidate_weight_cache()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_weight_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
 class WgradTable:
     """Records ``(a_off, b_off, M, N, d, out_off)`` of one launch, kept as a host buffer (kernel arguments)."""
 
