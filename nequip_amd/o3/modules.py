@@ -64,19 +64,22 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
             if differentiable_parameters(self.training, self.weight):
                 wp = (self.weight * self._scale_vec).unsqueeze(0)
             else:
-                # constants in eval mode: the packed (and, on first backward, transposed) weights are built once per
-                # parameter version instead of with a handful of tiny kernels every step
-                key = (id(self.weight), self.weight.data_ptr(), self.weight._version, x.device, x.dtype)
-                cached = getattr(self, "_eval_wp", None)
-                if cached is None or cached[0] != key:
-                    cached = (key, (self.weight.detach() * self._scale_vec).unsqueeze(0).contiguous())
-                    self._eval_wp = cached
-                wp = cached[1]
+                wp = self.eval_weights(x.device, x.dtype)
             return _node_linear(x, wp, None, self._meta, addend=addend, scale=scale)
         out = self._forward_reference(x)
         if scale != 1.0:
             out = out * scale
         return out if addend is None else out + addend
+
+    def eval_weights(self, device, dtype) -> torch.Tensor:
+        """Packed, path-normalised weights ``[1, wstride]`` as constants (eval mode): built once per parameter version
+        instead of with a handful of tiny kernels every step; the transposed copy for the backward rides on the tensor."""
+        key = (id(self.weight), self.weight.data_ptr(), self.weight._version, device, dtype)
+        cached = getattr(self, "_eval_wp", None)
+        if cached is None or cached[0] != key:
+            cached = (key, (self.weight.detach() * self._scale_vec).unsqueeze(0).contiguous())
+            self._eval_wp = cached
+        return cached[1]
 
     def _forward_reference(self, x: torch.Tensor) -> torch.Tensor:
         """ATen formulation (CPU tensors: host-side tests of the module algebra only)."""
@@ -192,6 +195,19 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             outs[io] = r if outs[io] is None else outs[io] + r
         return self._assemble(outs, x)
 
+    def eval_weights_typed(self, table: torch.Tensor, dtype) -> torch.Tensor:
+        """Per-type pre-contracted weights ``W_t[u, w] = sum_v table[t, v] W[u, v, w]`` as constants, ``[T, wstride]``."""
+        key = (id(self.weight), self.weight.data_ptr(), self.weight._version, table._version, table.data_ptr(),
+               table.device, dtype)
+        cached = getattr(self, "_eval_wp", None)
+        if cached is None or cached[0] != key:
+            perm, scale = self._contract_index(self.weight.device, self.weight.dtype)
+            w = self.weight.detach()
+            wp = torch.mm(table.detach(), w.index_select(0, perm).view(table.shape[1], -1) * scale)
+            cached = (key, wp.contiguous())
+            self._eval_wp = cached
+        return cached[1]
+
     def forward_typed(self, x: torch.Tensor, types: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
         if x.is_cuda and self._meta is not None and x.dtype in (torch.float32, torch.float64):
             # per-type pre-contraction W_t[u, w] = sum_v table[t, v] W[u, v, w] (tiny), then ONE fused launch
@@ -204,13 +220,7 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             if differentiable_parameters(self.training, self.weight):
                 wp = contract(self.weight, table)
             else:  # constants in eval mode: contracted once per (weight, table) version
-                key = (id(self.weight), self.weight.data_ptr(), self.weight._version, table._version, table.data_ptr(),
-                       x.device, x.dtype)
-                cached = getattr(self, "_eval_wp", None)
-                if cached is None or cached[0] != key:
-                    cached = (key, contract(self.weight.detach(), table.detach()))
-                    self._eval_wp = cached
-                wp = cached[1]
+                wp = self.eval_weights_typed(table, x.dtype)
             return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)
         Z = x.shape[0]
         T = table.shape[0]
