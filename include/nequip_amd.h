@@ -432,7 +432,8 @@ int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, in
  *   j < N).  ScalarMLP layer: one record {0, 0, in, out, 1, 0} over the E edge rows; o3.Linear / FCTP: one record per
  *   (input block -> output block) matrix with d = 2l+1 over the N atom rows (mul_ir layout), row_types / n_types > 1
  *   for the per-atom-type pre-contracted self-connection weights.
- *   The reduction over rows is split into `splits` ranges (nqa_wgrad_splits suggests a count that fills the device);
+ *   The reduction over rows is split into `splits` ranges (nqa_wgrad_splits suggests a count that fills the device;
+ *   each range is covered by the four wavefronts of one workgroup, which add their tiles in a fixed order on chip);
  *   partials is [splits][n_types][out_stride] floats, every element covered by a record is written (the rest is
  *   left untouched), and the caller sums over the first axis -- deterministic, no atomics.  float32 only (fp32 MFMA).
  * ------------------------------------------------------------------------------------------- */

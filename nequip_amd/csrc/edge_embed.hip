@@ -130,14 +130,6 @@ __device__ __forceinline__ S poly_cutoff_grad(const S& x, double p, int p_int) {
   return g;
 }
 
-// torch.sinc: sin(pi t)/(pi t), 1 at t == 0
-template <typename S>
-__device__ __forceinline__ S sinc_pi(const S& t) {
-  if (val(t) == 0.0) return S(1.0);
-  const S a = kPi * t;
-  return dsin(a) / a;
-}
-
 // ---- per-edge maps, templated on the scalar type ---------------------------------------------------------------
 // geometry shared by all maps: r = |v|, u = v / max(r, 1e-12)  (torch.nn.functional.normalize)
 template <typename S>
@@ -157,18 +149,44 @@ __device__ __forceinline__ Geom<S> geom(const S& vx, const S& vy, const S& vz) {
   return g;
 }
 
-// radial embedding value (before the cast / factor): b_n(x) and cutoff(x), x = r * rr
+// Radial basis b_n(x) = w_n sinc(x w_n) (torch.sinc: sin(pi t)/(pi t)), x = r * rr, evaluated without a division or a
+// transcendental per basis function:
+//   b_n(x)  = sin(pi x w_n) / (pi x)            (the w_n of the sinc argument cancels),   b_n(0)  = w_n
+//   b_n'(x) = (w_n cos(pi x w_n) - b_n(x)) / x                                           b_n'(0) = 0
+// and, when the weights are the untrained Bessel roots w_n = n + 1 (checked on the device, wave-uniform), sin/cos of
+// (n + 1) pi x follow from ONE sin/cos pair by angle addition (error grows ~ n ulp in f64; the outputs are cast to T).
 template <typename S>
-__device__ __forceinline__ S bessel_n(const S& x, double w) {
-  return sinc_pi(x * w) * w;
-}
-// d/dx [sinc(x w) w] = w^2 (cos(pi t) - sinc(t)) / t,  t = x w
-template <typename S>
-__device__ __forceinline__ S bessel_n_grad(const S& x, double w) {
-  const S t = x * w;
-  if (val(t) == 0.0) return S(0.0);
-  return (w * w) * (dcos(kPi * t) - sinc_pi(t)) / t;
-}
+struct BesselBasis {
+  S inv_x, inv_pix, s1, c1, s, c;
+  bool zero, harmonic;
+  __device__ __forceinline__ BesselBasis(const EdgeEmbedParams& prm, const S& x) {
+    zero = val(x) == 0.0;
+    inv_x = zero ? S(0.0) : 1.0 / x;
+    inv_pix = inv_x * (1.0 / kPi);
+    harmonic = true;
+    for (int n = 0; n < prm.nb; ++n) harmonic = harmonic && (prm.bw[n] == (double)(n + 1));
+    const S a = kPi * x;
+    s1 = dsin(a);
+    c1 = dcos(a);
+    s = S(0.0);
+    c = S(1.0);
+  }
+  // advance to basis function n (call with n = 0, 1, 2, ... in order); afterwards s, c = sin, cos(pi x w_n)
+  __device__ __forceinline__ void step(const S& x, double w) {
+    if (harmonic) {
+      const S ns = s * c1 + c * s1;
+      const S nc = c * c1 - s * s1;
+      s = ns;
+      c = nc;
+    } else {
+      const S a = kPi * (x * w);
+      s = dsin(a);
+      c = dcos(a);
+    }
+  }
+  __device__ __forceinline__ S value(double w) const { return zero ? S(w) : s * inv_pix; }
+  __device__ __forceinline__ S grad(double w) const { return zero ? S(0.0) : (w * c - s * inv_pix) * inv_x; }
+};
 
 // VJP of (sh, emb) w.r.t. the edge vector for cotangents (g_sh, g_emb); returns the three components in S.
 template <typename T, int L, typename S>
@@ -203,9 +221,11 @@ __device__ __forceinline__ void embed_vjp(const EdgeEmbedParams& prm, int64_t e,
     const S dc = poly_cutoff_grad(x, prm.p, prm.p_int);
     const T* __restrict__ gi = g_emb + e * prm.nb;
     S acc = S(0.0);
+    BesselBasis<S> bb(prm, x);
     for (int n = 0; n < prm.nb; ++n) {
       const double w = prm.bw[n];
-      acc += (double)gi[n] * (bessel_n_grad(x, w) * c + bessel_n(x, w) * dc);
+      bb.step(x, w);
+      acc += (double)gi[n] * (bb.grad(w) * c + bb.value(w) * dc);
     }
     const S gr = acc * (prm.factor * rr);  // dE/dr ; d|v|/dv = u
     gx += gr * gm.ux;
@@ -239,8 +259,11 @@ __global__ __launch_bounds__(256) void edge_embed_fwd_kernel(const EdgeEmbedPara
     if (emb != nullptr) {
       const T f = (T)prm.factor;
       T* __restrict__ o = emb + e * prm.nb;
+      BesselBasis<double> bb(prm, x);
       for (int n = 0; n < prm.nb; ++n) {
-        const T b = (T)bessel_n<double>(x, prm.bw[n]);
+        const double w = prm.bw[n];
+        bb.step(x, w);
+        const T b = (T)bb.value(w);
         o[n] = f * (b * c);  // same rounding order as the reference: factor * (bessel.to(T) * cutoff.to(T))
       }
     }
@@ -295,8 +318,11 @@ __global__ __launch_bounds__(256) void edge_embed_bwd_bwd_kernel(const EdgeEmbed
     const Dual x = gm.r * rr;
     const Dual cf = poly_cutoff<Dual>(x, prm.p, prm.p_int);
     T* __restrict__ o = gg_emb + e * prm.nb;
+    BesselBasis<Dual> bb(prm, x);
     for (int n = 0; n < prm.nb; ++n) {
-      const Dual b = bessel_n<Dual>(x, prm.bw[n]);
+      const double w = prm.bw[n];
+      bb.step(x, w);
+      const Dual b = bb.value(w);
       o[n] = (T)(prm.factor * (b.d * cf.v + b.v * cf.d));
     }
   }

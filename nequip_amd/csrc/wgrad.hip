@@ -8,11 +8,14 @@
 // step.  Here the reduction is split over S row ranges; one wavefront owns a (<=128) x 64 output tile of one range and
 // feeds fp32 MFMA 32x32x2 straight from global memory -- both operands are read in their natural row-major layout
 // (lane = output row / column, the two k-slots of the instruction = two consecutive rows), so there is no transposition
-// and no LDS.  The S partial tiles are written to a workspace [S][n_types][weight_numel]; the caller sums over S
-// (deterministic: no atomics).  Operands of the next step are loaded before the MFMAs of the current one.
+// and no LDS in the main loop.  The four wavefronts of a workgroup own four consecutive row ranges of the SAME output
+// tile and add their accumulators through LDS (fixed order) before one of them stores the tile: S partial tiles go to a
+// workspace [S][n_types][weight_numel] (a quarter of the wavefronts' count), the caller sums over S (deterministic: no
+// atomics).  Operands of the next step are loaded before the MFMAs of the current one.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -42,11 +45,13 @@ struct WgradArgs {
 typedef float wg_f16 __attribute__((ext_vector_type(16)));
 
 // RB: 32-row blocks of the output tile owned by a wavefront (M <= 32*RB per tile), two 32-column blocks.
-template <int RB, bool TYPED>
+// WGRED: the four wavefronts of a workgroup share one (tile, partial) unit (reduced on chip); otherwise one unit each
+template <int RB, bool TYPED, bool WGRED>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
-  const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (unit >= a.total_units) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int unit = WGRED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (!WGRED && unit >= a.total_units) return;
   int qi = 0;
   while (qi + 1 < a.n_instr && a.instr[qi + 1].unit_begin <= unit) ++qi;
   const WgradInstr q = a.instr[qi];
@@ -59,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const int s = local % a.S;
   const int t = local / a.S;
   const int m0 = mt_i * 32 * RB, n0 = nt_i * 64;
-  const int64_t z_begin = (int64_t)s * a.zc;
+  const int64_t z_begin0 = (WGRED ? (int64_t)s * 4 + wave : (int64_t)s) * a.zc;  // zc: rows per wavefront
+  const int64_t z_begin = z_begin0 < a.Z ? z_begin0 : a.Z;
   const int64_t z_end = z_begin + a.zc < a.Z ? z_begin + a.zc : a.Z;
 
   // addressing: wave-uniform base of the step's first row (scalar registers) + a 32-bit per-lane byte offset
@@ -159,6 +165,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       phase(1, 0);
     }
   }
+  // workgroup reduction in a fixed order: wavefronts 1..3 hand their accumulators to wavefront 0 through LDS
+  __shared__ float red[WGRED ? RB * 2 * 16 * 64 : 1];
+#pragma unroll 1
+  for (int src = 1; WGRED && src < 4; ++src) {
+    if (wave == src) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((rb * 2 + cb) * 16 + r) * 64 + lane] = acc[rb][cb][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][cb][r] += red[((rb * 2 + cb) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (WGRED && wave != 0) return;
   float* outp = a.partials + ((int64_t)s * a.T + t) * a.out_stride + q.out_off;
   const bool full = (m0 + 32 * RB <= q.M) && (n0 + 64 <= q.N);  // wave-uniform: interior tiles store unpredicated
 #pragma unroll
@@ -188,6 +218,14 @@ using namespace nqa;
 
 extern "C" {
 
+static bool wgrad_wg_reduce() {
+  static const bool on = [] {
+    const char* e = std::getenv("NQA_WGRAD_WG_REDUCE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int32_t nqa_wgrad_splits(const void* instr_table, int32_t n_instr, int32_t n_types, int64_t num_rows) {
   if (!instr_table || n_instr <= 0 || n_instr > kMaxWgradInstr || n_types < 1 || num_rows < 0) return NQA_ERR_INVALID;
   const int32_t* tab = static_cast<const int32_t*>(instr_table);
@@ -201,9 +239,10 @@ int32_t nqa_wgrad_splits(const void* instr_table, int32_t n_instr, int32_t n_typ
   }
   tiles *= n_types;
   if (tiles <= 0) return NQA_ERR_INVALID;
-  // ~2 wavefronts per SIMD on 256 CUs, at least 64 rows per split
-  int64_t S = (2048 + tiles - 1) / tiles;
-  const int64_t max_s = (num_rows + 63) / 64;
+  // ~2 wavefronts per SIMD on 256 CUs (four wavefronts = one workgroup per partial), at least 64 rows per wavefront
+  const int wpu = wgrad_wg_reduce() ? 4 : 1;  // wavefronts per partial
+  int64_t S = (2048 / wpu + tiles - 1) / tiles;
+  const int64_t max_s = (num_rows + 64 * wpu - 1) / (64 * wpu);
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;
   return (int32_t)S;
@@ -241,7 +280,9 @@ int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64
   a.T = n_types;
   a.S = splits;
   a.n_instr = n_instr;
-  int64_t zc = (num_rows + splits - 1) / splits;
+  const bool wgred = wgrad_wg_reduce();
+  const int64_t nranges = (wgred ? 4 : 1) * (int64_t)splits;
+  int64_t zc = (num_rows + nranges - 1) / nranges;  // rows per wavefront
   zc = (zc + 2 * kWgU - 1) / (2 * kWgU) * (2 * kWgU);
   if (zc > 2147483647LL / 2) {
     set_error("nqa_wgrad: split too long");
@@ -276,12 +317,15 @@ int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64
     }
   }
   a.total_units = (int32_t)units;
-  const dim3 grid((unsigned)((units + 3) / 4));
+  const dim3 grid((unsigned)(wgred ? units : (units + 3) / 4));
 #define NQA_WGRAD_LAUNCH(R)                                                        \
-  if (a.types != nullptr)                                                          \
-    hipLaunchKernelGGL((wgrad_kernel<R, true>), grid, dim3(256), 0, s, a);         \
-  else                                                                             \
-    hipLaunchKernelGGL((wgrad_kernel<R, false>), grid, dim3(256), 0, s, a);
+  if (a.types != nullptr) {                                                        \
+    if (wgred) hipLaunchKernelGGL((wgrad_kernel<R, true, true>), grid, dim3(256), 0, s, a);    \
+    else hipLaunchKernelGGL((wgrad_kernel<R, true, false>), grid, dim3(256), 0, s, a);         \
+  } else {                                                                         \
+    if (wgred) hipLaunchKernelGGL((wgrad_kernel<R, false, true>), grid, dim3(256), 0, s, a);   \
+    else hipLaunchKernelGGL((wgrad_kernel<R, false, false>), grid, dim3(256), 0, s, a);        \
+  }
   if (RB == 1) {
     NQA_WGRAD_LAUNCH(1)
   } else if (RB == 2) {

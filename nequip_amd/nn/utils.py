@@ -103,6 +103,8 @@ class _EdgeVectorsAdjFn(torch.autograd.Function):
             if batch is None or nframes == 1:
                 g_cell = part.sum(0).view(cell_shape)
             else:
+                # (a dense one-hot product instead of these atomics was measured: rocBLAS runs the float64
+                # [frames, N] x [N, 9] shape in 235 us against 38 us for index_add_)
                 g_cell = torch.zeros((nframes, 9), dtype=torch.float64, device=g.device).index_add_(0, batch, part)
                 g_cell = g_cell.view(cell_shape)
         ctx.edge_index, ctx.shift, ctx.batch = edge_index, shift, batch

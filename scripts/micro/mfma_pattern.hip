@@ -18,6 +18,14 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int tiles) {
     bl[s] = (u32x4){0x38003800u + s, 0x38003800u, 0x38003800u, 0x38003800u};
   }
   for (int q = 0; q < 3; ++q) { fa[0][q] = (u32x4){0x3f803f80u + q, 1, 2, 3}; fa[1][q] = (u32x4){0x3f003f00u + q, 1, 2, 3}; }
+  if (MODE >= 3) {  // realistic bit toggling (power): pseudo-random mantissas, exponents near 1 / 2^-8 / 2^-16
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    auto rnd = [&](unsigned base) { h = h * 1664525u + 1013904223u; return base ^ ((h >> 9) & 0x807f807fu); };
+    for (int s = 0; s < 8; ++s)
+      for (int j = 0; j < 4; ++j) { bh[s][j] = rnd(0x3f003f00u); bm[s][j] = rnd(0x3b003b00u); bl[s][j] = rnd(0x37003700u); }
+    for (int q = 0; q < 3; ++q)
+      for (int j = 0; j < 4; ++j) { fa[0][q][j] = rnd(0x3f003f00u >> (8 * q) | 0x30003000u); fa[1][q][j] = rnd(0x3e803e80u); }
+  }
   float sum = 0.f;
   for (int t = 0; t < tiles; ++t) {
     f32x16 accA = {0}, accB = {0};
@@ -59,5 +67,9 @@ int main() {
     printf("%d wave/SIMD: plain %.0f TF  sched_barrier %.0f TF  + per-tile read-out %.0f TF\n", wps,
            run(k<0>, blocks, 2000), run(k<1>, blocks, 2000), run(k<2>, blocks, 2000));
   }
+  // sustained issue (clock / power management): the same pattern for ~3, ~30 and ~300 ms, constant vs random operands
+  for (int tiles : {2000, 20000, 200000})
+    printf("2 waves/SIMD, %6d tiles: constant operands %.0f TF, random operands %.0f TF\n", tiles, run(k<1>, 512, tiles),
+           run(k<3>, 512, tiles));
   return 0;
 }

@@ -22,7 +22,10 @@ def _vectors(E, seed=0, r_lo=0.6, r_hi=5.2):
 @pytest.mark.gpu
 @pytest.mark.parametrize("lmax", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_sh_and_radial_forward_backward(device, lmax, dtype):
+@pytest.mark.parametrize("trained", [False, True])
+def test_sh_and_radial_forward_backward(device, lmax, dtype, trained):
+    # trained = True: Bessel weights moved off the roots n + 1 (the kernel's angle-addition path only applies to the
+    # untrained roots; any other weights take one sin/cos per basis function)
     from nequip_amd.nn.embedding._edge import _EdgeEmbedFn
 
     tol = 1e-5 if dtype == torch.float32 else 1e-9
@@ -30,11 +33,13 @@ def test_sh_and_radial_forward_backward(device, lmax, dtype):
     vec = _vectors(E, seed=lmax)
     vec[0] = torch.tensor([0.0, 4.5 * 1.2, 0.0])  # beyond the cutoff, on the polar axis
     bw = torch.linspace(1.0, nb, nb, dtype=torch.float64)
+    if trained:
+        bw = bw + 0.07 * torch.randn(nb, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
     factor = 2 * math.pi / (r_max * r_max)
 
     v_ref = vec.clone().requires_grad_(True)
     sh_ref = onn.sh_edge_attrs(v_ref, lmax, dtype)
-    emb_ref, _ = onn.bessel_embedding(v_ref, r_max, nb, p, dtype)
+    emb_ref, _ = onn.bessel_embedding(v_ref, r_max, nb, p, dtype, bessel_weights=bw.unsqueeze(0))
 
     v_dev = vec.to(device).requires_grad_(True)
     cfg = dict(dtype=dtype, lmax=lmax, want_sh=True, want_emb=True, nb=nb, rmax_recip=1.0 / r_max, p=p, factor=factor)
