@@ -43,6 +43,7 @@ TRAIN_WORKLOADS = {
 WORKLOADS = {
     # name: (box builder kwargs, model kwargs)
     "water10k": dict(box="water", n_side=15, l_max=2, num_features=64, num_layers=3),
+    "water81k": dict(box="water", n_side=30, l_max=2, num_features=64, num_layers=3),  # 8 x the default box
     "si1k": dict(box="si", reps=5, l_max=2, num_features=64, num_layers=3),
     "water_small": dict(box="water", n_side=5, l_max=2, num_features=64, num_layers=3),
     # BASELINE config 5: 100k-atom fcc Cu, l_max=3, 128 features (cu20k: same model on a fifth of the box)

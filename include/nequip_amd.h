@@ -423,6 +423,29 @@ int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, in
                                 int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Pair-centric backward of the tensor-product scatter with paired radial weights (all three gradients in one pass;
+ *   replaces, like nqa_tp_scatter_bwd_fused_paired, autograd's backward of `out = scatter(tp(x[src], y, w), dst)`,
+ *   nequip/nn/_tp_scatter_base.py:33-38, for the case where `w` holds one row per reverse-edge pair).
+ *   Every pair p = {other -> owner, owner -> other} has an owner node; the owner's wavefront evaluates both directed
+ *   edges, so the weight row is read once, grad_w = [num_pairs, weight_numel] leaves ALREADY SUMMED over the two
+ *   directed edges (no halves), and one per-pair row of grad_x contributions (instead of one per edge) goes through the
+ *   workspace.  The pair lists (int32, device), P = num_edges / 2 slots grouped by owner:
+ *     owner_rowptr [N+1]; per slot: pair_other (the other node), pair_row (row of w / grad_w), pair_edge_in (the edge
+ *     other -> owner, i.e. dst = owner), pair_edge_out (owner -> other);  other_rowptr [N+1] / other_slot [P]: the slots
+ *     grouped by their `other` node.  Any assignment of owners is valid; a balanced one halves every node's list.
+ *   grad_y [E, dim_in2] per directed edge, grad_x [N, dim_in1] or NULL (grad_w and grad_y only: other_rowptr /
+ *   other_slot are then not read).  float32 structure-specialised plans whose register
+ *   budget allows it: nqa_tp_bwd_pairs_workspace_bytes returns -1 otherwise (use the per-edge entry points).
+ * ------------------------------------------------------------------------------------------- */
+int64_t nqa_tp_bwd_pairs_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges);
+int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                             const void* w, const void* grad_out, const int32_t* owner_rowptr,
+                             const int32_t* pair_other, const int32_t* pair_row, const int32_t* pair_edge_in,
+                             const int32_t* pair_edge_out, const int32_t* other_rowptr, const int32_t* other_slot,
+                             void* grad_w, void* grad_y, void* grad_x, void* workspace, int64_t workspace_bytes,
+                             int64_t num_nodes, int64_t num_edges, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Parameter gradients of the dense maps of the path (training; in the reference these come out of autograd as the
  *   weight-side `mm` / `einsum` backward of ScalarLinearLayer.forward (nequip/nn/mlp.py:262-268), e3nn o3.Linear
  *   (nequip/nn/interaction_block.py:82-87,129-138) and the self-connection FullyConnectedTensorProduct (:142-146)):

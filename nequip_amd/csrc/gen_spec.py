@@ -312,7 +312,10 @@ def _emit(st: Structure) -> str:
     # One contraction serves both edge gradients:  B^p_j = sum_ik C^p_ijk x_i g_k  gives  gw_p = sum_j y_j B^p_j  and
     # gy_j += w_p B^p_j.  FUSED additionally forms A^p_i = sum_jk C^p_ijk y_j g_k and emits the edge's contribution
     # w_p A^p_i to grad_x[src] (grad_out[dst] is already in registers), summed per source node afterwards.
-    A("template <typename T, int WPN, bool FUSED, bool GW, bool GY>")
+    # FULL: mul is a multiple of 64, every lane owns a channel -- `act` is a compile-time true, so the per-path stores
+    # inside the edge loop are plain stores instead of one exec-mask branch region each (16 of them split the loop body
+    # of the l_max = 2 middle layer into as many scheduling regions)
+    A("template <typename T, int WPN, bool FUSED, bool GW, bool GY, bool FULL>")
     # l_max <= 2 structures sit at ~130 VGPRs: asking for four wavefronts per SIMD (128 registers) costs a couple of
     # spills and buys a third more loads in flight; the big l_max = 3 structures spill heavily under any bound
     # generator switch (build time): pipe3 = two operand sets at three wavefronts per SIMD (default; same-box cfg-3:
@@ -340,7 +343,7 @@ def _emit(st: Structure) -> str:
     A("  const int node = spec_uniform((int)(item / nchunk));")
     A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
     A("  const int u = chunk * 64 + lane;")
-    A("  const bool act = u < mul;")
+    A("  const bool act = FULL || (u < mul);")
     A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
     A("  if (beg + wsub >= end) return;")
     L.extend(lane_offsets("  ", want_x=True, want_g=True))
@@ -370,15 +373,36 @@ def _emit(st: Structure) -> str:
         out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
                f"      const T* __restrict__ yr = a.y + (int64_t){e} * kS;",
                f"      const T* __restrict__ wr = a.w + (int64_t)spec_wrow_of(a, {rg}) * a.wn;"]
-        out += load_x("      ", "xr", sfx=sfx, decl=False)
+        if probe & 8:
+            out.append("      if (!FUSED) {")
+            out += load_x("        ", "xr", sfx=sfx, decl=False)
+            out.append("      } else {")
+            for b in used_blocks:
+                for i in range(2 * st.in1_ls[b] + 1):
+                    out.append(f"        xb{b}{sfx}[{i}] = T(0.5) + T({i}) * probe_sink;")
+            out.append("      }")
+        else:
+            out += load_x("      ", "xr", sfx=sfx, decl=False)
         out.append("      if (GY || FUSED) {")
-        out += load_w("        ", "wr", sfx=sfx, decl=False)
+        if probe & 2:
+            out.append("        if (!FUSED) {")
+            out += load_w("          ", "wr", sfx=sfx, decl=False)
+            out.append("        } else {")
+            for p in range(NP):
+                out.append(f"          wv{sfx}[{p}] = T({0.3 + 0.01 * p!r}) + probe_sink;")
+            out.append("        }")
+        else:
+            out += load_w("        ", "wr", sfx=sfx, decl=False)
         out.append("      }")
         out.append("      if (GW || FUSED) {")
         out += load_y("        ", "yr", sfx=sfx, decl=False)
         out.append("      }")
         out.append("    }")
         return out
+
+    # timing probes of the fused backward (wrong results, never shipped): bit 1 no grad_w stores, 2 no weight loads,
+    # 4 no per-edge grad_x rows, 8 no x gather
+    probe = int(os.environ.get("NQA_GEN_PROBE", "0"))
 
     def be_compute(sfx, e, rg):
         # every path's weight gradient is stored as soon as it is formed, and an input block's grad_x components as soon
@@ -390,6 +414,8 @@ def _emit(st: Structure) -> str:
             out.append(f"    T* __restrict__ gwr_e = (GW || FUSED) ? a.gw + (int64_t){rg} * a.wn : nullptr;")
 
         def emit_gw(p, expr, ind):
+            if early_gw and (probe & 1):
+                return [f"{ind}{{ const T r_ = {expr}; if (FUSED) probe_sink += r_; else if (act) *spec_at(gwr_e + (unsigned)(mul * {p}), ucb) = r_; }}"]
             if early_gw:
                 return [f"{ind}{{ const T r_ = {expr}; if (act) *spec_at(gwr_e + (unsigned)(mul * {p}), ucb) = r_; }}"]
             return [f"{ind}rr[{p}] = {expr};"]
@@ -443,7 +469,10 @@ def _emit(st: Structure) -> str:
             for jj in live:
                 out.append(f"        q[{ypre[j] + jj}] += wv{sfx}[{p}] * B{jj};")
             out.append("      }")
-            if last_path_of_block[b_] == p:
+            if last_path_of_block[b_] == p and (probe & 4):
+                for i in range(d1):
+                    out.append(f"      probe_sink += gxa[{xpre[b_] + i}];")
+            elif last_path_of_block[b_] == p:
                 out.append("      if (act) {")
                 for i in range(d1):
                     out.append(f"        *spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb) = gxa[{xpre[b_] + i}];")
@@ -485,6 +514,7 @@ def _emit(st: Structure) -> str:
         out.append("    }")
         return out
 
+    A("  T probe_sink = T(0);")
     A("  int idx = beg + wsub;")
     if be_pipelined:
         A("  // Two operand sets (A/B) as in the forward kernel: the rows of edge i+1 are requested before edge i is")
@@ -522,6 +552,8 @@ def _emit(st: Structure) -> str:
         L.extend(be_compute("A", "e", "rg"))
         A("    idx = nidx; e = e_n; s = s_n; rg = rg_n;")
         A("  }")
+    if probe:
+        A("  if (probe_sink == T(12345.678)) a.gy[0] = probe_sink;")
     A("}")
 
     # ------------------------------------------------------------------ backward (node features)
@@ -596,8 +628,253 @@ def _emit(st: Structure) -> str:
     A("  }")
     A("}")
 
+    # ------------------------------------------------------------------ backward, pair-centric (paired radial weights)
+    # A reverse-edge pair p = {j -> o, o -> j} shares one weight row.  Walking the edges by destination, the two directed
+    # edges of a pair are evaluated by different wavefronts at different times: the weight row is read twice, the two
+    # halves of its gradient are written to separate rows (summed later by the radial backward), and every directed edge
+    # writes a per-edge row of grad_x contributions for its source.  Here every pair has an OWNER node o (half of each
+    # node's pairs, see EdgePairing.owner_csr); the wavefront of o holds x[o], grad_out[o] and the grad_x[o] accumulators
+    # in registers and, per owned pair, gathers x[j] and grad_out[j] and evaluates BOTH directed edges:
+    #   in  = j -> o  (x = x[j], g = grad_out[o]):  grad_w half, grad_y[in],  grad_x[j] contribution -> row of the pair
+    #   out = o -> j  (x = x[o], g = grad_out[j]):  grad_w half, grad_y[out], grad_x[o] contribution -> registers
+    # so the weight row is read once, grad_w leaves already summed ([P, W] instead of [2P, W]) and only one grad_x row per
+    # pair is written: per pair 2 W + dim_in1 floats of HBM traffic instead of 2 (2 W + dim_in1), in exchange for a second
+    # gathered node row (grad_out[j]) that comes out of the cache hierarchy.  Same arithmetic per directed edge as the
+    # fused kernel above (shared intermediate T_ij).
+    # register budget: two grad_out rows, three x rows, the weights.  Measured on cu20k (l_max 3, 269): 298 spilled
+    # registers, fused backward 10 -> 70 ms -- the big structures stay with the per-edge kernels
+    pair_ok = (2 * OD + 3 * XD + NP) <= 110  # (larger structures spill: l2p_second at 144 spills 127 registers)
+    pair_occ = os.environ.get("NQA_GEN_PAIR_OCC", "2")
+    pair_lb = "__launch_bounds__(256)" if big else f"__launch_bounds__(256, {pair_occ})"
+    if pair_ok:
+        A("// GX = false: grad_w (summed over the pair) and grad_y only -- layers whose grad_x is not needed or comes from bwd_x")
+        A("template <typename T, int WPN, bool FULL, bool GX>")
+        A(f"__global__ {pair_lb} void bwd_pair_kernel(const SpecArgs<T> a) {{")
+        A("  const int lane = threadIdx.x & 63;")
+        A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+        A("  const int mul = a.mul;")
+        A("  const int nchunk = (mul + 63) >> 6;")
+        A("  const int64_t witem = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+        A("  const int64_t item = witem / WPN;")
+        A("  const int wsub = (int)(witem - item * WPN);")
+        A("  if (item >= (int64_t)a.N * nchunk) return;  // (WPN == 4: the whole workgroup)")
+        A("  const int node = spec_uniform((int)(item / nchunk));")
+        A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
+        A("  const int u = chunk * 64 + lane;")
+        A("  const bool act = FULL || (u < mul);")
+        A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
+        L.extend(lane_offsets("  ", want_x=True, want_g=True))
+
+        def load_g(indent, rowexpr, name):
+            out = [f"{indent}{{ const T* __restrict__ gb = {rowexpr};"]
+            for s_ in range(NS):
+                d3 = 2 * st.out_ls[s_] + 1
+                for k in range(d3):
+                    if slot_coeff[s_] is None:
+                        out.append(f"{indent}  {name}[{opre[s_] + k}] = T(0);")
+                    else:
+                        out.append(f"{indent}  {name}[{opre[s_] + k}] = spec_at(gb, go{s_})[{k}];")
+            for s_ in range(NS):
+                d3 = 2 * st.out_ls[s_] + 1
+                if slot_coeff[s_] is None:
+                    continue
+                for k in range(d3):
+                    out.append(f"{indent}  {name}[{opre[s_] + k}] = act ? T({slot_coeff[s_]!r}) * {name}[{opre[s_] + k}] : T(0);")
+            out.append(f"{indent}}}")
+            return out
+
+        A("  T gvO[kOD], gxO[kXD];")
+        L.extend(load_g("  ", "a.g + (int64_t)node * a.dout", "gvO"))
+        L.extend(load_x("  ", "(a.x + (int64_t)node * a.din)", sfx="O"))
+        A("#pragma unroll")
+        A("  for (int i = 0; i < kXD; ++i) gxO[i] = T(0);")
+
+        pair_nohoist = os.environ.get("NQA_GEN_PAIR_NOHOIST", "0") != "0"  # measured: more spills, not fewer
+
+        def pair_path(out, pth, xs, gname, ys, tag_):
+            """One path of one directed edge: B{tag}{jj} (-> grad_w, grad_y) and the grad_x terms per input component."""
+            b_, j, s_ = st.instr[pth]
+            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
+            d1, d2, d3 = 2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1
+            C = np.array(wigner_3j(l1, l2, l3), dtype=np.float64)
+            started = [False] * d2
+            gx_terms = []
+            for i in range(d1):
+                a_terms = []
+                for jj in range(d2):
+                    ks = [k for k in range(d3) if C[i, jj, k] != 0.0]
+                    if not ks:
+                        continue
+                    expr = " + ".join(f"T({float(C[i, jj, k])!r}) * {gname}[{opre[s_] + k}]" for k in ks)
+                    out.append(f"        const T t{tag_}{i}_{jj} = {expr};")
+                    if started[jj]:
+                        out.append(f"        B{tag_}{jj} += xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
+                    else:
+                        out.append(f"        T B{tag_}{jj} = xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
+                        started[jj] = True
+                    a_terms.append(f"yb{j}{ys}[{jj}] * t{tag_}{i}_{jj}")
+                gx_terms.append((xpre[b_] + i, " + ".join(a_terms) if a_terms else None))
+            live = [jj for jj in range(d2) if started[jj]]
+            return live, gx_terms
+
+        def pair_loads(sfx, idx, with_g=True):
+            """Operands of the pair in owner slot `idx` into register set `sfx` (the indices are wave-uniform).  The
+            gathered grad_out row goes to the single array gvJ (with_g) or is requested later by pair_load_g."""
+            out = [f"    {{ jn{sfx} = spec_uniform(a.nbr[{idx}]);",
+                   f"      pr{sfx} = spec_uniform(a.wid[{idx}]); ei{sfx} = spec_uniform(a.eid[{idx}]); eo{sfx} = spec_uniform(a.eid2[{idx}]);",
+                   f"      const T* __restrict__ xr = a.x + (int64_t)jn{sfx} * a.din;",
+                   f"      const T* __restrict__ wr = a.w + (int64_t)pr{sfx} * a.wn;",
+                   f"      const T* __restrict__ yi = a.y + (int64_t)ei{sfx} * kS;",
+                   f"      const T* __restrict__ yo = a.y + (int64_t)eo{sfx} * kS;"]
+            out += load_w("      ", "wr", sfx=sfx, decl=False)
+            out += load_x("      ", "xr", sfx="J" + sfx, decl=False)
+            if with_g:
+                out += load_g("      ", f"a.g + (int64_t)jn{sfx} * a.dout", "gvJ")
+            out += load_y("      ", "yi", sfx="I" + sfx, decl=False)
+            out += load_y("      ", "yo", sfx="X" + sfx, decl=False)
+            out.append("    }")
+            return out
+
+        def pair_load_g(sfx):
+            return load_g("    ", f"a.g + (int64_t)jn{sfx} * a.dout", "gvJ")
+
+        def pair_decls(sfx):
+            return ([f"  T wv{sfx}[kNP];", f"  int jn{sfx} = 0, pr{sfx} = 0, ei{sfx} = 0, eo{sfx} = 0;"]
+                    + decl_x("  ", "J" + sfx) + decl_y("  ", "I" + sfx) + decl_y("  ", "X" + sfx))
+
+        def pair_compute(sfx, slot):
+            out = ["    {"]
+            if pair_nohoist:
+                # T_ij = sum_k C_ijk g_k of the owner's grad_out is the same for all its pairs: the compiler hoists those
+                # (hundreds of) products out of the pair loop and keeps them in registers -- 254 registers, nothing left
+                # for a second operand set.  An empty asm that "modifies" the row makes them per-pair values again.
+                out += ["#pragma unroll", "    for (int k = 0; k < kOD; ++k) asm volatile(\"\" : \"+v\"(gvO[k]));"]
+            out += ["    T qI[kS], qX[kS], gxa[kXD];", "#pragma unroll",
+                   "    for (int j = 0; j < kS; ++j) { qI[j] = T(0); qX[j] = T(0); }",
+                   f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;",
+                   f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;"]
+            last_path_of_block = {b_: p_ for p_, (b_, _, _) in enumerate(st.instr)}
+            first_path_of_block = {}
+            for p_, (b_, _, _) in enumerate(st.instr):
+                first_path_of_block.setdefault(b_, p_)
+            for pth, (b_, j, s_) in enumerate(st.instr):
+                d1 = 2 * st.in1_ls[b_] + 1
+                if first_path_of_block[b_] == pth:
+                    for i in range(d1):
+                        out.append(f"      gxa[{xpre[b_] + i}] = T(0);")
+                out.append(f"      {{  // path {pth}")
+                live_i, gx_i = pair_path(out, pth, "J" + sfx, "gvO", "I" + sfx, "i")
+                for comp, expr in gx_i:
+                    if expr:
+                        out.append(f"        if (GX) gxa[{comp}] += wv{sfx}[{pth}] * ({expr});")
+                live_x, gx_x = pair_path(out, pth, "O", "gvJ", "X" + sfx, "x")
+                for comp, expr in gx_x:
+                    if expr:
+                        out.append(f"        if (GX) gxO[{comp}] += wv{sfx}[{pth}] * ({expr});")
+                terms = [f"yb{j}I{sfx}[{jj}] * Bi{jj}" for jj in live_i] + [f"yb{j}X{sfx}[{jj}] * Bx{jj}" for jj in live_x]
+                gw_expr = " + ".join(terms) if terms else "T(0)"
+                out.append(f"        {{ const T r_ = {gw_expr}; if (act) *spec_at(gwr_e + (unsigned)(mul * {pth}), ucb) = r_; }}")
+                for jj in live_i:
+                    out.append(f"        qI[{ypre[j] + jj}] += wv{sfx}[{pth}] * Bi{jj};")
+                for jj in live_x:
+                    out.append(f"        qX[{ypre[j] + jj}] += wv{sfx}[{pth}] * Bx{jj};")
+                out.append("      }")
+                if last_path_of_block[b_] == pth:
+                    out.append("      if (GX && act) {")
+                    for i in range(d1):
+                        out.append(f"        *spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb) = gxa[{xpre[b_] + i}];")
+                    out.append("      }")
+            unused = [i for b in range(NB) if b not in first_path_of_block for i in range(xpre[b], xpre[b] + 2 * st.in1_ls[b] + 1)]
+            if unused:
+                out.append("      if (GX && act) {")
+                for i in unused:
+                    out.append(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
+                out.append("      }")
+            out.append(f"      spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)ei{sfx} * a.gy_stride + chunk * kS, lane);")
+            out.append(f"      spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eo{sfx} * a.gy_stride + chunk * kS, lane);")
+            out.append("    }")
+            return out
+
+        # NQA_GEN_PAIR_PIPE=1: two operand sets for the streamed rows (w, x[other], y); the gathered grad_out[other] row
+        # of the CURRENT pair is requested first (single buffer), then the next pair's rows, then the pair is evaluated
+        pair_pipe = os.environ.get("NQA_GEN_PAIR_PIPE", "0") != "0" and not big
+        A("  int idx = beg + wsub;")
+        A("  T gvJ[kOD];")
+        if pair_pipe:
+            L.extend(pair_decls("A") + pair_decls("B"))
+            A("  if (idx < end) {")
+            L.extend(pair_loads("A", "idx", with_g=False))
+            A("  }")
+            A("  while (idx < end) {")
+            L.extend(pair_load_g("A"))
+            A("    int nidx = idx + WPN;")
+            A("    if (nidx < end) {")
+            L.extend(pair_loads("B", "nidx", with_g=False))
+            A("    }")
+            L.extend(pair_compute("A", "idx"))
+            A("    idx = nidx;")
+            A("    if (idx >= end) break;")
+            L.extend(pair_load_g("B"))
+            A("    nidx = idx + WPN;")
+            A("    if (nidx < end) {")
+            L.extend(pair_loads("A", "nidx", with_g=False))
+            A("    }")
+            L.extend(pair_compute("B", "idx"))
+            A("    idx = nidx;")
+            A("  }")
+        else:
+            # NQA_GEN_PAIR_PREFETCH=1: touch the next pair's weight row (the one stream that comes from HBM) while this pair
+            # is evaluated -- plain loads into a sink value, so that the row is in the L2 when the real loads ask for it
+            pair_prefetch = os.environ.get("NQA_GEN_PAIR_PREFETCH", "1") != "0"  # same-box cfg-3: 2.930 -> 2.912 ms
+            L.extend(pair_decls("A"))
+            if pair_prefetch:
+                A("  T pf_sink = T(0);")
+            A("  for (; idx < end; idx += WPN) {")
+            L.extend(pair_loads("A", "idx"))
+            if pair_prefetch:
+                A("    T pf[kNP];")
+                A("    {")
+                A("      const int nidx_ = idx + WPN < end ? idx + WPN : idx;")
+                A("      const T* __restrict__ wn_ = a.w + (int64_t)spec_uniform(a.wid[nidx_]) * a.wn;")
+                for pth in range(NP):
+                    A(f"      pf[{pth}] = *spec_at(wn_ + (unsigned)(mul * {pth}), ucb);")
+                A("    }")
+            L.extend(pair_compute("A", "idx"))
+            if pair_prefetch:
+                A("#pragma unroll")
+                A("    for (int p_ = 0; p_ < kNP; ++p_) pf_sink += pf[p_];")
+            A("  }")
+            if pair_prefetch:
+                A("  if (pf_sink == T(12345.678)) a.gy[0] = pf_sink;")
+        A("  // grad_x[owner]: the owner-side contributions of all its pairs (the other side arrives through the rows)")
+        A("  if (!GX) return;")
+        A("  if (WPN > 1) {")
+        A("    extern __shared__ __align__(16) unsigned char nqa_smem[];")
+        A("    T* red = reinterpret_cast<T*>(nqa_smem);")
+        A("    if (wsub > 0) {")
+        A("#pragma unroll")
+        A("      for (int k = 0; k < kXD; ++k) red[((wsub - 1) * kXD + k) * 64 + lane] = gxO[k];")
+        A("    }")
+        A("    __syncthreads();")
+        A("    if (wsub > 0) return;")
+        A("#pragma unroll")
+        A("    for (int k = 0; k < kXD; ++k) {")
+        A("#pragma unroll")
+        A("      for (int w2 = 0; w2 < WPN - 1; ++w2) gxO[k] += red[(w2 * kXD + k) * 64 + lane];")
+        A("    }")
+        A("  }")
+        A("  if (act) {")
+        A("    T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+        for b in range(NB):
+            d = 2 * st.in1_ls[b] + 1
+            for i in range(d):
+                A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = gxO[{xpre[b] + i}];")
+        A("  }")
+        A("}")
+
     # ------------------------------------------------------------------ per-source-node sum of the fused rows
-    A("template <typename T>")
+    A("// ACC: add the rows to what a.out already holds (pair-centric backward: the owner-side sums) instead of overwriting")
+    A("template <typename T, bool ACC>")
     A("__global__ __launch_bounds__(256) void gx_rows_sum_kernel(const SpecArgs<T> a) {")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -638,7 +915,7 @@ def _emit(st: Structure) -> str:
     for b in range(NB):
         d = 2 * st.in1_ls[b] + 1
         for i in range(d):
-            A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = acc[{xpre[b] + i}];")
+            A(f"    {{ T* o_ = ob + ((int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}); *o_ = ACC ? *o_ + acc[{xpre[b] + i}] : acc[{xpre[b] + i}]; }}")
     A("  }")
     A("}")
 
@@ -647,24 +924,46 @@ def _emit(st: Structure) -> str:
     A("static int launch(int which, const SpecArgs<float>& a, hipStream_t stream) {")
     A("  const int nchunk = (a.mul + 63) / 64;")
     A("  const int64_t items = (int64_t)a.N * nchunk;")
+    A("  const bool full = (a.mul & 63) == 0;")
     A("  if (items == 0) return 0;")
     A("  if (which == 1) {")
     A("    const int64_t blocks = (items * WPN + 3) / 4;")
     A("    const dim3 grid((unsigned)blocks), blk(256);")
     A("    if (a.gxe != nullptr) {")
     A("      if (a.gw == nullptr || a.gy == nullptr) return 1;")
-    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, true, true, true>), grid, blk, 0, stream, a);")
+    A("      if (full) hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, true, true, true, true>), grid, blk, 0, stream, a); else hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, true, true, true, false>), grid, blk, 0, stream, a);")
     A("    } else if (a.gw != nullptr && a.gy != nullptr) {")
-    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, true>), grid, blk, 0, stream, a);")
+    A("      if (full) hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, true, true>), grid, blk, 0, stream, a); else hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, true, false>), grid, blk, 0, stream, a);")
     A("    } else if (a.gw != nullptr) {")
-    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, false>), grid, blk, 0, stream, a);")
+    A("      if (full) hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, false, true>), grid, blk, 0, stream, a); else hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, true, false, false>), grid, blk, 0, stream, a);")
     A("    } else if (a.gy != nullptr) {")
-    A("      hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, false, true>), grid, blk, 0, stream, a);")
+    A("      if (full) hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, false, true, true>), grid, blk, 0, stream, a); else hipLaunchKernelGGL((bwd_edge_kernel<float, WPN, false, false, true, false>), grid, blk, 0, stream, a);")
     A("    }")
     A("    return 0;")
     A("  }")
     A("  if (which == 3) {")
-    A("    hipLaunchKernelGGL((gx_rows_sum_kernel<float>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);")
+    A("    hipLaunchKernelGGL((gx_rows_sum_kernel<float, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);")
+    A("    return 0;")
+    A("  }")
+    A("  if (which == 4) {  // pair-centric backward (owner CSR in rowptr / nbr / wid / eid / eid2)")
+    if pair_ok:
+        A("    if (a.gw == nullptr || a.gy == nullptr || a.eid2 == nullptr || (a.out != nullptr && a.gxe == nullptr)) return 1;")
+        A("    const int64_t blocks = (items * WPN + 3) / 4;")
+        A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kXD * 64 * sizeof(float) : 0;")
+        A("    const dim3 grid((unsigned)blocks), blk(256);")
+        A("    if (a.out != nullptr) {")
+        A("      if (full) hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, true, true>), grid, blk, smem, stream, a);")
+        A("      else hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, false, true>), grid, blk, smem, stream, a);")
+        A("    } else {")
+        A("      if (full) hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, true, false>), grid, blk, 0, stream, a);")
+        A("      else hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, false, false>), grid, blk, 0, stream, a);")
+        A("    }")
+        A("    return 0;")
+    else:
+        A("    return 1;  // not generated for this structure (register budget)")
+    A("  }")
+    A("  if (which == 5) {  // grad_x += rows of the pairs in which the node is not the owner")
+    A("    hipLaunchKernelGGL((gx_rows_sum_kernel<float, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);")
     A("    return 0;")
     A("  }")
     A("  const int64_t blocks = WPN == 1 ? (items + 3) / 4 : items;")
@@ -682,7 +981,7 @@ def _emit(st: Structure) -> str:
     A("  if (wpn >= 4 && kOD <= 64) return launch<4>(which, a, stream);")
     A("  return launch<1>(which, a, stream);")
     A("}")
-    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP);')
+    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {1 if pair_ok else 0});')
     A("}  // namespace")
     A("}  // namespace nqa")
     return "\n".join(L) + "\n"

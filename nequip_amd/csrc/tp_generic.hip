@@ -782,4 +782,86 @@ int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, in
   return nqa_tp_scatter_bwd_x_impl(plan, plan_image, dtype, y, w, grad_out, rowptr_src, edge_id_src, dst_sorted, grad_x, num_nodes, num_edges, stream, weight_rows, num_pairs);
 }
 
+int64_t nqa_tp_bwd_pairs_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges) {
+  if (plan == nullptr || num_edges < 0 || (num_edges & 1) || !use_spec(plan, dtype) || !plan->spec->pair) return -1;
+  const int nchunk = (plan->uniform_mul + 63) / 64;
+  const int64_t ypart = nchunk > 1 ? num_edges * (int64_t)plan->dim_in2 * nchunk * 4 : 0;
+  return ((ypart + 255) & ~(int64_t)255) + (num_edges / 2) * (int64_t)plan->dim_in1 * 4;
+}
+
+int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                             const void* w, const void* grad_out, const int32_t* owner_rowptr,
+                             const int32_t* pair_other, const int32_t* pair_row, const int32_t* pair_edge_in,
+                             const int32_t* pair_edge_out, const int32_t* other_rowptr, const int32_t* other_slot,
+                             void* grad_w, void* grad_y, void* grad_x, void* workspace, int64_t workspace_bytes,
+                             int64_t num_nodes, int64_t num_edges, nqa_stream stream) {
+  int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_pairs");
+  if (rc != NQA_OK) return rc;
+  const int64_t need = nqa_tp_bwd_pairs_workspace_bytes(plan, dtype, num_edges);
+  if (need < 0) {
+    set_error("nqa_tp_scatter_bwd_pairs: no pair-centric float32 kernel for this plan (or an odd edge count)");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if ((num_nodes > 0 && (!owner_rowptr || (grad_x && !other_rowptr))) ||
+      (num_edges > 0 && (!x || !y || !w || !grad_out || !pair_other || !pair_row || !pair_edge_in || !pair_edge_out ||
+                         (grad_x && !other_slot) || !grad_w || !grad_y))) {
+    set_error("nqa_tp_scatter_bwd_pairs: NULL operand");
+    return NQA_ERR_INVALID;
+  }
+  if (num_edges > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("nqa_tp_scatter_bwd_pairs: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  if (num_nodes == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SpecArgs<float> a{};
+  spec_fill(a, plan, num_nodes);
+  const int nchunk = (plan->uniform_mul + 63) / 64;
+  const int64_t ypart = nchunk > 1 ? num_edges * (int64_t)plan->dim_in2 * nchunk * 4 : 0;
+  float* gxe = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((ypart + 255) & ~(int64_t)255));
+  a.x = static_cast<const float*>(x);
+  a.y = static_cast<const float*>(y);
+  a.w = static_cast<const float*>(w);
+  a.g = static_cast<const float*>(grad_out);
+  a.gw = static_cast<float*>(grad_w);
+  a.gxe = grad_x ? gxe : nullptr;
+  a.out = static_cast<float*>(grad_x);  // NULL: grad_w and grad_y only
+  a.rowptr = owner_rowptr;
+  a.nbr = pair_other;
+  a.wid = pair_row;
+  a.eid = pair_edge_in;
+  a.eid2 = pair_edge_out;
+  a.wP = 2147483647;
+  if (nchunk == 1) {
+    a.gy = static_cast<float*>(grad_y);
+    a.gy_stride = plan->dim_in2;
+  } else {
+    a.gy = static_cast<float*>(workspace);
+    a.gy_stride = plan->dim_in2 * nchunk;
+  }
+  if (plan->spec->launch(4, spec_wpn(plan, num_nodes), a, s) != 0) {
+    set_error("nqa_tp_scatter_bwd_pairs: kernel not available");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  rc = check_launch("nqa_tp_scatter_bwd_pairs(pairs)");
+  if (rc != NQA_OK) return rc;
+  if (nchunk > 1 && num_edges > 0) {
+    const int64_t total = num_edges * (int64_t)plan->dim_in2;
+    hipLaunchKernelGGL(spec_gy_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), static_cast<float*>(grad_y), plan->dim_in2, nchunk, total);
+    rc = check_launch("nqa_tp_scatter_bwd_pairs(reduce)");
+    if (rc != NQA_OK) return rc;
+  }
+  if (grad_x == nullptr) return NQA_OK;
+  SpecArgs<float> b{};
+  spec_fill(b, plan, num_nodes);
+  b.gxe = gxe;
+  b.out = static_cast<float*>(grad_x);
+  b.rowptr = other_rowptr;
+  b.eid = other_slot;
+  plan->spec->launch(5, 1, b, s);
+  return check_launch("nqa_tp_scatter_bwd_pairs(sum)");
+}
+
 }  // extern "C"
+

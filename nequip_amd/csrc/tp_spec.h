@@ -21,6 +21,7 @@ struct SpecArgs {
   const int32_t* __restrict__ rowptr;
   const int32_t* __restrict__ eid;
   const int32_t* __restrict__ nbr;
+  const int32_t* __restrict__ eid2;  // pair-centric backward: the pair's second directed edge (owner -> other)
   // Weight rows (paired radial weights, nqa_tp_scatter_*_paired): wid[slot] in CSR slot order is the row of grad_w the
   // edge writes, row (wid < wP ? wid : wid - wP) of w holds its weights.  Unpaired calls pass wid = eid, wP = INT32_MAX.
   const int32_t* __restrict__ wid;
@@ -31,13 +32,15 @@ struct SpecArgs {
   int32_t gy_stride;
 };
 
-// which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows;  wpn: requested wavefronts per (node, chunk)
+// which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows,
+// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows;  wpn: requested wavefronts per (node, chunk)
 using SpecLaunchFn = int (*)(int which, int wpn, const SpecArgs<float>& a, hipStream_t stream);
 
 struct SpecEntry {
   std::string key;
   SpecLaunchFn launch;
   int xd, s, od, np;
+  int pair;  // pair-centric backward (which = 4 / 5) generated for this structure
   SpecEntry* next;
 };
 
@@ -46,13 +49,14 @@ const SpecEntry* find_spec(const std::string& key);
 
 struct SpecRegistrar {
   SpecEntry entry;
-  SpecRegistrar(const char* key, SpecLaunchFn fn, int xd, int s, int od, int np) {
+  SpecRegistrar(const char* key, SpecLaunchFn fn, int xd, int s, int od, int np, int pair) {
     entry.key = key;
     entry.launch = fn;
     entry.xd = xd;
     entry.s = s;
     entry.od = od;
     entry.np = np;
+    entry.pair = pair;
     entry.next = spec_registry_head();
     spec_registry_head() = &entry;
   }

@@ -58,6 +58,19 @@ class RadialBackwardQueue:
         return os.environ.get("NQA_NO_OVERLAP", "") in ("", "0")
 
 
+def _pair_backward_pays(g: torch.Tensor) -> bool:
+    """The pair-centric backward halves the streamed bytes (weights, their gradient, the grad_x rows) and pays with a
+    second gathered node row per pair -- grad_out[other], ``dim_out`` floats -- that has to come out of the cache
+    hierarchy.  Measured a win both with ``grad_out`` resident in the 256 MB infinity cache (cfg-3, 90 MB: fused backward
+    + radial backward 1.36 -> 1.10 ms) and far beyond it (81 000-atom water box, 725 MB: 9.9 -> 8.5 ms; the neighbours of
+    spatially ordered atoms are re-used out of the L2), so there is no size limit by default.  ``NQA_PAIR_BWD_MAX_MB``
+    sets one, ``NQA_NO_PAIR_BWD=1`` switches the kernel off."""
+    if os.environ.get("NQA_NO_PAIR_BWD", "") not in ("", "0"):
+        return False
+    limit_mb = os.environ.get("NQA_PAIR_BWD_MAX_MB", "")
+    return limit_mb == "" or g.numel() * g.element_size() <= float(limit_mb) * (1 << 20)
+
+
 class _PairedRadialTPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb_half, x, y, w0, w1, alpha0: float, alpha1: float, mode: int, cache, k: _Kernels,
@@ -82,14 +95,24 @@ class _PairedRadialTPFn(torch.autograd.Function):
         P = pairing.num_pairs
         gx = gy = G = None
         fused = None
+        folded = False  # G = [P, W] already summed over the two directed edges of every pair (else the two halves [2P, W])
         if need_emb and need_x and need_y and k.prefer_fused_bwd and os.environ.get("NQA_NO_FUSED_BWD", "") in ("", "0"):
-            fused = k.bwd_fused(x, y, w_half, g, topo, pairing=pairing)
+            if _pair_backward_pays(g):
+                fused = k.bwd_pairs(x, y, w_half, g, topo, pairing)
+                folded = fused is not None
+            if fused is None:
+                fused = k.bwd_fused(x, y, w_half, g, topo, pairing=pairing)
         if fused is not None:
             gx, G, gy = fused
         else:
             if need_x:
                 gx = k.bwd_x(y, w_half, g, topo, pairing)
-            G, gy = k.bwd_edge(x, y, w_half, g, topo, need_gw=need_emb, need_gy=need_y, pairing=pairing)
+            pairs = k.bwd_pairs(x, y, w_half, g, topo, pairing, need_gx=False) if (need_emb and need_y and _pair_backward_pays(g)) else None
+            if pairs is not None:
+                _, G, gy = pairs
+                folded = True
+            else:
+                G, gy = k.bwd_edge(x, y, w_half, g, topo, need_gw=need_emb, need_gy=need_y, pairing=pairing)
         g_emb = None
         q = ctx.queue
         if q is not None:
@@ -98,13 +121,18 @@ class _PairedRadialTPFn(torch.autograd.Function):
             cur = torch.cuda.current_stream(g.device)
             q.stream.wait_stream(cur)  # grad_w is complete
             with torch.cuda.stream(q.stream):
-                part = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
+                if folded:
+                    part = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache)
+                else:
+                    part = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
                 q.acc = part if q.acc is None else q.acc.add_(part)
             G.record_stream(q.stream)
             if q.layers <= 0:  # first layer of the model = last backward of the evaluation: join
                 cur.wait_stream(q.stream)
                 g_emb, q.acc = q.acc, None
                 g_emb.record_stream(cur)
+        elif need_emb and folded:
+            g_emb = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache)
         elif need_emb:
             g_emb = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
         return (g_emb, gx, gy) + (None,) * 10

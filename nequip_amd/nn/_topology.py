@@ -136,6 +136,7 @@ class EdgePairing:
         self._topo = weakref.ref(topo)
         self._slots_dst: Optional[torch.Tensor] = None
         self._slots_src: Optional[torch.Tensor] = None
+        self._owner_csr = None
 
     @property
     def slots_dst(self) -> torch.Tensor:
@@ -150,6 +151,35 @@ class EdgePairing:
             eid = self._topo().by_src[1][: self.rows.numel()]
             self._slots_src = self.rows.index_select(0, eid.to(torch.int64)).contiguous()
         return self._slots_src
+
+
+    @property
+    def owner_csr(self):
+        """Pair lists of the pair-centric backward (``nqa_tp_scatter_bwd_pairs``): every pair gets an owner node --
+        ``(i < j) xor (i + j odd)`` picks i, which hands every node about half of its pairs -- and the pairs are grouped by
+        owner (within an owner by the other node, for the locality of the gathered rows) and, separately, by the other node.
+        Returns int32 device tensors ``(owner_rowptr, pair_other, pair_row, edge_in, edge_out, other_rowptr, other_slot)``.
+        Built once per neighbour list with a handful of ATen sorts (no synchronisation)."""
+        if self._owner_csr is None:
+            topo = self._topo()
+            P, N = self.num_pairs, topo.num_nodes
+            dev = self.rows.device
+            order = torch.argsort(self.rows.to(torch.int64))  # rows are a permutation of 0 .. 2P-1
+            ea, eb = order[:P], order[P:]  # representative edge and its reverse, in pair order
+            i, j = topo._dst.index_select(0, ea), topo._src.index_select(0, ea)
+            own_i = (i == j) | ((i < j) ^ (((i + j) & 1) == 1))
+            owner, other = torch.where(own_i, i, j), torch.where(own_i, j, i)
+            e_in, e_out = torch.where(own_i, ea, eb), torch.where(own_i, eb, ea)  # dst = owner / dst = other
+            perm = torch.argsort(owner * N + other)
+            owner_s, other_s = owner.index_select(0, perm), other.index_select(0, perm)
+            nodes = torch.arange(N + 1, dtype=torch.int64, device=dev)
+            owner_rowptr = torch.searchsorted(owner_s, nodes).to(torch.int32)
+            perm2 = torch.argsort(other_s, stable=True)
+            other_rowptr = torch.searchsorted(other_s.index_select(0, perm2), nodes).to(torch.int32)
+            i32 = lambda t: t.to(torch.int32).contiguous()  # noqa: E731
+            self._owner_csr = (owner_rowptr.contiguous(), i32(other_s), i32(perm), i32(e_in.index_select(0, perm)),
+                               i32(e_out.index_select(0, perm)), other_rowptr.contiguous(), i32(perm2))
+        return self._owner_csr
 
 
 class _TopologyCache:

@@ -181,6 +181,40 @@ class _Kernels:
         _lib.check(rc, "nqa_tp_scatter_bwd_fused")
         return gx, gw, gy
 
+    def has_pairs_kernel(self, dtype: torch.dtype) -> bool:
+        cache = self.__dict__.setdefault("_has_pairs", {})
+        if dtype not in cache:
+            cache[dtype] = _lib.load().nqa_tp_bwd_pairs_workspace_bytes(self.plan.handle, _nqa_dtype(dtype), 0) >= 0
+        return cache[dtype]
+
+    def bwd_pairs(self, x, y, w, g, topo: EdgeTopology, pairing, need_gx: bool = True):
+        """(gx, gw, gy) with ``gw = [num_pairs, weight_numel]`` already summed over the two directed edges of every pair
+        (``nqa_tp_scatter_bwd_pairs``), or None when the plan has no pair-centric kernel.  ``need_gx=False``: gx is None
+        (the edge gradients only)."""
+        lib = _lib.load()
+        E, N = topo.num_edges, topo.num_nodes
+        ws_bytes = lib.nqa_tp_bwd_pairs_workspace_bytes(self.plan.handle, _nqa_dtype(x.dtype), E)
+        if ws_bytes < 0:
+            return None
+        self._check(x, y, w, topo, pairing)
+        P = pairing.num_pairs
+        gx = torch.empty((N, self.dim_in1), dtype=x.dtype, device=x.device) if need_gx else None
+        gw = torch.empty((P, self.weight_numel), dtype=x.dtype, device=x.device)
+        gy = torch.empty((E, self.dim_in2), dtype=x.dtype, device=x.device)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        orow, oth, prow, ein, eout, trow, tslot = pairing.owner_csr
+        es = x.element_size()
+        # algorithmic bytes as for bwd_fused (w and gw counted per pair: that is what this formulation moves)
+        nbytes = E * (es * self.dim_in2 * 2 + 24) + P * es * 2 * self.weight_numel + N * es * (2 * self.dim_in1 + self.dim_out)
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused" if need_gx else "tp_bwd_edge", nbytes):
+            rc = lib.nqa_tp_scatter_bwd_pairs(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
+                _ptr(orow), _ptr(oth), _ptr(prow), _ptr(ein), _ptr(eout), _ptr(trow), _ptr(tslot),
+                _ptr(gw), _ptr(gy), _ptr(gx), _ptr(ws), ws_bytes, N, E, current_stream_ptr(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_bwd_pairs")
+        return gx, gw, gy
+
     def bwd_x(self, y, w, g, topo: EdgeTopology, pairing=None) -> torch.Tensor:
         self._check(None, y, w, topo, pairing)
         lib = _lib.load()

@@ -142,6 +142,17 @@ def test_spec_kernels_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul):
         _close(rgx, fx, f"bwd_fused gx {tag}")
         _close(rgw, fw, f"bwd_fused gw {tag}")
         _close(rgy, fy, f"bwd_fused gy {tag}")
+        if symmetric and k.has_pairs_kernel(torch.float32):
+            # pair-centric backward: grad_w comes out summed over the two directed edges of every pair
+            px, pw, py = k.bwd_pairs(xd, yd, wd, god, topo, pr)
+            rgw_pairs = torch.zeros(P, k.weight_numel).index_add_(0, rows % P, rgw)
+            _close(rgx, px, f"bwd_pairs gx {tag}")
+            _close(rgw_pairs, pw, f"bwd_pairs gw {tag}")
+            _close(rgy, py, f"bwd_pairs gy {tag}")
+            none_x, pw2, py2 = k.bwd_pairs(xd, yd, wd, god, topo, pr, need_gx=False)  # the edge gradients only
+            assert none_x is None
+            _close(rgw_pairs, pw2, f"bwd_pairs<no gx> gw {tag}")
+            _close(rgy, py2, f"bwd_pairs<no gx> gy {tag}")
 
 
 @pytest.mark.gpu
@@ -175,3 +186,57 @@ def test_spec_kernels_large_degree_and_wave_split(device, mul):
     _close(rgx, fx, "fused gx")
     _close(rgw, fw, "fused gw")
     _close(rgy, fy, "fused gy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("system", ["si_small_cell", "water", "cu_l3"])
+def test_pair_backward_equals_per_edge_backward(device, system):
+    """`nqa_tp_scatter_bwd_pairs` against `nqa_tp_scatter_bwd_fused_paired` on real neighbour lists: a cell thinner than
+    2 r_max (several images of one (i, j), self images: owner == other), a water box large enough for one wavefront per
+    node and for four, and the l_max = 3 / 128-feature structure (two channel chunks, grad_y through the partial buffer)."""
+    from nequip_amd.nn._topology import EdgeTopology
+    from nequip_amd.utils import synthetic as syn
+
+    if system == "si_small_cell":
+        pos, types, cell, names = syn.silicon_box(reps=1, seed=2)
+        sname, mul = "l2n_mid", 64
+    elif system == "water":
+        pos, types, cell, names = syn.water_box(n_side=4, seed=1)
+        sname, mul = "l2n_mid", 64
+    else:
+        pos, types, cell, names = syn.copper_box(reps=(3, 3, 3), seed=3)
+        sname, mul = "l3n_mid", 128
+    data = syn.make_data(pos, types, 4.5, cell)
+    name, f_in_1x, lmax, f_out_1x = next(s for s in STRUCTS if s[0] == sname)
+    tps, f_in, e_at, mid_s, instructions = _module(f_in_1x, lmax, f_out_1x, mul, device)
+    k = tps._get_kernels()
+    if not k.has_pairs_kernel(torch.float32):
+        pytest.skip("no pair-centric kernel generated for this structure")
+    ei = data["edge_index"].to(device)
+    N, E = data["pos"].shape[0], ei.shape[1]
+    topo = EdgeTopology(ei[0].contiguous(), ei[1].contiguous(), N)
+    pr = topo.pairing(data["edge_cell_shift"].to(device))
+    assert pr is not None
+    P = pr.num_pairs
+    # the owner lists: a partition of the pairs, edge_in / edge_out are the two directed edges of the pair
+    orow, oth, prow, ein, eout, trow, tslot = (t.cpu().long() for t in pr.owner_csr)
+    assert sorted(prow.tolist()) == list(range(P)) and sorted(tslot.tolist()) == list(range(P))
+    dst, src, rows = ei[0].cpu(), ei[1].cpu(), pr.rows.cpu().long()
+    owner = torch.repeat_interleave(torch.arange(N), orow[1:] - orow[:-1])
+    assert torch.equal(dst[ein], owner) and torch.equal(src[ein], oth)
+    assert torch.equal(dst[eout], oth) and torch.equal(src[eout], owner)
+    assert torch.equal(rows[ein] % P, prow) and torch.equal(rows[eout] % P, prow)
+    assert torch.equal(oth[tslot], torch.repeat_interleave(torch.arange(N), trow[1:] - trow[:-1]))
+    per_owner = (orow[1:] - orow[:-1]).float()
+    per_node = torch.bincount(dst, minlength=N).float()
+    assert float((per_owner - per_node / 2).abs().max()) <= 0.25 * float(per_node.max()) + 2  # balanced halves
+
+    g = torch.Generator().manual_seed(11)
+    d = lambda t: t.to(device)  # noqa: E731
+    x, y = d(torch.randn(N, k.dim_in1, generator=g)), d(torch.randn(E, k.dim_in2, generator=g))
+    w, go = d(torch.randn(P, k.weight_numel, generator=g) / 4), d(torch.randn(N, k.dim_out, generator=g))
+    fx, fw, fy = k.bwd_fused(x, y, w, go, topo, pairing=pr)
+    px, pw, py = k.bwd_pairs(x, y, w, go, topo, pr)
+    _close(fx.cpu(), px, "gx")
+    _close((fw[:P] + fw[P:]).cpu(), pw, "gw (summed over the pair)")
+    _close(fy.cpu(), py, "gy")
