@@ -215,6 +215,20 @@ class _Kernels:
         _lib.check(rc, "nqa_tp_scatter_bwd_pairs")
         return gx, gw, gy
 
+    def use_pairs(self, dtype: torch.dtype, pairing) -> bool:
+        """Pair-centric backward applicable (paired weights, kernel generated for this structure, not switched off)?"""
+        return (pairing is not None and os.environ.get("NQA_NO_PAIR_BWD", "") in ("", "0")
+                and self.has_pairs_kernel(dtype))
+
+    def edge_grads_folded(self, x, y, w, g, topo: EdgeTopology, pairing, need_gw: bool, need_gy: bool):
+        """(gw, gy) of the edge operands with ``gw`` per weight ROW (per pair when ``pairing`` is given, summed over its
+        two directed edges): the pair-centric kernel when it applies, else ``bwd_edge`` + the fold of the two halves."""
+        if need_gw and self.use_pairs(x.dtype, pairing):
+            _, gw, gy = self.bwd_pairs(x, y, w, g, topo, pairing, need_gx=False)
+            return gw, (gy if need_gy else None)
+        gw, gy = self.bwd_edge(x, y, w, g, topo, need_gw=need_gw, need_gy=need_gy, pairing=pairing)
+        return _fold(gw, pairing), gy
+
     def bwd_x(self, y, w, g, topo: EdgeTopology, pairing=None) -> torch.Tensor:
         self._check(None, y, w, topo, pairing)
         lib = _lib.load()
@@ -275,14 +289,20 @@ class _TPScatterBwdFn(torch.autograd.Function):
     def forward(ctx, g, x, y, w, k: _Kernels, topo: EdgeTopology, need: Tuple[bool, bool, bool], pairing=None):
         g = g.contiguous()
         fused = None
+        folded = False
         if need[0] and need[1] and need[2] and k.prefer_fused_bwd and os.environ.get("NQA_NO_FUSED_BWD", "") in ("", "0"):
-            fused = k.bwd_fused(x, y, w, g, topo, need_gw=need[2], need_gy=need[1], pairing=pairing)
+            if k.use_pairs(x.dtype, pairing):
+                fused = k.bwd_pairs(x, y, w, g, topo, pairing)
+                folded = fused is not None
+            if fused is None:
+                fused = k.bwd_fused(x, y, w, g, topo, need_gw=need[2], need_gy=need[1], pairing=pairing)
         if fused is not None:
             gx, gw, gy = fused
+            if not folded:
+                gw = _fold(gw, pairing)
         else:
             gx = k.bwd_x(y, w, g, topo, pairing) if need[0] else None
-            gw, gy = k.bwd_edge(x, y, w, g, topo, need_gw=need[2], need_gy=need[1], pairing=pairing)
-        gw = _fold(gw, pairing)
+            gw, gy = k.edge_grads_folded(x, y, w, g, topo, pairing, need_gw=need[2], need_gy=need[1])
         ctx.save_for_backward(g, x, y, w)
         ctx.k, ctx.topo, ctx.pairing = k, topo, pairing
         ctx.mark_non_differentiable(*[t for t, n in zip((gx, gy, gw), need) if not n and t is not None])
@@ -314,7 +334,12 @@ class _TPScatterBwdFn(torch.autograd.Function):
                 gxx = add(gxx, k.bwd_x(c_y, w, g, topo, pr))
             if c_w is not None:
                 gxx = add(gxx, k.bwd_x(y, c_w, g, topo, pr))
-        if pr is not None and need_w and c_x is not None and c_y is not None:
+        if need_w and c_x is not None and c_y is not None and k.use_pairs(x.dtype, pr):
+            # pair-centric kernels: both contributions arrive summed over the directed edges of every pair
+            a_w1, a_y = k.edge_grads_folded(c_x, y, w, g, topo, pr, need_gw=True, need_gy=need_y)
+            a_w2, _ = k.edge_grads_folded(x, c_y, w, g, topo, pr, need_gw=True, need_gy=False)
+            gww, gyy = a_w1 + a_w2, add(gyy, a_y)
+        elif pr is not None and need_w and c_x is not None and c_y is not None:
             # paired weights, both contributions: the four half-row streams (two directed edges x two kernels) land in
             # one buffer and are summed in a single pass (5 array passes instead of 9 for fold, fold, add)
             P = pr.num_pairs
@@ -325,11 +350,11 @@ class _TPScatterBwdFn(torch.autograd.Function):
         else:
             if c_x is not None and (need_y or need_w):
                 # one pass yields both Bw(c_x, y, g) and By(c_x, g, w)
-                a_w, a_y = k.bwd_edge(c_x, y, w, g, topo, need_gw=need_w, need_gy=need_y, pairing=pr)
-                gww, gyy = add(gww, _fold(a_w, pr)), add(gyy, a_y)
+                a_w, a_y = k.edge_grads_folded(c_x, y, w, g, topo, pr, need_gw=need_w, need_gy=need_y)
+                gww, gyy = add(gww, a_w), add(gyy, a_y)
             if c_y is not None and need_w:
-                a_w, _ = k.bwd_edge(x, c_y, w, g, topo, need_gw=True, need_gy=False, pairing=pr)
-                gww = add(gww, _fold(a_w, pr))
+                a_w, _ = k.edge_grads_folded(x, c_y, w, g, topo, pr, need_gw=True, need_gy=False)
+                gww = add(gww, a_w)
         if c_w is not None and need_y:
             _, a_y = k.bwd_edge(x, y, c_w, g, topo, need_gw=False, need_gy=True, pairing=pr)
             gyy = add(gyy, a_y)
