@@ -95,6 +95,10 @@ def baseline_irreps() -> List[Tuple[str, str, int, str]]:
             else:
                 out.append((f"{tag}_mid", hidden, lmax, hidden))
                 out.append((f"{tag}_last", hidden, lmax, "1x0e"))
+    # experiments: NQA_GEN_EXTRA="name:irreps_in:lmax:irreps_out;..." adds structures (scripts/r2_split_probe.py)
+    for rec in filter(None, os.environ.get("NQA_GEN_EXTRA", "").split(";")):
+        name, f_in, lmax, f_out = rec.split(":")
+        out.append((name, f_in, int(lmax), f_out))
     return out
 
 
