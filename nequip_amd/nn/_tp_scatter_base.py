@@ -204,8 +204,13 @@ class _Kernels:
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
         orow, oth, prow, ein, eout, trow, tslot = pairing.owner_csr
         es = x.element_size()
-        # algorithmic bytes as for bwd_fused (w and gw counted per pair: that is what this formulation moves)
-        nbytes = E * (es * self.dim_in2 * 2 + 24) + P * es * 2 * self.weight_numel + N * es * (2 * self.dim_in1 + self.dim_out)
+        # algorithmic bytes: SURVEY.md 8(d)'s boundary figure of the backward, per DIRECTED edge as the reference's
+        # interface defines it (the same formulas as bwd_fused / bwd_edge) -- this kernel moves less than that because it
+        # reads the shared weight row and writes its gradient once per pair
+        if need_gx:
+            nbytes = E * (es * (2 * self.weight_numel + 2 * self.dim_in2) + 24) + N * es * (2 * self.dim_in1 + self.dim_out)
+        else:
+            nbytes = E * (es * (2 * self.weight_numel + 2 * self.dim_in2) + 16) + N * es * (self.dim_in1 + self.dim_out)
         with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused" if need_gx else "tp_bwd_edge", nbytes):
             rc = lib.nqa_tp_scatter_bwd_pairs(
                 self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),

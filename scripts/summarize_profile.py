@@ -19,10 +19,12 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 # bench.py region name -> substrings identifying the GPU kernels launched inside that region
 REGIONS = {  # region: (regexes of the main kernel family, regexes of helper kernels that run once per launch)
     "tp_fwd": ([r"::fwd_kernel<", r"tp_fwd_kernel"], []),
-    "tp_bwd_edge": ([r"::bwd_edge_kernel<float, \d, false", r"tp_bwd_edge_kernel"],
+    "tp_bwd_edge": ([r"::bwd_edge_kernel<float, \d, false", r"tp_bwd_edge_kernel",
+                     r"::bwd_pair_kernel<float, \d, (true|false), false>"],
                     [r"spec_gy_reduce_kernel", r"tp_ypart_reduce_kernel"]),
     "tp_bwd_x": ([r"::bwd_x_kernel<", r"tp_bwd_x_kernel"], []),
-    "tp_bwd_fused": ([r"::bwd_edge_kernel<float, \d, true"], [r"gx_rows_sum_kernel"]),
+    "tp_bwd_fused": ([r"::bwd_edge_kernel<float, \d, true", r"::bwd_pair_kernel<float, \d, (true|false), true>"],
+                     [r"gx_rows_sum_kernel"]),
     "radial_mlp_fwd": ([r"radial_mlp_fwd(_bf16x6)?(_bal)?_kernel"], [r"radial_mlp_split_w1_fwd_kernel"]),
     "radial_mlp_bwd": ([r"radial_mlp_bwd(_bf16x6)?_kernel"],
                        [r"radial_mlp_transpose_w1_kernel", r"radial_mlp_split_w1_bwd_kernel"]),
