@@ -182,6 +182,12 @@ int nqa_edge_vectors_bwd(const double* g_edge_vec, const double* edge_cell_shift
  *   stress may be NULL (no cell); batch [N] int64 is required iff num_frames > 1). */
 int nqa_virial_finalize(const double* per_atom, const int64_t* batch, const double* cell, int64_t num_nodes,
                         int64_t num_frames, double* virial, double* stress, nqa_stream stream);
+/* nqa_frame_sum: out[f, :] = sum_{n: batch[n] = f} rows[n, :]  (float64, width <= 16, every frame written; batch may be
+ * NULL for a single frame).  The per-frame reductions of the training path -- autograd's backward of
+ * `symmetric_displacement[batch]` and the d/dcell sum of with_edge_vectors_ (nequip/nn/grad_output.py:230-247,
+ * nequip/nn/utils.py:88-114), which ATen evaluates as float64 atomics -- as one ordered tree reduction per frame. */
+int nqa_frame_sum(const double* rows, const int64_t* batch, int64_t num_nodes, int32_t width, int64_t num_frames,
+                  double* out, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge embedding: real spherical harmonics + Bessel radial basis with polynomial cutoff.

@@ -98,6 +98,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         + [c_int64, c_int64, c_void_p],
     ),
+    "nqa_frame_sum": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p]),
     "nqa_edge_pairs_workspace_bytes": (c_int64, [c_int64]),
     "nqa_edge_pairs": (
         c_int32,

@@ -140,6 +140,36 @@ __global__ __launch_bounds__(256) void virial_finalize_kernel(const double* __re
   }
 }
 
+// out[f, :] = sum over the atoms n of frame f of rows[n, :] (K <= 16 columns): one workgroup per frame, ordered tree
+// reduction -- the deterministic replacement of `zeros(B, K).index_add_(0, batch, rows)`, whose 8192 x 9 float64 atomics
+// on 32 x 9 addresses take 38 us.
+__global__ __launch_bounds__(256) void frame_sum_kernel(const double* __restrict__ rows,
+                                                        const int64_t* __restrict__ batch, int64_t N, int K,
+                                                        double* __restrict__ out) {
+  __shared__ double red[16][256];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  double m[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m[i] = 0.0;
+  for (int64_t n = tid; n < N; n += 256) {
+    if (batch != nullptr && batch[n] != f) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < K) m[i] += rows[(int64_t)K * n + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[i][tid] = m[i];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[i][tid] += red[i][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < K) out[(int64_t)K * f + tid] = red[tid][0];
+}
+
 }  // namespace nqa
 
 using namespace nqa;
@@ -203,6 +233,25 @@ int nqa_virial_finalize(const double* per_atom, const int64_t* batch, const doub
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_virial_finalize: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_frame_sum(const double* rows, const int64_t* batch, int64_t num_nodes, int32_t width, int64_t num_frames,
+                  double* out, nqa_stream stream) {
+  if (num_nodes < 0 || num_frames < 0 || width < 1 || width > 16 || (num_frames > 0 && !out) ||
+      (num_nodes > 0 && !rows) || (num_frames > 1 && batch == nullptr)) {
+    set_error("nqa_frame_sum: invalid argument (1 <= width <= 16; batch is required for more than one frame)");
+    return NQA_ERR_INVALID;
+  }
+  if (num_frames == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(frame_sum_kernel, dim3((unsigned)num_frames), dim3(256), 0, s, rows, batch, num_nodes, (int)width,
+                     out);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_frame_sum: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

@@ -56,9 +56,11 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         did_pos_req_grad = pos.requires_grad
         pos.requires_grad_(True)
         if num_batch > 1:
-            data[K.POSITIONS_KEY] = pos + torch.bmm(
-                pos.unsqueeze(-2), torch.index_select(symmetric_displacement, 0, batch)
-            ).squeeze(-2)
+            # pos_n + pos_n . eps_sym[frame(n)]: broadcast product instead of 8192 batched 1x3 @ 3x3 GEMMs (rocBLAS: 20 us
+            # per bmm, forward and backward), per-frame rows through frame_rows (backward = one ordered sum per frame)
+            from .utils import frame_rows
+
+            data[K.POSITIONS_KEY] = pos + (pos.unsqueeze(-1) * frame_rows(symmetric_displacement, batch)).sum(-2)
         else:
             data[K.POSITIONS_KEY] = pos + torch.sum(pos.view(-1, 3, 1) * symmetric_displacement, 1)
         if has_cell:

@@ -62,3 +62,34 @@ def test_float32_positions_through_the_model(device):
     out32 = model(d32)
     f64, f32 = out64[K.FORCE_KEY].detach(), out32[K.FORCE_KEY].detach().double()
     torch.testing.assert_close(f32, f64, atol=2e-4 * max(1.0, float(f64.abs().max())), rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(9,), (3, 3), (1,), (16,)])
+def test_frame_sum_and_frame_rows(device, shape):
+    """`nqa_frame_sum` (ordered per-frame tree sum) against `index_add_`, its adjoint `per_frame[batch]`, and both once
+    more through autograd (the training path differentiates them twice); unsorted frame indices, an empty frame."""
+    from nequip_amd.nn.utils import frame_rows, frame_sum
+
+    g = torch.Generator().manual_seed(3)
+    N, B = 1000, 7
+    batch = torch.randint(0, B - 1, (N,), generator=g)  # frame B-1 stays empty
+    rows = torch.randn((N,) + shape, generator=g, dtype=torch.float64)
+    ref = torch.zeros((B,) + shape, dtype=torch.float64).index_add_(0, batch, rows)
+    rows_d = rows.to(device).requires_grad_(True)
+    out = frame_sum(rows_d, batch.to(device), B)
+    torch.testing.assert_close(out.cpu(), ref, atol=1e-12, rtol=1e-12)
+    assert float(out[B - 1].abs().max()) == 0.0
+    c = torch.randn((B,) + shape, generator=g, dtype=torch.float64)
+    (g_rows,) = torch.autograd.grad(out, rows_d, c.to(device))
+    torch.testing.assert_close(g_rows.cpu(), c[batch], atol=0, rtol=0)
+
+    per_frame = torch.randn((B,) + shape, generator=g, dtype=torch.float64).to(device).requires_grad_(True)
+    picked = frame_rows(per_frame, batch.to(device))
+    torch.testing.assert_close(picked.cpu(), per_frame.detach().cpu()[batch], atol=0, rtol=0)
+    w = torch.randn((N,) + shape, generator=g, dtype=torch.float64).to(device).requires_grad_(True)
+    (g_pf,) = torch.autograd.grad(picked, per_frame, w, create_graph=True)  # = frame_sum(w)
+    torch.testing.assert_close(g_pf.detach().cpu(), torch.zeros((B,) + shape, dtype=torch.float64).index_add_(0, batch, w.detach().cpu()),
+                               atol=1e-12, rtol=1e-12)
+    (gg,) = torch.autograd.grad(g_pf, w, c.to(device))  # second order: rows of c again
+    torch.testing.assert_close(gg.cpu(), c[batch], atol=0, rtol=0)
