@@ -35,6 +35,14 @@ constexpr int kMaxNb = 8;    // radial basis size limit of the fused kernels (ne
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (CDNA4 counts stores in
 // vmcnt), which would make every chunk wait for its own HBM stores / prefetch loads at the barrier.
+typedef float mlp_v4f __attribute__((ext_vector_type(4)));
+// The weight rows are written once and read by the tensor-product kernels long after the caches have turned over:
+// nontemporal stores keep them from displacing the node rows those kernels gather (cu20k: tp_fwd 2.96 -> 2.83 ms,
+// radial_mlp_fwd -1 %).  Nontemporal LOADS of the gradient rows in the backward were measured too: 3.15 -> 4.1 ms, not used.
+__device__ __forceinline__ void mlp_store4(float* p, const float4& v) {
+  __builtin_nontemporal_store((mlp_v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<mlp_v4f*>(p));
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -608,8 +616,7 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
       float* __restrict__ ob = out + (wrow0 + rsub) * W + n0 + 4 * c4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(ob + (int64_t)(8 * i) * W) =
-            *reinterpret_cast<const float4*>(tb + (8 * i + rsub) * kTS + 4 * c4);
+        mlp_store4(ob + (int64_t)(8 * i) * W, *reinterpret_cast<const float4*>(tb + (8 * i + rsub) * kTS + 4 * c4));
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -774,8 +781,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const
       float* __restrict__ ob = out + (wrow0 + rsub) * W + n0 + 4 * c4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(ob + (int64_t)(8 * i) * W) =
-            *reinterpret_cast<const float4*>(tb + (8 * i + rsub) * kTS + 4 * c4);
+        mlp_store4(ob + (int64_t)(8 * i) * W, *reinterpret_cast<const float4*>(tb + (8 * i + rsub) * kTS + 4 * c4));
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
