@@ -135,6 +135,8 @@ def _emit(st: Structure) -> str:
     # after the caches have turned over and should not displace the gathered node rows (same-box A/B: cfg-3 edge backward
     # 0.24 -> 0.22 ms, cu20k step 22.2 -> 21.8 ms; NQA_GEN_NT=0 at build time restores plain stores)
     nt_stores = os.environ.get("NQA_GEN_NT", "1") != "0"
+    # weight rows through nontemporal LOADS: measured worse (cfg-3 tp_fwd 0.36 -> 0.39 ms, edge backward 0.21 -> 0.25)
+    nt_loads = os.environ.get("NQA_GEN_NT_LOADS", "0") != "0"
 
     def emit_store(ptr, val):
         return f"__builtin_nontemporal_store({val}, {ptr})" if nt_stores else f"*{ptr} = {val}"
@@ -193,7 +195,9 @@ def _emit(st: Structure) -> str:
         out = [f"{indent}T wv{sfx}[kNP];"] if decl else []
         for p in range(NP):
             c = f"T({coeff[p]!r}) * " if scale else ""
-            out.append(f"{indent}wv{sfx}[{p}] = {c}*spec_at({row} + (unsigned)(mul * {p}), ucb);")
+            ld = (f"__builtin_nontemporal_load(spec_at({row} + (unsigned)(mul * {p}), ucb))" if nt_loads
+                  else f"*spec_at({row} + (unsigned)(mul * {p}), ucb)")
+            out.append(f"{indent}wv{sfx}[{p}] = {c}{ld};")
         return out
 
     # ------------------------------------------------------------------ forward
