@@ -987,10 +987,17 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4 fb[3][NT];
+      if (!(dbg & 16) || ch == 0) {  // (ablation bit 16: weight fragments read from LDS for the first chunk only)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) fb[q][t] = bs[((s * 3 + q) * NT + t) * 64];
+          for (int t = 0; t < NT; ++t) fb[q][t] = bs[((s * 3 + q) * NT + t) * 64];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) fb[q][t] = (u32x4){0x3f803f80u + (unsigned)lane, 0x3c003c00u, 0x38003800u + (unsigned)t, 0x3f803f80u + (unsigned)q};
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(am[s], fb[1][t], acc[t]);
