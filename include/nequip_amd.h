@@ -464,7 +464,8 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
  *   The reduction over rows is split into `splits` ranges (nqa_wgrad_splits suggests a count that fills the device;
  *   each range is covered by the four wavefronts of one workgroup, which add their tiles in a fixed order on chip);
  *   partials is [splits][n_types][out_stride] floats, every element covered by a record is written (the rest is
- *   left untouched), and the caller sums over the first axis -- deterministic, no atomics.  float32 only (fp32 MFMA).
+ *   left untouched), and the caller sums over the first axis -- deterministic, no atomics.  float32 only (fp32 MFMA;
+ *   outputs wider than 64 rows run as fp32-accurate split-bf16 products, NQA_WGRAD_EXACT_FP32=1 keeps them on fp32 MFMA).
  * ------------------------------------------------------------------------------------------- */
 int32_t nqa_wgrad_splits(const void* instr_table, int32_t n_instr, int32_t n_types, int64_t num_rows);
 int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64_t* row_types,

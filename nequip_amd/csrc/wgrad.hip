@@ -212,11 +212,228 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- split-bf16 form (output tiles wider than 64 rows: the radial-MLP weight gradients) ---------------------------------
+// The same reduction on v_mfma_f32_32x32x16_bf16: a pipeline step is 16 rows, lane half kg owns rows zb + 8 kg + t
+// (t = 0..7) of its A column / B column, both operands are split into three bf16 terms in registers (six partial products,
+// fp32-accurate: as radial_mlp.hip) -- 24 MFMAs x 32 cycles per 16 rows and 64 x 64 tile instead of 32 x 64 on the fp32
+// matrix path.  One wavefront owns a 64 x 64 tile (two row blocks: the raw operands of the next step, 80 registers, stay
+// in flight during the MFMAs of the current one).  Measured: the 128-row calls of the training step 0.95 -> 0.83 ms only --
+// 32 scalar row loads (8 KB) per step and wavefront are 80 B/clk per CU at the MFMA rate, more than the 64 B/clk the
+// vector memory path delivers; a wider tile per wavefront (or LDS staging shared by the workgroup) is what it needs next.
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t wg_u32x4;
+
+__device__ __forceinline__ uint32_t wg_cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_u32x4& h, wg_u32x4& m, wg_u32x4& l) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = v[2 * p], x1 = v[2 * p + 1];
+    const uint32_t hh = wg_cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(hh << 16);
+    float r1 = x1 - __uint_as_float(hh & 0xffff0000u);
+    const uint32_t mm = wg_cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(mm << 16);
+    r1 -= __uint_as_float(mm & 0xffff0000u);
+    h[p] = hh;
+    m[p] = mm;
+    l[p] = wg_cvt_pk_bf16(r0, r1);
+  }
+}
+__device__ __forceinline__ wg_f16 wg_mfma_bf16(const wg_u32x4& a, const wg_u32x4& b, const wg_f16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b), c, 0,
+                                                 0, 0);
+}
+
+constexpr int kWgRows = 16;  // rows per pipeline step of the split form
+
+// (174 registers; asking for three wavefronts per SIMD spills 36 and doubles the kernel's time: measured)
+template <bool TYPED, bool WGRED>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) {
+  constexpr int RB = 2;
+  const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int unit = WGRED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (!WGRED && unit >= a.total_units) return;
+  int qi = 0;
+  while (qi + 1 < a.n_instr && a.instr[qi + 1].unit_begin <= unit) ++qi;
+  const WgradInstr q = a.instr[qi];
+  const int nt = (q.N + 63) >> 6;
+  int local = unit - q.unit_begin;
+  const int nt_i = local % nt;
+  local /= nt;
+  const int mt_i = local % q.mt;
+  local /= q.mt;
+  const int s = local % a.S;
+  const int t = local / a.S;
+  const int m0 = mt_i * 32 * RB, n0 = nt_i * 64;
+  const int64_t z_begin0 = (WGRED ? (int64_t)s * 4 + wave : (int64_t)s) * a.zc;
+  const int64_t z_begin = z_begin0 < a.Z ? z_begin0 : a.Z;
+  const int64_t z_end = z_begin + a.zc < a.Z ? z_begin + a.zc : a.Z;
+
+  uint32_t ao[RB], bo[2], amask[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int i = m0 + rb * 32 + li;
+    amask[rb] = i < q.M ? 0xFFFFFFFFu : 0u;
+    ao[rb] = 4u * (uint32_t)(q.a_off + (i < q.M ? i : q.M - 1) * q.d);
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int j = n0 + cb * 32 + li;
+    bo[cb] = 4u * (uint32_t)(q.b_off + (j < q.N ? j : q.N - 1) * q.d);
+  }
+  const uint32_t lda4 = 4u * (uint32_t)a.lda, ldb4 = 4u * (uint32_t)a.ldb;
+
+  wg_f16 acc[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+
+  float av[2][RB][8], bv[2][2][8];
+  uint32_t msk[2][8];
+  // operands of step (zb, m): rows zb + 8 half + t.  Loads are unconditional (rows clamped to zb, which is inside the
+  // range); rows outside the range / of another atom type are zeroed through the mask when the A values are consumed.
+  auto load = [&](int buf, int64_t zb, int m, bool live) __attribute__((always_inline)) {
+    const char* __restrict__ as = reinterpret_cast<const char*>(a.A + zb * a.lda + m);  // uniform
+    const char* __restrict__ bs = reinterpret_cast<const char*>(a.B + zb * a.ldb + m);
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const bool in = live && (zb + 8 * half + tt < z_end);
+      const uint32_t row = in ? (uint32_t)(8 * half + tt) : 0u;
+      const uint32_t mk = in ? 0xFFFFFFFFu : 0u;
+      if (TYPED) {
+        const int64_t ty = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(a.types + zb) + 8u * row);
+        msk[buf][tt] = ty == (int64_t)t ? mk : 0u;
+      } else {
+        msk[buf][tt] = mk;
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) av[buf][rb][tt] = *reinterpret_cast<const float*>(as + (row * lda4 + ao[rb]));
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) bv[buf][cb][tt] = *reinterpret_cast<const float*>(bs + (row * ldb4 + bo[cb]));
+    }
+  };
+  auto mfma_all = [&](int buf) __attribute__((always_inline)) {
+    wg_u32x4 bh[2], bm[2], bl[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) wg_split8(bv[buf][cb], bh[cb], bm[cb], bl[cb]);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float x[8];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt)
+        x[tt] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av[buf][rb][tt]) & msk[buf][tt] & amask[rb]);
+      wg_u32x4 ah, am, al;
+      wg_split8(x, ah, am, al);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        acc[rb][cb] = wg_mfma_bf16(am, bm[cb], acc[rb][cb]);
+        acc[rb][cb] = wg_mfma_bf16(ah, bl[cb], acc[rb][cb]);
+        acc[rb][cb] = wg_mfma_bf16(al, bh[cb], acc[rb][cb]);
+        acc[rb][cb] = wg_mfma_bf16(ah, bm[cb], acc[rb][cb]);
+        acc[rb][cb] = wg_mfma_bf16(am, bh[cb], acc[rb][cb]);
+        acc[rb][cb] = wg_mfma_bf16(ah, bh[cb], acc[rb][cb]);
+      }
+    }
+  };
+  if (z_begin < z_end) {
+    const int64_t nzb = (z_end - z_begin + kWgRows - 1) / kWgRows;
+    const int64_t nsteps = nzb * q.d;
+    int64_t zb = z_begin;
+    int m = 0;
+    int64_t it = 0;
+    auto phase = [&](int cur_buf, int nxt_buf) __attribute__((always_inline)) {
+      int64_t zb_n = zb;
+      int m_n = m + 1;
+      if (m_n == q.d) {
+        m_n = 0;
+        zb_n = zb + kWgRows;
+      }
+      ++it;
+      const bool live = it < nsteps;
+      if (!live) {
+        zb_n = zb;
+        m_n = 0;
+      }
+      load(nxt_buf, zb_n, m_n, live);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_all(cur_buf);
+      __builtin_amdgcn_sched_barrier(0);
+      zb = zb_n;
+      m = m_n;
+    };
+    load(0, zb, m, true);
+    const int64_t npairs = (nsteps + 1) / 2;
+    for (int64_t pr = 0; pr < npairs; ++pr) {
+      phase(0, 1);
+      phase(1, 0);
+    }
+  }
+  __shared__ float red[WGRED ? RB * 2 * 16 * 64 : 1];
+#pragma unroll 1
+  for (int src = 1; WGRED && src < 4; ++src) {
+    if (wave == src) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((rb * 2 + cb) * 16 + r) * 64 + lane] = acc[rb][cb][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rb][cb][r] += red[((rb * 2 + cb) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (WGRED && wave != 0) return;
+  float* outp = a.partials + ((int64_t)s * a.T + t) * a.out_stride + q.out_off;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int j = n0 + cb * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (i < q.M && j < q.N) outp[(int64_t)i * q.N + j] = acc[rb][cb][r];
+      }
+    }
+}
+
 }  // namespace nqa
+
 
 using namespace nqa;
 
 extern "C" {
+
+// NQA_WGRAD_EXACT_FP32=1: every shape on the fp32 matrix path (no split-bf16 kernel)
+static bool wgrad_split_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("NQA_WGRAD_EXACT_FP32");
+    return !(e && e[0] != '\0' && e[0] != '0');
+  }();
+  return on;
+}
+// rows-of-32 per output tile: 1 / 2 for M <= 32 / 64; wider outputs take 64-row tiles of the split-bf16 kernel (or
+// 128-row tiles of the fp32 kernel when that is switched off)
+static int wgrad_rb(int maxM, bool* split) {
+  *split = maxM > 64 && wgrad_split_enabled();
+  return maxM <= 32 ? 1 : ((maxM <= 64 || *split) ? 2 : 4);
+}
 
 static bool wgrad_wg_reduce() {
   static const bool on = [] {
@@ -231,7 +448,8 @@ int32_t nqa_wgrad_splits(const void* instr_table, int32_t n_instr, int32_t n_typ
   const int32_t* tab = static_cast<const int32_t*>(instr_table);
   int maxM = 0;
   for (int i = 0; i < n_instr; ++i) maxM = tab[6 * i + 2] > maxM ? tab[6 * i + 2] : maxM;
-  const int RB = maxM <= 32 ? 1 : (maxM <= 64 ? 2 : 4);
+  bool split = false;
+  const int RB = wgrad_rb(maxM, &split);
   int64_t tiles = 0;
   for (int i = 0; i < n_instr; ++i) {
     const int M = tab[6 * i + 2], N = tab[6 * i + 3];
@@ -283,7 +501,7 @@ int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64
   const bool wgred = wgrad_wg_reduce();
   const int64_t nranges = (wgred ? 4 : 1) * (int64_t)splits;
   int64_t zc = (num_rows + nranges - 1) / nranges;  // rows per wavefront
-  zc = (zc + 2 * kWgU - 1) / (2 * kWgU) * (2 * kWgU);
+  zc = (zc + kWgRows - 1) / kWgRows * kWgRows;  // (16: a multiple of both kernels' step)
   if (zc > 2147483647LL / 2) {
     set_error("nqa_wgrad: split too long");
     return NQA_ERR_UNSUPPORTED;
@@ -292,7 +510,8 @@ int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64
   const int32_t* tab = static_cast<const int32_t*>(instr_table);
   int maxM = 0;
   for (int i = 0; i < n_instr; ++i) maxM = tab[6 * i + 2] > maxM ? tab[6 * i + 2] : maxM;
-  const int RB = maxM <= 32 ? 1 : (maxM <= 64 ? 2 : 4);
+  bool split = false;
+  const int RB = wgrad_rb(maxM, &split);
   int64_t units = 0;
   for (int i = 0; i < n_instr; ++i) {
     WgradInstr& q = a.instr[i];
@@ -326,7 +545,15 @@ int nqa_wgrad(int32_t dtype, const void* a_rows, const void* b_rows, const int64
     if (wgred) hipLaunchKernelGGL((wgrad_kernel<R, false, true>), grid, dim3(256), 0, s, a);   \
     else hipLaunchKernelGGL((wgrad_kernel<R, false, false>), grid, dim3(256), 0, s, a);        \
   }
-  if (RB == 1) {
+  if (split) {
+    if (a.types != nullptr) {
+      if (wgred) hipLaunchKernelGGL((wgrad_split_kernel<true, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((wgrad_split_kernel<true, false>), grid, dim3(256), 0, s, a);
+    } else {
+      if (wgred) hipLaunchKernelGGL((wgrad_split_kernel<false, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((wgrad_split_kernel<false, false>), grid, dim3(256), 0, s, a);
+    }
+  } else if (RB == 1) {
     NQA_WGRAD_LAUNCH(1)
   } else if (RB == 2) {
     NQA_WGRAD_LAUNCH(2)
