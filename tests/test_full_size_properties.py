@@ -92,3 +92,18 @@ def test_paired_equals_per_edge_at_headline_size(device, monkeypatch):
     e1, f1, v1 = _eval(model, data)
     torch.testing.assert_close(e1, e0, rtol=1e-6, atol=1e-4)
     torch.testing.assert_close(f1, f0, rtol=0, atol=3e-6 * max(1.0, float(f0.abs().max())))
+
+
+@pytest.mark.gpu
+def test_pair_centric_backward_equals_per_edge_backward_at_headline_size(device, monkeypatch):
+    """cfg-3 box: the pair-centric backward kernels (`nqa_tp_scatter_bwd_pairs`, what bench.py times) against the per-edge
+    fused / edge backward on the same paired weights: same energy, forces and virial."""
+    model, data, n = _setup("water10k", device)
+    monkeypatch.delenv("NQA_NO_PAIRED", raising=False)
+    monkeypatch.delenv("NQA_NO_PAIR_BWD", raising=False)
+    e0, f0, v0 = _eval(model, data)
+    monkeypatch.setenv("NQA_NO_PAIR_BWD", "1")
+    e1, f1, v1 = _eval(model, data)
+    torch.testing.assert_close(e1, e0, rtol=0, atol=0)  # the forward pass is the same code
+    torch.testing.assert_close(f1, f0, rtol=0, atol=3e-6 * max(1.0, float(f0.abs().max())))
+    torch.testing.assert_close(v1, v0, rtol=0, atol=3e-6 * max(1.0, float(v0.abs().max())))
