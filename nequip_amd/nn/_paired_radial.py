@@ -188,6 +188,10 @@ def available(edge_mlp, tp_scatter, x: torch.Tensor, emb: torch.Tensor) -> bool:
     """float32 GPU evaluation with the fused split-bf16 MLP and structure-specialised TP kernels."""
     if not x.is_cuda or x.dtype != torch.float32 or emb.dtype != torch.float32:
         return False
+    from ..utils.tracing import traceable
+
+    if traceable():
+        return False  # pairing is decided from the data on the host
     if os.environ.get("NQA_NO_PAIRED", "") not in ("", "0"):
         return False
     if not edge_mlp._fused_ok(emb) or _mlp.radial_mlp_mode() != _lib.NQA_MLP_BF16X6:

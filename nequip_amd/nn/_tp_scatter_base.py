@@ -413,21 +413,24 @@ class TensorProductScatter(torch.nn.Module):
     def forward(self, x, edge_attr, edge_weight, edge_dst, edge_src, topology: Optional[EdgeTopology] = None,
                 pairing=None):
         """``pairing`` (extension, ``EdgeTopology.pairing``): ``edge_weight`` has one row per reverse-edge pair."""
-        if not x.is_cuda:
+        from ..utils.tracing import traceable
+
+        tracing = self.use_dispatcher_ops or traceable()
+        if not x.is_cuda and not tracing:  # (fake CPU tensors may flow through the dispatcher ops while tracing)
             raise RuntimeError(
                 "nequip_amd.nn.TensorProductScatter runs on the GPU only (HIP kernels); no CPU fallback exists"
             )
-        if self._plan_image.device != x.device:
+        if self._plan_image.device != x.device and not tracing:
             raise RuntimeError("module and inputs are on different devices; call .to(device) on the model")
         # explicit cast to account for AMP (as nequip/nn/_tp_scatter_oeq.py:49-57)
         x = x.to(self.model_dtype)
         edge_attr = edge_attr.to(self.model_dtype)
         edge_weight = edge_weight.to(self.model_dtype)
-        if pairing is not None:
+        if pairing is not None and not tracing:
             if topology is None:
                 topology = topology_cache.get(edge_dst, edge_src, x.size(0))
             return _TPScatterFn.apply(x, edge_attr, edge_weight, self._get_kernels(), topology, pairing)
-        if self.use_dispatcher_ops or torch.compiler.is_compiling():
+        if tracing:
             from ._tp_scatter_ops import tp_scatter
 
             return tp_scatter(x, edge_attr, edge_weight, edge_dst, edge_src, self._plan_key)

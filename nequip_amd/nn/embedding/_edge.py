@@ -22,6 +22,16 @@ from ...o3.irreps import Irreps
 from .._graph_mixin import GraphModuleMixin
 from .._topology import _ptr, current_stream_ptr
 from ..utils import with_edge_vectors_
+from ...utils.tracing import traceable
+
+
+def _embed(edge_vec, bessel_weights, cfg):
+    """The fused kernel as an autograd Function (eager) or as dispatcher ops (while tracing)."""
+    if traceable():
+        from ._edge_ops import edge_embed
+
+        return edge_embed(edge_vec, bessel_weights, cfg)
+    return _EdgeEmbedFn.apply(edge_vec, bessel_weights, cfg)
 
 _GLOBAL_DTYPE = torch.float64  # nequip/utils/global_dtype.py:5
 
@@ -94,22 +104,29 @@ class _EdgeEmbedBwdFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, c):
         vec, bw, g_sh, g_emb = ctx.saved_tensors
-        cfg = ctx.cfg
-        lib = _lib.load()
-        c = c.contiguous()
-        E = vec.shape[0]
         need_vec, _, need_gsh, need_gemb = ctx.needs_input_grad[:4]
-        g_vec2 = torch.empty((E, 3), dtype=torch.float64, device=vec.device) if need_vec else None
-        gg_sh = torch.empty_like(g_sh) if (g_sh is not None and need_gsh) else None
-        gg_emb = torch.empty_like(g_emb) if (g_emb is not None and need_gemb) else None
-        with torch.cuda.device(vec.device):
-            rc = lib.nqa_edge_embed_bwd_bwd(
-                _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
-                cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(c), _ptr(gg_sh),
-                _ptr(gg_emb), _ptr(g_vec2), current_stream_ptr(vec.device),
-            )  # fmt: skip
-        _lib.check(rc, "nqa_edge_embed_bwd_bwd")
+        g_vec2, gg_sh, gg_emb = _edge_embed_second_order(vec, bw, g_sh, g_emb, c, ctx.cfg, need_vec, need_gsh, need_gemb)
         return g_vec2, None, gg_sh, gg_emb, None
+
+
+def _edge_embed_second_order(vec, bw, g_sh, g_emb, c, cfg, need_vec: bool, need_gsh: bool, need_gemb: bool):
+    """``nqa_edge_embed_bwd_bwd``: gradients of ``g_vec = J(v)^T g`` w.r.t. (v, g_sh, g_emb) for the cotangent ``c``."""
+    lib = _lib.load()
+    c = c.contiguous()
+    g_sh = g_sh.contiguous() if g_sh is not None else None
+    g_emb = g_emb.contiguous() if g_emb is not None else None
+    E = vec.shape[0]
+    g_vec2 = torch.empty((E, 3), dtype=torch.float64, device=vec.device) if need_vec else None
+    gg_sh = torch.empty_like(g_sh) if (g_sh is not None and need_gsh) else None
+    gg_emb = torch.empty_like(g_emb) if (g_emb is not None and need_gemb) else None
+    with torch.cuda.device(vec.device):
+        rc = lib.nqa_edge_embed_bwd_bwd(
+            _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
+            cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(c), _ptr(gg_sh),
+            _ptr(gg_emb), _ptr(g_vec2), current_stream_ptr(vec.device),
+        )  # fmt: skip
+    _lib.check(rc, "nqa_edge_embed_bwd_bwd")
+    return g_vec2, gg_sh, gg_emb
 
 
 class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):
@@ -162,9 +179,7 @@ class BesselEdgeLengthEncoding(GraphModuleMixin, torch.nn.Module):
         data = with_edge_vectors_(data, with_lengths=False)
         cfg = dict(dtype=self._output_dtype, lmax=0, want_sh=False, want_emb=True, nb=self.num_bessels,
                    rmax_recip=float(data["_nqa_rmax_recip"]), p=float(self.cutoff.p), factor=float(self.factor))
-        data[self.edge_invariant_field] = _EdgeEmbedFn.apply(
-            data[AtomicDataDict.EDGE_VECTORS_KEY], self.bessel_weights.view(-1), cfg
-        )
+        data[self.edge_invariant_field] = _embed(data[AtomicDataDict.EDGE_VECTORS_KEY], self.bessel_weights.view(-1), cfg)
         return data
 
 
@@ -193,5 +208,5 @@ class SphericalHarmonicEdgeAttrs(GraphModuleMixin, torch.nn.Module):
         data = with_edge_vectors_(data, with_lengths=False)
         cfg = dict(dtype=self._output_dtype, lmax=self.lmax, want_sh=True, want_emb=False, nb=0, rmax_recip=1.0,
                    p=6.0, factor=1.0)
-        data[self.out_field] = _EdgeEmbedFn.apply(data[AtomicDataDict.EDGE_VECTORS_KEY], self._dummy_bw, cfg)
+        data[self.out_field] = _embed(data[AtomicDataDict.EDGE_VECTORS_KEY], self._dummy_bw, cfg)
         return data

@@ -5,6 +5,7 @@
 import torch
 
 from ..data import AtomicDataDict
+from ..utils.tracing import traceable
 from ..utils.wgrad import inputs_only_backward
 from ._graph_mixin import GraphModuleMixin
 from .model_modifier_utils import model_modifier, replace_submodules
@@ -42,7 +43,7 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
             num_batch = 1
         pos = data[K.POSITIONS_KEY]
         has_cell = K.CELL_KEY in data
-        if not self.training and pos.is_cuda and pos.dtype == torch.float64:
+        if not self.training and pos.is_cuda and pos.dtype == torch.float64 and not traceable():
             return self._forward_inference(data, pos, batch, num_batch, has_cell)
         if has_cell:
             orig_cell = data[K.CELL_KEY]

@@ -39,6 +39,8 @@ def uvu_paths(features_in: Irreps, edge_attr: Irreps, features_out: Irreps):
     return mid_sorted, [(a, b, slot_of[n], "uvu", True) for n, (a, b, _) in enumerate(created)]
 
 
+from ..utils.tracing import traceable
+
 class InteractionBlock(GraphModuleMixin, torch.nn.Module):
     use_sc: bool
     paired_radial_ok: bool = True  # the edge embedding depends on |r| only (see forward)
@@ -107,7 +109,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         # the four launches it replaces (340-500 us against ~140 us: DESIGN.md section 4) -- NQA_CHAIN=1 enables it.
         if nxt is None or os.environ.get("NQA_CHAIN", "") in ("", "0"):
             return None
-        if not x.is_cuda or x.dtype != torch.float32 or torch.compiler.is_compiling():
+        if not x.is_cuda or x.dtype != torch.float32 or traceable():
             return None
         if AtomicDataDict.LMP_MLIAP_DATA_KEY in data:
             return None
@@ -154,7 +156,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             # after linear_2, so it runs as a parallel branch on a side stream (its backward too: autograd runs a node's
             # backward on the stream of its forward); both kernels are small and latency-bound at 10k atoms
             if (not differentiable_parameters(self.training, self.sc.weight) and x.is_cuda
-                    and _paired_radial.RadialBackwardQueue.enabled() and not torch.compiler.is_compiling()):
+                    and _paired_radial.RadialBackwardQueue.enabled() and not traceable()):
                 sc_stream = _paired_radial.side_stream(x.device, 1)
                 sc_stream.wait_stream(torch.cuda.current_stream(x.device))
                 x.record_stream(sc_stream)
@@ -167,7 +169,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         norm = self.avg_num_neighbors_norm
         if chained is not None:
             pass  # x = scale * linear_1(Gate(...)) came out of the fused launch
-        elif norm.norm_shortcut and x.is_cuda and norm.norm_key not in data:
+        elif norm.norm_shortcut and x.is_cuda and not traceable() and norm.norm_key not in data:
             # one avg_num_neighbors for all types: 1/sqrt(avg) rides on the linear_1 launch (no separate N x D pass)
             x = self.linear_1(x, scale=norm.norm_scalar)
         else:

@@ -24,6 +24,8 @@ def radial_mlp_mode() -> int:
     return _lib.NQA_MLP_FP32 if os.environ.get("NQA_MLP_EXACT_FP32", "") not in ("", "0") else _lib.NQA_MLP_BF16X6
 
 
+from ..utils.tracing import traceable
+
 class _WeightImages:
     """Per-module cache of the split / re-laid-out second-layer weights (``workspace`` of ``nqa_radial_mlp_fwd/bwd``):
     in eval mode the weights are constants, so the prepass kernel runs once per parameter version, not per call."""
@@ -292,7 +294,7 @@ class ScalarLinearLayer(torch.nn.Module):
         w = self.weight * self.alpha
         if self.bias is not None:
             return torch.addmm(self.bias, input, w)
-        if self.out_features == 1 and self.training and input.is_cuda:
+        if self.out_features == 1 and self.training and input.is_cuda and not traceable():
             # single-column layer (the per-atom energy readout): its weight-side backward as a library GEMM is a
             # [in, N] x [N, 1] product that runs on one workgroup (0.12 ms at 8k atoms); as multiply + row sum both
             # directions are plain streaming kernels
@@ -329,6 +331,8 @@ class ScalarMLPFunction(_WeightCacheMixin, torch.nn.Module):
     def _fused_ok(self, x: torch.Tensor) -> bool:
         if not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear or self.has_bias:
             return False
+        if traceable():
+            return False  # the mm / SiLU form traces
         ok = getattr(self, "_fused_supported", None)
         if ok is None:
             lib = _lib.load()

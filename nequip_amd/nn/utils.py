@@ -6,6 +6,7 @@ import torch
 
 from ..data import AtomicDataDict
 from ..o3.irreps import Irrep, Irreps
+from ..utils.tracing import traceable
 
 
 def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: Optional[int] = None) -> torch.Tensor:
@@ -28,7 +29,7 @@ def _frame_kernel_ok(like: torch.Tensor, batch: torch.Tensor, num_frames: int) -
     width = 1
     for d in like.shape[1:]:
         width *= d
-    return (like.is_cuda and like.dtype == torch.float64 and batch.dtype == torch.int64 and 1 <= width <= 16
+    return (like.is_cuda and not traceable() and like.dtype == torch.float64 and batch.dtype == torch.int64 and 1 <= width <= 16
             and num_frames * batch.shape[0] <= _FRAME_SCAN_MAX)
 
 
@@ -195,7 +196,7 @@ def with_edge_vectors_(data: AtomicDataDict.Type, with_lengths: bool = True) -> 
         return data
     pos = data[K.POSITIONS_KEY]
     edge_index = data[K.EDGE_INDEX_KEY]
-    if pos.is_cuda:
+    if pos.is_cuda and not traceable():
         cell = data.get(K.CELL_KEY)
         shift = data[K.EDGE_CELL_SHIFT_KEY].contiguous() if cell is not None else None
         batch = data[K.BATCH_KEY].contiguous() if (cell is not None and K.BATCH_KEY in data) else None

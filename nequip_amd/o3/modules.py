@@ -21,6 +21,8 @@ from ._node_kernels import GateMeta, NodeLinearMeta, gate as _gate_kernel, node_
 from ..utils.wgrad import _WeightCacheMixin, differentiable_parameters
 
 
+from ..utils.tracing import traceable
+
 class Linear(_WeightCacheMixin, torch.nn.Module):
     """``out[z, i_out, w, m] = sum_{i_in} fan_in(i_out)^-1/2 sum_u x[z, i_in, u, m] W[u, w]`` (no bias)."""
 
@@ -58,7 +60,7 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
         self.register_buffer("_scale_vec", scale_vec, persistent=False)
 
     def forward(self, x: torch.Tensor, addend: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
-        if x.is_cuda and x.dtype in (torch.float32, torch.float64) and self.weight_numel > 0:
+        if x.is_cuda and not traceable() and x.dtype in (torch.float32, torch.float64) and self.weight_numel > 0:
             # eval mode: parameter gradients are not produced (inference fast path, as for the radial MLP) unless
             # nequip_amd.utils.wgrad.eval_parameter_gradients(True) asks for the reference's behaviour
             if differentiable_parameters(self.training, self.weight):
@@ -209,7 +211,7 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
         return cached[1]
 
     def forward_typed(self, x: torch.Tensor, types: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
-        if x.is_cuda and self._meta is not None and x.dtype in (torch.float32, torch.float64):
+        if x.is_cuda and not traceable() and self._meta is not None and x.dtype in (torch.float32, torch.float64):
             # per-type pre-contraction W_t[u, w] = sum_v table[t, v] W[u, v, w] (tiny), then ONE fused launch
             def contract(weight, table):
                 # all instructions at once: gather the flat [u, v, w] blocks into one [v, sum(u*w)] matrix (fixed
@@ -312,7 +314,7 @@ class Gate(torch.nn.Module):
         return torch.cat(cols, dim=-1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.is_cuda and self._kernel_meta is not None and x.dtype in (torch.float32, torch.float64):
+        if x.is_cuda and not traceable() and self._kernel_meta is not None and x.dtype in (torch.float32, torch.float64):
             # one fused launch per pass: forward, backward and (training) the backward's own backward
             return _gate_kernel(x, self._kernel_meta)
         ns, ng = self.irreps_scalars.dim, self.irreps_gates.dim

@@ -1,0 +1,137 @@
+"""Whole-model traceability (the reference compiles a model by symbolic tracing, nequip/nn/compile.py:176-191):
+inside `traceable_forms()` every module picks a form `make_fx` can follow -- dispatcher ops for the tensor-product scatter
+and the edge embedding, ATen formulations for the rest -- so energy AND forces (autograd inside the model) trace into one
+graph.  Traced here without a GPU through fake tensors; on the GPU the traced graph must reproduce the eager model."""
+import pytest
+import torch
+
+from nequip_amd.data import AtomicDataDict
+from nequip_amd.model import NequIPGNNModel
+from nequip_amd.utils import synthetic as syn
+from nequip_amd.utils.tracing import traceable, traceable_forms
+
+FIELDS = ("pos", "cell", "edge_index", "edge_cell_shift", "atom_types")
+
+
+def _model_and_data(device, parity=False, l_max=2):
+    pos, types, cell, names = syn.water_box(n_side=2, seed=5)
+    data = syn.make_data(pos, types, 4.0, cell)
+    model = NequIPGNNModel(seed=3, model_dtype="float32", r_max=4.0, type_names=names, num_layers=2, l_max=l_max,
+                           parity=parity, num_features=8, radial_mlp_depth=1, radial_mlp_width=16,
+                           avg_num_neighbors=float(data["edge_index"].shape[1] / data["pos"].shape[0]),
+                           per_type_energy_scales=1.0, per_type_energy_shifts=0.0).to(device).eval()
+    data = AtomicDataDict.to_device(data, device)
+    return model, {k: data[k] for k in FIELDS}
+
+
+def _fn(model):
+    def f(inputs):
+        out = model(dict(inputs))
+        return out["total_energy"], out["forces"], out["virial"]
+
+    return f
+
+
+def _functional(model):
+    """(params, buffers, inputs) -> outputs: the weights are graph inputs, as in the reference's compile path
+    (nequip/nn/compile.py:150-191)."""
+    def f(params, buffers, inputs):
+        out = torch.func.functional_call(model, (params, buffers), (dict(inputs),))
+        return out["total_energy"], out["forces"], out["virial"]
+
+    return f, dict(model.named_parameters()), dict(model.named_buffers())
+
+
+def test_flag_scopes():
+    assert not traceable()
+    with traceable_forms():
+        assert traceable()
+        with traceable_forms(False):
+            assert traceable()
+    assert not traceable()
+
+
+def test_whole_model_traces_with_fake_tensors_on_cpu():
+    from torch.fx.experimental.proxy_tensor import make_fx
+
+    model, inputs = _model_and_data(torch.device("cpu"))
+    f, params, buffers = _functional(model)
+    with traceable_forms():
+        gm = make_fx(f, tracing_mode="fake")(params, buffers, inputs)
+    targets = {str(n.target) for n in gm.graph.nodes if n.op == "call_function"}
+    ours = {t for t in targets if t.startswith("nequip_amd.")}
+    assert {"nequip_amd.tp_scatter_fwd.default", "nequip_amd.tp_scatter_bwd.default",
+            "nequip_amd.edge_embed_fwd.default", "nequip_amd.edge_embed_bwd.default"} <= ours, ours
+    assert all(t.startswith(("aten.", "nequip_amd.", "<built-in", "_operator", "prims.")) for t in targets), targets
+    # outputs: energy [1, 1], forces [N, 3], virial [1, 3, 3]
+    outs = [n for n in gm.graph.nodes if n.op == "output"][0].args[0]
+    assert len(outs) == 3
+
+
+def test_whole_model_traces_symbolically_on_cpu():
+    """`tracing_mode="symbolic"` (what nequip/nn/compile.py:176-191 uses): the edge count stays a symbol."""
+    from torch.fx.experimental.proxy_tensor import make_fx
+
+    model, inputs = _model_and_data(torch.device("cpu"))
+    f, params, buffers = _functional(model)
+    with traceable_forms():
+        gm = make_fx(f, tracing_mode="symbolic")(params, buffers, inputs)
+    shift = [n for n in gm.graph.nodes if n.op == "placeholder"][-2].meta["val"]
+    assert not isinstance(shift.shape[0], int), "the number of edges must be symbolic"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parity,l_max", [(False, 2), (True, 1)])
+def test_traced_graph_reproduces_the_eager_model(device, parity, l_max):
+    from torch.fx.experimental.proxy_tensor import make_fx
+
+    model, inputs = _model_and_data(device, parity, l_max)
+    e0, f0, v0 = _fn(model)(inputs)  # eager: fused kernels
+    with traceable_forms():
+        e1, f1, v1 = _fn(model)(inputs)  # the traceable forms themselves, eagerly
+        f, params, buffers = _functional(model)
+        gm = make_fx(f, tracing_mode="real")(params, buffers, inputs)
+    e2, f2, v2 = gm(params, buffers, inputs)  # the traced graph, outside the context
+    for a, b in ((e1, e0), (f1, f0), (v1, v0), (e2, e0), (f2, f0), (v2, v0)):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5 * max(1.0, float(b.abs().max())))
+    # other positions through the same graph (no constants of the traced example baked in)
+    inputs2 = dict(inputs)
+    inputs2["pos"] = inputs["pos"] + 0.01 * torch.randn_like(inputs["pos"])
+    e3, f3, _ = gm(params, buffers, inputs2)
+    e4, f4, _ = _fn(model)(inputs2)
+    torch.testing.assert_close(e3, e4, rtol=1e-5, atol=2e-5 * max(1.0, float(e4.abs().max())))
+    torch.testing.assert_close(f3, f4, rtol=1e-5, atol=2e-5 * max(1.0, float(f4.abs().max())))
+
+
+@pytest.mark.gpu
+def test_trace_model_helper_and_edge_embed_ops(device):
+    """`trace_model` (dict outputs) and the edge-embedding ops against the autograd-Function form, second order included."""
+    from nequip_amd.nn.embedding._edge import _EdgeEmbedFn
+    from nequip_amd.nn.embedding._edge_ops import edge_embed
+    from nequip_amd.utils.tracing import trace_model
+
+    model, inputs = _model_and_data(device)
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="real")
+    out = gm(params, buffers, inputs)
+    ref = model(dict(inputs))
+    torch.testing.assert_close(out["forces"], ref["forces"], rtol=1e-5, atol=2e-5 * float(ref["forces"].abs().max()))
+
+    g = torch.Generator().manual_seed(2)
+    vec = (torch.randn(300, 3, generator=g, dtype=torch.float64) * 2.0).to(device)
+    bw = torch.linspace(1.0, 8, 8, dtype=torch.float64, device=device)
+    for cfg in (dict(dtype=torch.float32, lmax=2, want_sh=True, want_emb=False, nb=0, rmax_recip=1.0, p=6.0, factor=1.0),
+                dict(dtype=torch.float32, lmax=0, want_sh=False, want_emb=True, nb=8, rmax_recip=1 / 4.5, p=6.0, factor=0.31),
+                dict(dtype=torch.float64, lmax=3, want_sh=True, want_emb=True, nb=8, rmax_recip=1 / 4.5, p=6.0, factor=0.31)):
+        res = []
+        for form in (_EdgeEmbedFn.apply, edge_embed):
+            v = vec.clone().requires_grad_(True)
+            out = form(v, bw, cfg)
+            outs = list(out) if isinstance(out, tuple) else [out]
+            cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(7 + i), dtype=o.dtype).to(device).requires_grad_(True)
+                   for i, o in enumerate(outs)]
+            (gv,) = torch.autograd.grad(outs, [v], cot, create_graph=True)
+            c = torch.randn(gv.shape, generator=torch.Generator().manual_seed(11), dtype=gv.dtype).to(device)
+            second = torch.autograd.grad([gv], [v] + cot, [c])
+            res.append([o.detach() for o in outs] + [gv.detach()] + [s.detach() for s in second])
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=0, atol=0)  # the same kernels
