@@ -277,6 +277,7 @@ class ScalarLinearLayer(torch.nn.Module):
         self.in_features = in_features
         self.out_features = out_features
         self.register_buffer("alpha", torch.tensor(alpha), persistent=False)
+        self.alpha_value = float(alpha)  # the same number as a host constant (kernel arguments, tracing)
         self.weight = torch.nn.Parameter(torch.empty((in_features, out_features)))
         if init_mode == "uniform":
             torch.nn.init.uniform_(self.weight, -sqrt(3), sqrt(3))
@@ -328,23 +329,32 @@ class ScalarMLPFunction(_WeightCacheMixin, torch.nn.Module):
                 self.is_nonlinear = True
         self.mlp = mlp
 
-    def _fused_ok(self, x: torch.Tensor) -> bool:
+    def _fused_ok(self, x: torch.Tensor, tracing_ok: bool = False) -> bool:
         if not x.is_cuda or x.dtype != torch.float32 or self.num_layers != 2 or not self.is_nonlinear or self.has_bias:
             return False
-        if traceable():
-            return False  # the mm / SiLU form traces
+        if traceable() and not tracing_ok:
+            return False  # (callers that cannot use the dispatcher-op form take the mm / SiLU form, which traces)
         ok = getattr(self, "_fused_supported", None)
         if ok is None:
             lib = _lib.load()
             ok = bool(lib.nqa_radial_mlp_supported(_lib.NQA_F32, self.dims[0], self.dims[1], self.dims[2]))
             self._fused_supported = ok
-            self._alphas = (float(self.mlp[0].alpha), float(self.mlp[2].alpha))
+            self._alphas = (self.mlp[0].alpha_value, self.mlp[2].alpha_value)
         return ok
 
     def forward(self, x):
         # GPU, float32, two layers of a supported shape: fused MFMA kernels (the hidden layer stays on chip).  Eval mode:
         # weights are constants (inference Function, gradient w.r.t. the embedding only).  Training: the same kernels
         # inside a twice-differentiable Function pair that also produces the parameter gradients.
+        if traceable():
+            # while tracing: the fused kernels as dispatcher ops when the weights are constants (nn/_mlp_ops.py), else ATen
+            if self._fused_ok(x, tracing_ok=True) and not differentiable_parameters(
+                    self.training, self.mlp[0].weight, self.mlp[2].weight):
+                from ._mlp_ops import radial_mlp
+
+                return radial_mlp(x, self.mlp[0].weight.detach(), self.mlp[2].weight.detach(), self._alphas[0],
+                                  self._alphas[1])
+            return self.mlp(x)
         if self._fused_ok(x):
             cache = getattr(self, "_weight_images", None)
             if cache is None:

@@ -135,3 +135,33 @@ def test_trace_model_helper_and_edge_embed_ops(device):
             res.append([o.detach() for o in outs] + [gv.detach()] + [s.detach() for s in second])
         for a, b in zip(*res):
             torch.testing.assert_close(a, b, rtol=0, atol=0)  # the same kernels
+
+
+@pytest.mark.gpu
+def test_radial_mlp_ops_match_the_function_form(device):
+    """`torch.ops.nequip_amd.radial_mlp_fwd/_bwd/_bwd_bwd` against the module's eager (training-capable) Functions: value,
+    gradient w.r.t. the embedding, and the second-order terms w.r.t. the embedding and the incoming gradient."""
+    from nequip_amd.nn._mlp_ops import radial_mlp
+    from nequip_amd.nn.mlp import ScalarMLPFunction
+
+    torch.manual_seed(0)
+    mlp = ScalarMLPFunction(8, 192, 1, 128).to(device)
+    emb = (torch.randn(1000, 8, device=device) * 0.5)
+    g = torch.randn(1000, 192, device=device)
+    c = torch.randn(1000, 8, device=device)
+    w0, w1 = mlp.mlp[0].weight.detach(), mlp.mlp[2].weight.detach()
+    a0, a1 = float(mlp.mlp[0].alpha), float(mlp.mlp[2].alpha)
+
+    def run(fwd):
+        e = emb.clone().requires_grad_(True)
+        gg = g.clone().requires_grad_(True)
+        out = fwd(e)
+        (ge,) = torch.autograd.grad(out, e, gg, create_graph=True)
+        s_e, s_g = torch.autograd.grad(ge, [e, gg], c)
+        return out.detach(), ge.detach(), s_e, s_g
+
+    mlp.train()  # the twice-differentiable Function pair
+    ref = run(lambda e: mlp(e))
+    got = run(lambda e: radial_mlp(e, w0, w1, a0, a1))
+    for r, o, what in zip(ref, got, ("value", "grad emb", "second order emb", "second order g")):
+        torch.testing.assert_close(o, r, rtol=2e-5, atol=2e-5 * max(1.0, float(r.abs().max())), msg=lambda m: f"{what}: {m}")
