@@ -9,8 +9,6 @@ gradient flows to ``w0`` / ``w1``): modules with differentiable parameters keep 
 
 from __future__ import annotations
 
-import collections
-
 import torch
 
 _NS = "nequip_amd"
@@ -20,22 +18,14 @@ _lib_def.define("radial_mlp_bwd(Tensor emb, Tensor w0, Tensor w1, Tensor g, floa
 _lib_def.define("radial_mlp_bwd_bwd(Tensor emb, Tensor w0, Tensor w1, Tensor g, Tensor c, float alpha0, float alpha1, "
                 "bool need_emb, bool need_g) -> (Tensor, Tensor)")
 
-_caches: "collections.OrderedDict" = collections.OrderedDict()
-
-
 def _cache_for(w1: torch.Tensor):
-    """Split / re-laid-out weight images per parameter version (what the modules keep in ``_weight_images``)."""
+    """A fresh image cache per call: the op sees the weights as plain tensors (no parameter identity to key a cache on --
+    addresses are re-used across models), so the split / re-laid-out second-layer weights are rebuilt by the ~7 us prepass
+    kernel each time; the eager modules keep theirs per parameter version."""
     from .mlp import _WeightImages
 
-    key = (w1.data_ptr(), w1._version, str(w1.device), tuple(w1.shape))
-    c = _caches.get(key)
-    if c is None:
-        c = _caches[key] = _WeightImages()
-        c.validate(w1)
-        while len(_caches) > 32:
-            _caches.popitem(last=False)
-    else:
-        _caches.move_to_end(key)
+    c = _WeightImages()
+    c.validate(w1)
     return c
 
 

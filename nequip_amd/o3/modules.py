@@ -22,6 +22,7 @@ from ..utils.wgrad import _WeightCacheMixin, differentiable_parameters
 
 
 from ..utils.tracing import traceable
+from . import _node_ops
 
 class Linear(_WeightCacheMixin, torch.nn.Module):
     """``out[z, i_out, w, m] = sum_{i_in} fan_in(i_out)^-1/2 sum_u x[z, i_in, u, m] W[u, w]`` (no bias)."""
@@ -54,6 +55,7 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
             off += n
         # fused HIP path: all per-irrep matrices in one launch (csrc/node_ops.hip)
         self._meta = NodeLinearMeta(self.irreps_in, self.irreps_out, self.instructions)
+        self._op_key = _node_ops.linear_key(self.irreps_in, self.irreps_out, self.instructions)
         scale_vec = torch.cat(
             [torch.full((sl.stop - sl.start,), self._scale[o]) for (i, o), (sl, _) in zip(self.instructions, self.weight_index_slices)]
         ) if self.instructions else torch.zeros(0)
@@ -68,6 +70,11 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
             else:
                 wp = self.eval_weights(x.device, x.dtype)
             return _node_linear(x, wp, None, self._meta, addend=addend, scale=scale)
+        if (traceable() and x.is_cuda and x.dtype == torch.float32 and self.weight_numel > 0
+                and not differentiable_parameters(self.training, self.weight)):
+            # while tracing, constant weights: the fused kernel as a dispatcher op (o3/_node_ops.py)
+            wp = (self.weight.detach() * self._scale_vec).unsqueeze(0)
+            return _node_ops.node_linear_op(x, wp, self._op_key, addend=addend, scale=scale)
         out = self._forward_reference(x)
         if scale != 1.0:
             out = out * scale
@@ -158,6 +165,8 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             if len(self.irreps_in2) == 1
             else None
         )
+        self._op_key = (_node_ops.linear_key(self.irreps_in1, self.irreps_out, [(i1, io) for i1, _, io in self.instructions])
+                        if self._meta is not None else None)
 
     def _contract_index(self, device, dtype):
         key = (str(device), dtype)
@@ -224,6 +233,11 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             else:  # constants in eval mode: contracted once per (weight, table) version
                 wp = self.eval_weights_typed(table, x.dtype)
             return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)
+        if (traceable() and x.is_cuda and x.dtype == torch.float32 and self._meta is not None
+                and not differentiable_parameters(self.training, self.weight)):
+            perm, scale = self._contract_index(self.weight.device, self.weight.dtype)
+            wp = torch.mm(table.detach(), self.weight.detach().index_select(0, perm).view(table.shape[1], -1) * scale)
+            return _node_ops.node_linear_op(x, wp, self._op_key, types=types.view(-1).contiguous())
         Z = x.shape[0]
         T = table.shape[0]
         onehot = torch.nn.functional.one_hot(types.view(-1), T).to(x.dtype)  # [Z, T]
@@ -300,6 +314,11 @@ class Gate(torch.nn.Module):
                 self.irreps_gates, [(names[a], c) for a, c in zip(self.act_gates, self._cst_gates)],
                 self.irreps_gated,
             )
+            self._op_key = _node_ops.gate_key(
+                self.irreps_scalars, [(names[a], c) for a, c in zip(self.act_scalars, self._cst_scalars)],
+                self.irreps_gates, [(names[a], c) for a, c in zip(self.act_gates, self._cst_gates)],
+                self.irreps_gated,
+            )
 
     @staticmethod
     def _activate(t, irreps, acts, csts):
@@ -317,6 +336,8 @@ class Gate(torch.nn.Module):
         if x.is_cuda and not traceable() and self._kernel_meta is not None and x.dtype in (torch.float32, torch.float64):
             # one fused launch per pass: forward, backward and (training) the backward's own backward
             return _gate_kernel(x, self._kernel_meta)
+        if traceable() and x.is_cuda and x.dtype == torch.float32 and self._kernel_meta is not None:
+            return _node_ops.gate_op(x, self._op_key)  # while tracing: the fused kernel as a dispatcher op
         ns, ng = self.irreps_scalars.dim, self.irreps_gates.dim
         if ng == 0:
             return self._activate(x, self.irreps_scalars, self.act_scalars, self._cst_scalars)

@@ -165,3 +165,28 @@ def test_radial_mlp_ops_match_the_function_form(device):
     got = run(lambda e: radial_mlp(e, w0, w1, a0, a1))
     for r, o, what in zip(ref, got, ("value", "grad emb", "second order emb", "second order g")):
         torch.testing.assert_close(o, r, rtol=2e-5, atol=2e-5 * max(1.0, float(r.abs().max())), msg=lambda m: f"{what}: {m}")
+
+
+@pytest.mark.gpu
+def test_traced_benchmark_shaped_model_keeps_the_fused_kernels(device):
+    """cfg-3-shaped model (64 features, radial MLP 8-128-W) on a small box: traced on the GPU, every fused kernel family
+    appears as a dispatcher op in the graph, and the graph reproduces the eager model (energy, forces, virial)."""
+    from nequip_amd.utils.tracing import trace_model
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=2)
+    data = syn.make_data(pos, types, 4.5, cell)
+    model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
+                           avg_num_neighbors=float(data["edge_index"].shape[1] / data["pos"].shape[0]),
+                           per_type_energy_scales=1.0, per_type_energy_shifts=0.0).to(device).eval()
+    data = AtomicDataDict.to_device(data, device)
+    inputs = {k: data[k] for k in FIELDS}
+    ref = model(dict(inputs))
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="real")
+    ours = {str(n.target) for n in gm.graph.nodes if n.op == "call_function" and str(n.target).startswith("nequip_amd.")}
+    for op in ("tp_scatter_fwd", "tp_scatter_bwd", "edge_embed_fwd", "edge_embed_bwd", "radial_mlp_fwd", "radial_mlp_bwd",
+               "node_linear", "gate", "gate_bwd"):
+        assert f"nequip_amd.{op}.default" in ours, (op, ours)
+    out = gm(params, buffers, inputs)
+    for k in ("total_energy", "forces", "virial"):
+        torch.testing.assert_close(out[k], ref[k], rtol=1e-5, atol=3e-5 * max(1.0, float(ref[k].abs().max())))
