@@ -196,11 +196,16 @@ def with_edge_vectors_(data: AtomicDataDict.Type, with_lengths: bool = True) -> 
         return data
     pos = data[K.POSITIONS_KEY]
     edge_index = data[K.EDGE_INDEX_KEY]
-    if pos.is_cuda and not traceable():
+    if pos.is_cuda:
         cell = data.get(K.CELL_KEY)
         shift = data[K.EDGE_CELL_SHIFT_KEY].contiguous() if cell is not None else None
         batch = data[K.BATCH_KEY].contiguous() if (cell is not None and K.BATCH_KEY in data) else None
-        edge_vec = _EdgeVectorsFn.apply(pos, cell, edge_index, shift, batch)
+        if traceable():  # the same kernels as dispatcher ops (nn/_edge_vector_ops.py)
+            from ._edge_vector_ops import edge_vectors as _edge_vectors_op
+
+            edge_vec = _edge_vectors_op(pos, cell, edge_index, shift, batch)
+        else:
+            edge_vec = _EdgeVectorsFn.apply(pos, cell, edge_index, shift, batch)
         data[K.EDGE_VECTORS_KEY] = edge_vec
         if with_lengths:
             data[K.EDGE_LENGTH_KEY] = edge_vec.square().sum(1, keepdim=True).sqrt()

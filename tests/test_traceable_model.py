@@ -185,7 +185,7 @@ def test_traced_benchmark_shaped_model_keeps_the_fused_kernels(device):
     gm, params, buffers = trace_model(model, inputs, tracing_mode="real")
     ours = {str(n.target) for n in gm.graph.nodes if n.op == "call_function" and str(n.target).startswith("nequip_amd.")}
     for op in ("tp_scatter_fwd", "tp_scatter_bwd", "edge_embed_fwd", "edge_embed_bwd", "radial_mlp_fwd", "radial_mlp_bwd",
-               "node_linear", "gate", "gate_bwd"):
+               "node_linear", "gate", "gate_bwd", "edge_vectors", "edge_vectors_adj"):
         assert f"nequip_amd.{op}.default" in ours, (op, ours)
     out = gm(params, buffers, inputs)
     for k in ("total_energy", "forces", "virial"):
