@@ -887,6 +887,209 @@ def _emit(st: Structure) -> str:
         A("  }")
         A("}")
 
+    # ------------------------------------------------------------------ pair-centric backward, split by input block
+    # Structures whose two grad_out rows do not fit one wavefront's registers (l_max = 3: 99 values each): every input
+    # block l_1 owns its paths, its output slots, its weight columns and its grad_x components, so the pair kernel splits
+    # over PS wavefronts per (node, channel chunk) with no exchange -- wavefront `part` holds only its blocks' slice of
+    # grad_out[owner] / grad_out[other] / x / w.  Shared by the parts: the two y rows and the pair indices (scalar loads).
+    # grad_y: every part reduces its own partial sums into a [chunk, part] slot of the partial buffer (summed by
+    # spec_gy_reduce_kernel, as the chunk partials are).
+    pair_parts = 1 if pair_ok else 0
+    part_paths: List[List[int]] = []
+    if not pair_ok and os.environ.get("NQA_GEN_PAIR_SPLIT", "1") != "0":
+        by_block = {}
+        for pth, (b_, _, s_) in enumerate(st.instr):
+            by_block.setdefault(b_, []).append(pth)
+
+        def budget(paths):
+            od = sum(2 * st.out_ls[st.instr[p_][2]] + 1 for p_ in paths)
+            xd = sum(2 * st.in1_ls[b_] + 1 for b_ in {st.instr[p_][0] for p_ in paths})
+            return 2 * od + 3 * xd + len(paths)
+
+        # greedy merge of consecutive blocks while a (conservative) register budget holds: the l_max = 3 parts carry 32
+        # grad_y accumulators and up to 49 intermediates per path on top of what `budget` counts (merging l_1 = 0 and 1,
+        # budget 102, spilled 82 registers)
+        for b_ in sorted(by_block):
+            if part_paths and budget(part_paths[-1] + by_block[b_]) <= 70:
+                part_paths[-1] = part_paths[-1] + by_block[b_]
+            else:
+                part_paths.append(list(by_block[b_]))
+        if all(budget(pp) <= 110 for pp in part_paths) and 1 < len(part_paths) <= 8:
+            pair_parts = len(part_paths)
+        else:
+            part_paths = []
+    if pair_parts > 1:
+        PS = pair_parts
+        A(f"constexpr int kPairParts = {PS};")
+        A("template <typename T, bool FULL, bool GX>")
+        A("__global__ __launch_bounds__(256, 2) void bwd_pair_split_kernel(const SpecArgs<T> a) {")
+        A("  const int lane = threadIdx.x & 63;")
+        A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+        A("  const int mul = a.mul;")
+        A("  const int nchunk = (mul + 63) >> 6;")
+        A("  const int64_t item = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+        A("  if (item >= (int64_t)a.N * nchunk * kPairParts) return;")
+        A("  const int node = spec_uniform((int)(item / (nchunk * kPairParts)));")
+        A("  const int rem = (int)(item - (int64_t)node * (nchunk * kPairParts));")
+        A("  const int chunk = spec_uniform(rem / kPairParts);")
+        A("  const int part = spec_uniform(rem - chunk * kPairParts);")
+        A("  const int u = chunk * 64 + lane;")
+        A("  const bool act = FULL || (u < mul);")
+        A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
+        L.extend(lane_offsets("  ", want_x=True, want_g=True))
+        used_any = {b_ for b_, _, _ in st.instr}
+        unused_comps = [i for b in range(NB) if b not in used_any for i in range(xpre[b], xpre[b] + 2 * st.in1_ls[b] + 1)]
+
+        def sp_path(out, pth, xs, gname, ys, tag_):
+            b_, j, s_ = st.instr[pth]
+            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
+            d1, d2, d3 = 2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1
+            C = np.array(wigner_3j(l1, l2, l3), dtype=np.float64)
+            started = [False] * d2
+            gx_terms = []
+            for i in range(d1):
+                a_terms = []
+                for jj in range(d2):
+                    ks = [k for k in range(d3) if C[i, jj, k] != 0.0]
+                    if not ks:
+                        continue
+                    expr = " + ".join(f"T({float(C[i, jj, k])!r}) * {gname}[{opre[s_] + k}]" for k in ks)
+                    out.append(f"          const T t{tag_}{i}_{jj} = {expr};")
+                    if started[jj]:
+                        out.append(f"          B{tag_}{jj} += xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
+                    else:
+                        out.append(f"          T B{tag_}{jj} = xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
+                        started[jj] = True
+                    a_terms.append(f"yb{j}{ys}[{jj}] * t{tag_}{i}_{jj}")
+                gx_terms.append((xpre[b_] + i, " + ".join(a_terms) if a_terms else None))
+            return [jj for jj in range(d2) if started[jj]], gx_terms
+
+        def sp_load_g(ind, rowexpr, name, slots):
+            out = [f"{ind}{{ const T* __restrict__ gb = {rowexpr};"]
+            for s_ in slots:
+                for k in range(2 * st.out_ls[s_] + 1):
+                    out.append(f"{ind}  {name}[{opre[s_] + k}] = spec_at(gb, go{s_})[{k}];")
+            for s_ in slots:
+                for k in range(2 * st.out_ls[s_] + 1):
+                    out.append(f"{ind}  {name}[{opre[s_] + k}] = act ? T({slot_coeff[s_]!r}) * {name}[{opre[s_] + k}] : T(0);")
+            out.append(f"{ind}}}")
+            return out
+
+        def sp_load_x(ind, rowexpr, sfx, blocks):
+            out = []
+            for b in blocks:
+                for i in range(2 * st.in1_ls[b] + 1):
+                    out.append(f"{ind}xb{b}{sfx}[{i}] = spec_at({rowexpr}, xo{b})[{i}];")
+            return out
+
+        A("  switch (part) {")
+        for part_i, paths in enumerate(part_paths):
+            blocks = sorted({st.instr[p_][0] for p_ in paths})
+            slots = sorted({st.instr[p_][2] for p_ in paths})
+            ys = sorted({st.instr[p_][1] for p_ in paths})
+            A(f"    case {part_i}: {{  // input blocks {blocks}: paths {paths}")
+            A("      T gvO[kOD], gvJ[kOD], gxO[kXD], wv[kNP];")
+            for b in blocks:
+                A(f"      T xb{b}O[{2 * st.in1_ls[b] + 1}], xb{b}J[{2 * st.in1_ls[b] + 1}];")
+            for j in ys:
+                A(f"      T yb{j}I[{2 * st.in2_ls[j] + 1}], yb{j}X[{2 * st.in2_ls[j] + 1}];")
+            L.extend(sp_load_g("      ", "a.g + (int64_t)node * a.dout", "gvO", slots))
+            L.extend(sp_load_x("      ", "(a.x + (int64_t)node * a.din)", "O", blocks))
+            for b in blocks:
+                for i in range(2 * st.in1_ls[b] + 1):
+                    A(f"      gxO[{xpre[b] + i}] = T(0);")
+            A("      for (int idx = beg; idx < end; ++idx) {")
+            A("        const int j_ = spec_uniform(a.nbr[idx]), pr = spec_uniform(a.wid[idx]);")
+            A("        const int ei = spec_uniform(a.eid[idx]), eo = spec_uniform(a.eid2[idx]);")
+            A("        const T* __restrict__ xr = a.x + (int64_t)j_ * a.din;")
+            A("        const T* __restrict__ wr = a.w + (int64_t)pr * a.wn;")
+            A("        const T* __restrict__ yi = a.y + (int64_t)ei * kS;")
+            A("        const T* __restrict__ yo = a.y + (int64_t)eo * kS;")
+            for pth in paths:
+                A(f"        wv[{pth}] = *spec_at(wr + (unsigned)(mul * {pth}), ucb);")
+            L.extend(sp_load_x("        ", "xr", "J", blocks))
+            L.extend(sp_load_g("        ", "a.g + (int64_t)j_ * a.dout", "gvJ", slots))
+            for j in ys:
+                for i in range(2 * st.in2_ls[j] + 1):
+                    A(f"        yb{j}I[{i}] = yi[{ypre[j] + i}]; yb{j}X[{i}] = yo[{ypre[j] + i}];")
+            n_t = 0  # owner-side intermediates of this part (one per (path, i, j) with a non-zero 3j row)
+            for p_ in paths:
+                b2, j2, s2 = st.instr[p_]
+                C2 = np.array(wigner_3j(st.in1_ls[b2], st.in2_ls[j2], st.out_ls[s2]))
+                n_t += int((np.abs(C2).sum(axis=2) != 0).sum())
+            nohoist_limit = int(os.environ.get("NQA_GEN_SPLIT_NOHOIST", "64"))  # 0: always hoistable
+            if nohoist_limit and n_t > nohoist_limit:
+                # the owner-side intermediates T_ij = sum_k C_ijk grad_out[owner]_k are the same for all pairs; hoisted out
+                # of the pair loop they are ~150 live values for the l_1 = 3 block (79 spilled registers).  An empty asm
+                # that "modifies" the owner's slots makes them per-pair values.
+                for s_ in slots:
+                    for k in range(2 * st.out_ls[s_] + 1):
+                        A(f"        asm volatile(\"\" : \"+v\"(gvO[{opre[s_] + k}]));")
+            A("        T qI[kS], qX[kS], gxa[kXD];")
+            A("#pragma unroll")
+            A("        for (int j = 0; j < kS; ++j) { qI[j] = T(0); qX[j] = T(0); }")
+            A("        T* __restrict__ gwr_e = a.gw + (int64_t)pr * a.wn;")
+            A("        T* __restrict__ gxr = a.gxe + (int64_t)idx * a.din;")
+            last_of = {st.instr[p_][0]: p_ for p_ in paths}
+            first_of = {}
+            for p_ in paths:
+                first_of.setdefault(st.instr[p_][0], p_)
+            for pth in paths:
+                b_, j, s_ = st.instr[pth]
+                d1 = 2 * st.in1_ls[b_] + 1
+                if first_of[b_] == pth:
+                    for i in range(d1):
+                        A(f"        gxa[{xpre[b_] + i}] = T(0);")
+                A(f"        {{  // path {pth}")
+                body = []
+                live_i, gx_i = sp_path(body, pth, "J", "gvO", "I", "i")
+                for comp, expr in gx_i:
+                    if expr:
+                        body.append(f"          if (GX) gxa[{comp}] += wv[{pth}] * ({expr});")
+                live_x, gx_x = sp_path(body, pth, "O", "gvJ", "X", "x")
+                for comp, expr in gx_x:
+                    if expr:
+                        body.append(f"          if (GX) gxO[{comp}] += wv[{pth}] * ({expr});")
+                terms = [f"yb{j}I[{jj}] * Bi{jj}" for jj in live_i] + [f"yb{j}X[{jj}] * Bx{jj}" for jj in live_x]
+                gw_expr = " + ".join(terms) if terms else "T(0)"
+                body.append(f"          {{ const T r_ = {gw_expr}; if (act) {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'r_')}; }}")
+                for jj in live_i:
+                    body.append(f"          qI[{ypre[j] + jj}] += wv[{pth}] * Bi{jj};")
+                for jj in live_x:
+                    body.append(f"          qX[{ypre[j] + jj}] += wv[{pth}] * Bx{jj};")
+                L.extend(body)
+                A("        }")
+                if last_of[b_] == pth:
+                    A("        if (GX && act) {")
+                    for i in range(d1):
+                        A(f"          {emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')};")
+                    A("        }")
+            if part_i == 0 and unused_comps:
+                A("        if (GX && act) {")
+                for i in unused_comps:
+                    A(f"          *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
+                A("        }")
+            A(f"        spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)ei * a.gy_stride + (chunk * kPairParts + {part_i}) * kS, lane);")
+            A(f"        spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eo * a.gy_stride + (chunk * kPairParts + {part_i}) * kS, lane);")
+            A("      }")
+            A("      if (GX && act) {")
+            A("        T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+            for b in blocks:
+                d = 2 * st.in1_ls[b] + 1
+                for i in range(d):
+                    A(f"        ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = gxO[{xpre[b] + i}];")
+            if part_i == 0:
+                for b in range(NB):
+                    if b not in used_any:
+                        d = 2 * st.in1_ls[b] + 1
+                        for i in range(d):
+                            A(f"        ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = T(0);")
+            A("      }")
+            A("    } break;")
+        A("    default: break;")
+        A("  }")
+        A("}")
+
     # ------------------------------------------------------------------ per-source-node sum of the fused rows
     A("// ACC: add the rows to what a.out already holds (pair-centric backward: the owner-side sums) instead of overwriting")
     A("template <typename T, bool ACC>")
@@ -974,6 +1177,18 @@ def _emit(st: Structure) -> str:
         A("      else hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, false, false>), grid, blk, 0, stream, a);")
         A("    }")
         A("    return 0;")
+    elif pair_parts > 1:
+        A("    if (a.gw == nullptr || a.gy == nullptr || a.eid2 == nullptr || (a.out != nullptr && a.gxe == nullptr)) return 1;")
+        A("    const int64_t witems = items * kPairParts;  // one wavefront per (node, chunk, part)")
+        A("    const dim3 grid((unsigned)((witems + 3) / 4)), blk(256);")
+        A("    if (a.out != nullptr) {")
+        A("      if (full) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true>), grid, blk, 0, stream, a);")
+        A("      else hipLaunchKernelGGL((bwd_pair_split_kernel<float, false, true>), grid, blk, 0, stream, a);")
+        A("    } else {")
+        A("      if (full) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, false>), grid, blk, 0, stream, a);")
+        A("      else hipLaunchKernelGGL((bwd_pair_split_kernel<float, false, false>), grid, blk, 0, stream, a);")
+        A("    }")
+        A("    return 0;")
     else:
         A("    return 1;  // not generated for this structure (register budget)")
     A("  }")
@@ -996,7 +1211,7 @@ def _emit(st: Structure) -> str:
     A("  if (wpn >= 4 && kOD <= 64) return launch<4>(which, a, stream);")
     A("  return launch<1>(which, a, stream);")
     A("}")
-    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {1 if pair_ok else 0});')
+    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {pair_parts});')
     A("}  // namespace")
     A("}  // namespace nqa")
     return "\n".join(L) + "\n"

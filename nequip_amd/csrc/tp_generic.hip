@@ -784,7 +784,7 @@ int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, in
 
 int64_t nqa_tp_bwd_pairs_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges) {
   if (plan == nullptr || num_edges < 0 || (num_edges & 1) || !use_spec(plan, dtype) || !plan->spec->pair) return -1;
-  const int nchunk = (plan->uniform_mul + 63) / 64;
+  const int nchunk = ((plan->uniform_mul + 63) / 64) * plan->spec->pair;  // grad_y partials per edge
   const int64_t ypart = nchunk > 1 ? num_edges * (int64_t)plan->dim_in2 * nchunk * 4 : 0;
   return ((ypart + 255) & ~(int64_t)255) + (num_edges / 2) * (int64_t)plan->dim_in1 * 4;
 }
@@ -816,7 +816,7 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
   hipStream_t s = static_cast<hipStream_t>(stream);
   SpecArgs<float> a{};
   spec_fill(a, plan, num_nodes);
-  const int nchunk = (plan->uniform_mul + 63) / 64;
+  const int nchunk = ((plan->uniform_mul + 63) / 64) * plan->spec->pair;  // grad_y partials per edge
   const int64_t ypart = nchunk > 1 ? num_edges * (int64_t)plan->dim_in2 * nchunk * 4 : 0;
   float* gxe = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((ypart + 255) & ~(int64_t)255));
   a.x = static_cast<const float*>(x);

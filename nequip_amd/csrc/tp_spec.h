@@ -40,7 +40,8 @@ struct SpecEntry {
   std::string key;
   SpecLaunchFn launch;
   int xd, s, od, np;
-  int pair;  // pair-centric backward (which = 4 / 5) generated for this structure
+  int pair;  // pair-centric backward (which = 4 / 5): 0 not generated, 1 one wavefront per (node, chunk), n > 1 split
+             // over n wavefronts by input block (grad_y partials: nchunk * n per edge)
   SpecEntry* next;
 };
 
