@@ -663,7 +663,10 @@ def _emit(st: Structure) -> str:
     pair_lb = "__launch_bounds__(256)" if big else f"__launch_bounds__(256, {pair_occ})"
     if pair_ok:
         A("// GX = false: grad_w (summed over the pair) and grad_y only -- layers whose grad_x is not needed or comes from bwd_x")
-        A("template <typename T, int WPN, bool FULL, bool GX>")
+        A("// DUAL (with GX = false; second-order backward of training): two operand sets in one pass,")
+        A("//   grad_w = Bw(x2, y, g) + Bw(x, y2, g),  grad_y = By(x2, w, g)   (x2 = a.x2, y2 = a.y2: the cotangents of grad_x /")
+        A("//   grad_y of the first-order backward) -- the intermediate T_ij = sum_k C_ijk g_k serves both products")
+        A("template <typename T, int WPN, bool FULL, bool GX, bool DUAL = false>")
         A(f"__global__ {pair_lb} void bwd_pair_kernel(const SpecArgs<T> a) {{")
         A("  const int lane = threadIdx.x & 63;")
         A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -701,6 +704,10 @@ def _emit(st: Structure) -> str:
         A("  T gvO[kOD], gxO[kXD];")
         L.extend(load_g("  ", "a.g + (int64_t)node * a.dout", "gvO"))
         L.extend(load_x("  ", "(a.x + (int64_t)node * a.din)", sfx="O"))
+        L.extend(decl_x("  ", "O2"))
+        A("  if (DUAL) {")
+        L.extend(load_x("    ", "(a.x2 + (int64_t)node * a.din)", sfx="O2", decl=False))
+        A("  }")
         A("#pragma unroll")
         A("  for (int i = 0; i < kXD; ++i) gxO[i] = T(0);")
 
@@ -722,10 +729,14 @@ def _emit(st: Structure) -> str:
                         continue
                     expr = " + ".join(f"T({float(C[i, jj, k])!r}) * {gname}[{opre[s_] + k}]" for k in ks)
                     out.append(f"        const T t{tag_}{i}_{jj} = {expr};")
+                    # DUAL: B from the cotangent rows x2 (pairs with y and w), D from x (pairs with y2)
+                    xa = f"(DUAL ? xb{b_}{xs}2[{i}] : xb{b_}{xs}[{i}])"
                     if started[jj]:
-                        out.append(f"        B{tag_}{jj} += xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
+                        out.append(f"        B{tag_}{jj} += {xa} * t{tag_}{i}_{jj};")
+                        out.append(f"        if (DUAL) D{tag_}{jj} += xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
                     else:
-                        out.append(f"        T B{tag_}{jj} = xb{b_}{xs}[{i}] * t{tag_}{i}_{jj};")
+                        out.append(f"        T B{tag_}{jj} = {xa} * t{tag_}{i}_{jj};")
+                        out.append(f"        T D{tag_}{jj} = DUAL ? xb{b_}{xs}[{i}] * t{tag_}{i}_{jj} : T(0);")
                         started[jj] = True
                     a_terms.append(f"yb{j}{ys}[{jj}] * t{tag_}{i}_{jj}")
                 gx_terms.append((xpre[b_] + i, " + ".join(a_terms) if a_terms else None))
@@ -747,6 +758,11 @@ def _emit(st: Structure) -> str:
                 out += load_g("      ", f"a.g + (int64_t)jn{sfx} * a.dout", "gvJ")
             out += load_y("      ", "yi", sfx="I" + sfx, decl=False)
             out += load_y("      ", "yo", sfx="X" + sfx, decl=False)
+            out.append("      if (DUAL) {")
+            out += load_x("        ", f"(a.x2 + (int64_t)jn{sfx} * a.din)", sfx="J" + sfx + "2", decl=False)
+            out += load_y("        ", f"(a.y2 + (int64_t)ei{sfx} * kS)", sfx="I" + sfx + "2", decl=False)
+            out += load_y("        ", f"(a.y2 + (int64_t)eo{sfx} * kS)", sfx="X" + sfx + "2", decl=False)
+            out.append("      }")
             out.append("    }")
             return out
 
@@ -755,7 +771,8 @@ def _emit(st: Structure) -> str:
 
         def pair_decls(sfx):
             return ([f"  T wv{sfx}[kNP];", f"  int jn{sfx} = 0, pr{sfx} = 0, ei{sfx} = 0, eo{sfx} = 0;"]
-                    + decl_x("  ", "J" + sfx) + decl_y("  ", "I" + sfx) + decl_y("  ", "X" + sfx))
+                    + decl_x("  ", "J" + sfx) + decl_y("  ", "I" + sfx) + decl_y("  ", "X" + sfx)
+                    + decl_x("  ", "J" + sfx + "2") + decl_y("  ", "I" + sfx + "2") + decl_y("  ", "X" + sfx + "2"))
 
         def pair_compute(sfx, slot):
             out = ["    {"]
@@ -788,7 +805,9 @@ def _emit(st: Structure) -> str:
                         out.append(f"        if (GX) gxO[{comp}] += wv{sfx}[{pth}] * ({expr});")
                 terms = [f"yb{j}I{sfx}[{jj}] * Bi{jj}" for jj in live_i] + [f"yb{j}X{sfx}[{jj}] * Bx{jj}" for jj in live_x]
                 gw_expr = " + ".join(terms) if terms else "T(0)"
-                out.append(f"        {{ const T r_ = {gw_expr}; if (act) {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'r_')}; }}")
+                dterms = [f"yb{j}I{sfx}2[{jj}] * Di{jj}" for jj in live_i] + [f"yb{j}X{sfx}2[{jj}] * Dx{jj}" for jj in live_x]
+                dual_expr = " + ".join(dterms) if dterms else "T(0)"
+                out.append(f"        {{ T r_ = {gw_expr}; if (DUAL) r_ += {dual_expr}; if (act) {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'r_')}; }}")
                 for jj in live_i:
                     out.append(f"        qI[{ypre[j] + jj}] += wv{sfx}[{pth}] * Bi{jj};")
                 for jj in live_x:
@@ -1191,6 +1210,16 @@ def _emit(st: Structure) -> str:
         A("    return 0;")
     else:
         A("    return 1;  // not generated for this structure (register budget)")
+    A("  }")
+    A("  if (which == 6) {  // dual pair-centric edge gradients (second-order backward), see bwd_pair_kernel<DUAL>")
+    if pair_ok:
+        A("    if (a.gw == nullptr || a.gy == nullptr || a.eid2 == nullptr || a.x2 == nullptr || a.y2 == nullptr) return 1;")
+        A("    const dim3 grid((unsigned)((items * WPN + 3) / 4)), blk(256);")
+        A("    if (full) hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, true, false, true>), grid, blk, 0, stream, a);")
+        A("    else hipLaunchKernelGGL((bwd_pair_kernel<float, WPN, false, false, true>), grid, blk, 0, stream, a);")
+        A("    return 0;")
+    else:
+        A("    return 1;")
     A("  }")
     A("  if (which == 5) {  // grad_x += rows of the pairs in which the node is not the owner")
     A("    hipLaunchKernelGGL((gx_rows_sum_kernel<float, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);")

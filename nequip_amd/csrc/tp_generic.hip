@@ -863,5 +863,73 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
   return check_launch("nqa_tp_scatter_bwd_pairs(sum)");
 }
 
+int32_t nqa_tp_bwd_pairs_dual_supported(const nqa_plan* plan, int32_t dtype) {
+  return (plan != nullptr && use_spec(plan, dtype) && plan->spec->pair == 1) ? 1 : 0;
+}
+
+int nqa_tp_scatter_bwd_pairs_dual(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
+                                  const void* x_cot, const void* y, const void* y_cot, const void* w,
+                                  const void* grad_out, const int32_t* owner_rowptr, const int32_t* pair_other,
+                                  const int32_t* pair_row, const int32_t* pair_edge_in, const int32_t* pair_edge_out,
+                                  void* grad_w, void* grad_y, void* workspace, int64_t workspace_bytes,
+                                  int64_t num_nodes, int64_t num_edges, nqa_stream stream) {
+  int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_pairs_dual");
+  if (rc != NQA_OK) return rc;
+  if (!nqa_tp_bwd_pairs_dual_supported(plan, dtype) || (num_edges & 1)) {
+    set_error("nqa_tp_scatter_bwd_pairs_dual: no dual pair-centric kernel for this plan (or an odd edge count)");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  const int64_t need = nqa_tp_bwd_pairs_workspace_bytes(plan, dtype, num_edges);
+  if ((num_nodes > 0 && !owner_rowptr) ||
+      (num_edges > 0 && (!x || !x_cot || !y || !y_cot || !w || !grad_out || !pair_other || !pair_row || !pair_edge_in ||
+                         !pair_edge_out || !grad_w || !grad_y))) {
+    set_error("nqa_tp_scatter_bwd_pairs_dual: NULL operand");
+    return NQA_ERR_INVALID;
+  }
+  if (num_edges > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("nqa_tp_scatter_bwd_pairs_dual: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  if (num_nodes == 0 || num_edges == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SpecArgs<float> a{};
+  spec_fill(a, plan, num_nodes);
+  const int nchunk = (plan->uniform_mul + 63) / 64;
+  a.x = static_cast<const float*>(x);
+  a.x2 = static_cast<const float*>(x_cot);
+  a.y = static_cast<const float*>(y);
+  a.y2 = static_cast<const float*>(y_cot);
+  a.w = static_cast<const float*>(w);
+  a.g = static_cast<const float*>(grad_out);
+  a.gw = static_cast<float*>(grad_w);
+  a.rowptr = owner_rowptr;
+  a.nbr = pair_other;
+  a.wid = pair_row;
+  a.eid = pair_edge_in;
+  a.eid2 = pair_edge_out;
+  a.wP = 2147483647;
+  if (nchunk == 1) {
+    a.gy = static_cast<float*>(grad_y);
+    a.gy_stride = plan->dim_in2;
+  } else {
+    a.gy = static_cast<float*>(workspace);
+    a.gy_stride = plan->dim_in2 * nchunk;
+  }
+  if (plan->spec->launch(6, spec_wpn(plan, num_nodes), a, s) != 0) {
+    set_error("nqa_tp_scatter_bwd_pairs_dual: kernel not available");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  rc = check_launch("nqa_tp_scatter_bwd_pairs_dual");
+  if (rc != NQA_OK) return rc;
+  if (nchunk > 1) {
+    const int64_t total = num_edges * (int64_t)plan->dim_in2;
+    hipLaunchKernelGGL(spec_gy_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), static_cast<float*>(grad_y), plan->dim_in2, nchunk, total);
+    rc = check_launch("nqa_tp_scatter_bwd_pairs_dual(reduce)");
+  }
+  return rc;
+}
+
 }  // extern "C"
+
 

@@ -220,6 +220,35 @@ class _Kernels:
         _lib.check(rc, "nqa_tp_scatter_bwd_pairs")
         return gx, gw, gy
 
+    def has_dual_pairs_kernel(self, dtype: torch.dtype) -> bool:
+        cache = self.__dict__.setdefault("_has_dual", {})
+        if dtype not in cache:
+            cache[dtype] = bool(_lib.load().nqa_tp_bwd_pairs_dual_supported(self.plan.handle, _nqa_dtype(dtype)))
+        return cache[dtype]
+
+    def edge_grads_dual(self, x, x_cot, y, y_cot, w, g, topo: EdgeTopology, pairing):
+        """``(Bw(x_cot, y, g) + Bw(x, y_cot, g), By(x_cot, w, g))`` in one pair-centric pass
+        (``nqa_tp_scatter_bwd_pairs_dual``): the two weight-gradient terms of the second-order backward, summed over the
+        directed edges of every pair."""
+        lib = _lib.load()
+        E, N = topo.num_edges, topo.num_nodes
+        self._check(x, y, w, topo, pairing)
+        ws_bytes = lib.nqa_tp_bwd_pairs_workspace_bytes(self.plan.handle, _nqa_dtype(x.dtype), E)
+        gw = torch.empty((pairing.num_pairs, self.weight_numel), dtype=x.dtype, device=x.device)
+        gy = torch.empty((E, self.dim_in2), dtype=x.dtype, device=x.device)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        orow, oth, prow, ein, eout, _, _ = pairing.owner_csr
+        es = x.element_size()
+        nbytes = E * (es * (2 * self.weight_numel + 3 * self.dim_in2) + 16) + N * es * (2 * self.dim_in1 + self.dim_out)
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_edge", nbytes):
+            rc = lib.nqa_tp_scatter_bwd_pairs_dual(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(x_cot), _ptr(y), _ptr(y_cot),
+                _ptr(w), _ptr(g), _ptr(orow), _ptr(oth), _ptr(prow), _ptr(ein), _ptr(eout), _ptr(gw), _ptr(gy),
+                _ptr(ws), ws_bytes, N, E, current_stream_ptr(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_bwd_pairs_dual")
+        return gw, gy
+
     def use_pairs(self, dtype: torch.dtype, pairing) -> bool:
         """Pair-centric backward applicable (paired weights, kernel generated for this structure, not switched off)?"""
         return (pairing is not None and os.environ.get("NQA_NO_PAIR_BWD", "") in ("", "0")
@@ -339,7 +368,12 @@ class _TPScatterBwdFn(torch.autograd.Function):
                 gxx = add(gxx, k.bwd_x(c_y, w, g, topo, pr))
             if c_w is not None:
                 gxx = add(gxx, k.bwd_x(y, c_w, g, topo, pr))
-        if need_w and c_x is not None and c_y is not None and k.use_pairs(x.dtype, pr):
+        if (need_w and c_x is not None and c_y is not None and k.use_pairs(x.dtype, pr)
+                and k.has_dual_pairs_kernel(x.dtype) and os.environ.get("NQA_NO_DUAL_PAIR_BWD", "") in ("", "0")):
+            # both weight-gradient terms (and By(c_x, w, g)) in one pair-centric pass over the shared intermediate
+            gww, a_y = k.edge_grads_dual(x, c_x, y, c_y, w, g, topo, pr)
+            gyy = add(gyy, a_y if need_y else None)
+        elif need_w and c_x is not None and c_y is not None and k.use_pairs(x.dtype, pr):
             # pair-centric kernels: both contributions arrive summed over the directed edges of every pair
             a_w1, a_y = k.edge_grads_folded(c_x, y, w, g, topo, pr, need_gw=True, need_gy=need_y)
             a_w2, _ = k.edge_grads_folded(x, c_y, w, g, topo, pr, need_gw=True, need_gy=False)

@@ -149,6 +149,15 @@ def test_spec_kernels_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul):
             _close(rgx, px, f"bwd_pairs gx {tag}")
             _close(rgw_pairs, pw, f"bwd_pairs gw {tag}")
             _close(rgy, py, f"bwd_pairs gy {tag}")
+            if k.has_dual_pairs_kernel(torch.float32):
+                # dual pass of the second-order backward: Bw(x2, y, g) + Bw(x, y2, g) and By(x2, w, g)
+                x2d = d(torch.randn(N, k.dim_in1, generator=g))
+                y2d = d(torch.randn(E, k.dim_in2, generator=g))
+                _, w_a, y_a = k.bwd_pairs(x2d, yd, wd, god, topo, pr, need_gx=False)
+                _, w_b, _ = k.bwd_pairs(xd, y2d, wd, god, topo, pr, need_gx=False)
+                dw, dy = k.edge_grads_dual(xd, x2d, yd, y2d, wd, god, topo, pr)
+                _close((w_a + w_b).cpu(), dw, f"dual gw {tag}")
+                _close(y_a.cpu(), dy, f"dual gy {tag}")
             none_x, pw2, py2 = k.bwd_pairs(xd, yd, wd, god, topo, pr, need_gx=False)  # the edge gradients only
             assert none_x is None
             _close(rgw_pairs, pw2, f"bwd_pairs<no gx> gw {tag}")
