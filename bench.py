@@ -328,7 +328,11 @@ def train_bench(args, world, rank, device, distributed):
         avg_num_neighbors=n_edges / n_atoms, per_type_energy_scales=1.0, per_type_energy_shifts=0.0,
     ).to(device).train()
     strategy = SimpleDDPStrategy(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    # hipGraph replay of the whole optimizer step (forward, double backward, Adam) on one rank: the eager step is bound by
+    # the host (8.9 ms of Python / launch work to enqueue 7.2 ms of kernels, scripts/r2_train_cpu_bound.py).  Multi-rank
+    # runs stay eager (the gradient all-reduce is issued by the strategy between backward and the optimizer).
+    use_graph = (not distributed) and os.environ.get("NQA_TRAIN_GRAPH", "1") not in ("", "0")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=use_graph)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -341,12 +345,41 @@ def train_bench(args, world, rank, device, distributed):
 
     for _ in range(max(args.warmup, 1)):
         step()
+    graph = None
+    launch = "eager"
+    if use_graph:
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = "hipGraph replay of the whole optimizer step"
+        except Exception as exc:  # capture not possible in this configuration: time the eager step
+            print(f"[bench] training-step graph capture failed ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def timed_step():
+        if graph is not None:
+            graph.replay()
+            return static_loss
+        return step()
+
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = timed_step()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -376,7 +409,7 @@ def train_bench(args, world, rank, device, distributed):
             "config": {"workload": f"{args.workload}: {w['batch']} frames x {w['n_atoms']} atoms per rank "
                        f"({n_edges} edges), {w['n_species']} species, l_max={w['l_max']}, {w['num_features']} features, "
                        "energy+force MSE loss, Adam, flat gradient all-reduce (SimpleDDP)",
-                       "parallelism": f"dp{world}", "final_loss": float(loss),
+                       "parallelism": f"dp{world}", "final_loss": float(loss.detach()), "launch": launch,
                        "collective": ("RCCL all-reduce of one flat fp32 gradient buffer per step" if distributed else "none (1 rank)")},
             "roofline": roofline, "step_roofline": step_roofline,
             "kernels_ms_per_step": {k: v["total_ms"] / max(args.kernel_steps, 1) for k, v in kernels.items()},

@@ -466,6 +466,18 @@ int nqa_tp_scatter_bwd_pairs_dual(const nqa_plan* plan, const void* plan_image, 
                                   void* grad_w, void* grad_y, void* workspace, int64_t workspace_bytes,
                                   int64_t num_nodes, int64_t num_edges, nqa_stream stream);
 
+/* Forward-mode companion of the same second-order backward: the gradient w.r.t. grad_out of <cotangents, backward outputs>,
+ *   out = F(x_cot, y, w) + F(x, y_cot, w) + F(x, y, w_cot)      (F = nqa_tp_scatter_fwd; the op is trilinear)
+ *   in one pass over the edges instead of three forward launches and two additions.  A NULL cotangent drops its term (at
+ *   least one is required); w / w_cot hold one row per edge, or per pair when weight_rows (dst-CSR slot order, as
+ *   nqa_tp_scatter_fwd_paired) is given.  Structure-specialised float32 plans (nqa_tp_fwd_jvp_supported). */
+int32_t nqa_tp_fwd_jvp_supported(const nqa_plan* plan, int32_t dtype);
+int nqa_tp_scatter_fwd_jvp(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                           const void* w, const void* x_cot, const void* y_cot, const void* w_cot,
+                           const int32_t* rowptr_dst, const int32_t* edge_id_dst, const int32_t* src_sorted, void* out,
+                           int64_t num_nodes, int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs,
+                           nqa_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Parameter gradients of the dense maps of the path (training; in the reference these come out of autograd as the
  *   weight-side `mm` / `einsum` backward of ScalarLinearLayer.forward (nequip/nn/mlp.py:262-268), e3nn o3.Linear

@@ -130,6 +130,12 @@ SIGNATURES = {
         + [c_void_p] * 7  # owner_rowptr, pair_other, pair_row, pair_edge_in, pair_edge_out, other_rowptr, other_slot
         + [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p],
     ),
+    "nqa_tp_fwd_jvp_supported": (c_int32, [c_void_p, c_int32]),
+    "nqa_tp_scatter_fwd_jvp": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32] + [c_void_p] * 6  # plan, image, dtype, x, y, w, x_cot, y_cot, w_cot
+        + [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
     "nqa_tp_bwd_pairs_dual_supported": (c_int32, [c_void_p, c_int32]),
     "nqa_tp_scatter_bwd_pairs_dual": (
         c_int32,

@@ -201,7 +201,9 @@ def _emit(st: Structure) -> str:
         return out
 
     # ------------------------------------------------------------------ forward
-    A("template <typename T, int WPN>")
+    A("// JVP (second-order backward of training: the gradient w.r.t. grad_out): out = F(x2, y, w) + F(x, y2, w) + F(x, y, w2) in")
+    A("// one pass over the edges; a term whose cotangent pointer (a.x2 / a.y2 / a.w2) is NULL is skipped (wave-uniform).")
+    A("template <typename T, int WPN, bool JVP = false>")
     # (four wavefronts per SIMD would need 128 registers: 19-48 spills in the pipelined loop, measured 2.2x slower)
     A(f"__global__ {lb} void fwd_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
@@ -229,8 +231,10 @@ def _emit(st: Structure) -> str:
         A("  // Two register sets (A/B): the operands of edge i+1 are requested before edge i is evaluated, the indices of")
         A("  // edge i+2 before that -- every HBM/L2 round trip of an edge hides behind the arithmetic of the previous one.")
         L.extend(["  T wvA[kNP], wvB[kNP];"] + decl_x("  ", "A") + decl_x("  ", "B") + decl_y("  ", "A") + decl_y("  ", "B"))
+        L.extend(["  T wv2A[kNP], wv2B[kNP];"] + decl_x("  ", "A2") + decl_x("  ", "B2") + decl_y("  ", "A2") + decl_y("  ", "B2"))
     else:
         L.extend(["  T wvA[kNP];"] + decl_x("  ", "A") + decl_y("  ", "A"))
+        L.extend(["  T wv2A[kNP];"] + decl_x("  ", "A2") + decl_y("  ", "A2"))
 
     def fwd_loads(sfx, e, sv, r):
         out = [f"    {{ const T* __restrict__ xr = a.x + (int64_t){sv} * a.din;",
@@ -239,6 +243,17 @@ def _emit(st: Structure) -> str:
         out += load_w("      ", "wr", sfx=sfx, decl=False)
         out += load_x("      ", "xr", sfx=sfx, decl=False)
         out += load_y("      ", "yr", sfx=sfx, decl=False)
+        out.append("      if (JVP) {")
+        out.append("        if (a.x2 != nullptr) {")
+        out += load_x("          ", f"(a.x2 + (int64_t){sv} * a.din)", sfx=sfx + "2", decl=False)
+        out.append("        }")
+        out.append("        if (a.y2 != nullptr) {")
+        out += load_y("          ", f"(a.y2 + (int64_t){e} * kS)", sfx=sfx + "2", decl=False)
+        out.append("        }")
+        out.append("        if (a.w2 != nullptr) {")
+        out += load_w("          ", f"(a.w2 + (int64_t){r} * a.wn)", sfx="2" + sfx, decl=False)
+        out.append("        }")
+        out.append("      }")
         out.append("    }")
         return out
 
@@ -247,9 +262,18 @@ def _emit(st: Structure) -> str:
         for p, (b, j, sl) in enumerate(st.instr):
             l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[sl]
             d3 = 2 * l3 + 1
-            out.append(f"    {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}{sfx}, yb{j}{sfx}, t);")
+            out.append("    if (!JVP) {")
+            out.append(f"      T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>(xb{b}{sfx}, yb{j}{sfx}, t);")
             for k in range(d3):
                 out.append(f"      acc[{opre[sl] + k}] += wv{sfx}[{p}] * t[{k}];")
+            out.append("    } else {")
+            for cond, xa, ya, wa in ((f"a.w2 != nullptr", f"xb{b}{sfx}", f"yb{j}{sfx}", f"wv2{sfx}[{p}]"),
+                                     (f"a.x2 != nullptr", f"xb{b}{sfx}2", f"yb{j}{sfx}", f"wv{sfx}[{p}]"),
+                                     (f"a.y2 != nullptr", f"xb{b}{sfx}", f"yb{j}{sfx}2", f"wv{sfx}[{p}]")):
+                out.append(f"      if ({cond}) {{ T t[{d3}]; CGT<{l1},{l2},{l3}>::template ab_c<T>({xa}, {ya}, t);")
+                for k in range(d3):
+                    out.append(f"        acc[{opre[sl] + k}] += {wa} * t[{k}];")
+                out.append("      }")
             out.append("    }")
         return out
 
@@ -1211,6 +1235,12 @@ def _emit(st: Structure) -> str:
     else:
         A("    return 1;  // not generated for this structure (register budget)")
     A("  }")
+    A("  if (which == 7) {  // forward JVP (second-order backward): out = F(x2, y, w) + F(x, y2, w) + F(x, y, w2)")
+    A("    const int64_t blocks7 = WPN == 1 ? (items + 3) / 4 : items;")
+    A("    const size_t smem7 = WPN > 1 ? (size_t)(WPN - 1) * kOD * 64 * sizeof(float) : 0;")
+    A("    hipLaunchKernelGGL((fwd_kernel<float, WPN, true>), dim3((unsigned)blocks7), dim3(256), smem7, stream, a);")
+    A("    return 0;")
+    A("  }")
     A("  if (which == 6) {  // dual pair-centric edge gradients (second-order backward), see bwd_pair_kernel<DUAL>")
     if pair_ok:
         A("    if (a.gw == nullptr || a.gy == nullptr || a.eid2 == nullptr || a.x2 == nullptr || a.y2 == nullptr) return 1;")
@@ -1228,7 +1258,7 @@ def _emit(st: Structure) -> str:
     A("  const int64_t blocks = WPN == 1 ? (items + 3) / 4 : items;")
     A("  if (which == 0) {")
     A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kOD * 64 * sizeof(float) : 0;")
-    A("    hipLaunchKernelGGL((fwd_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
+    A("    hipLaunchKernelGGL((fwd_kernel<float, WPN, false>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
     A("  } else {")
     A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kXD * 64 * sizeof(float) : 0;")
     A("    hipLaunchKernelGGL((bwd_x_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")

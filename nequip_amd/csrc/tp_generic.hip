@@ -930,6 +930,48 @@ int nqa_tp_scatter_bwd_pairs_dual(const nqa_plan* plan, const void* plan_image, 
   return rc;
 }
 
+int32_t nqa_tp_fwd_jvp_supported(const nqa_plan* plan, int32_t dtype) {
+  return (plan != nullptr && use_spec(plan, dtype)) ? 1 : 0;
+}
+
+int nqa_tp_scatter_fwd_jvp(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
+                           const void* w, const void* x_cot, const void* y_cot, const void* w_cot,
+                           const int32_t* rowptr_dst, const int32_t* edge_id_dst, const int32_t* src_sorted, void* out,
+                           int64_t num_nodes, int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs,
+                           nqa_stream stream) {
+  int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_fwd_jvp");
+  if (rc != NQA_OK) return rc;
+  if (!use_spec(plan, dtype)) {
+    set_error("nqa_tp_scatter_fwd_jvp: no structure-specialised float32 kernel for this plan");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (num_nodes < 0 || num_edges < 0 || (num_nodes > 0 && (!out || !rowptr_dst)) ||
+      (num_edges > 0 && (!x || !y || !w || !edge_id_dst || !src_sorted)) || (!x_cot && !y_cot && !w_cot) ||
+      (weight_rows != nullptr && (num_pairs <= 0 || num_pairs > 1073741823))) {
+    set_error("nqa_tp_scatter_fwd_jvp: NULL operand (at least one cotangent is required)");
+    return NQA_ERR_INVALID;
+  }
+  if (num_nodes == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SpecArgs<float> a{};
+  spec_fill(a, plan, num_nodes);
+  a.x = static_cast<const float*>(x);
+  a.y = static_cast<const float*>(y);
+  a.w = static_cast<const float*>(w);
+  a.x2 = static_cast<const float*>(x_cot);
+  a.y2 = static_cast<const float*>(y_cot);
+  a.w2 = static_cast<const float*>(w_cot);
+  a.out = static_cast<float*>(out);
+  a.rowptr = rowptr_dst;
+  a.eid = edge_id_dst;
+  a.nbr = src_sorted;
+  a.wid = weight_rows ? weight_rows : edge_id_dst;
+  a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
+  plan->spec->launch(7, spec_wpn(plan, num_nodes), a, s);
+  return check_launch("nqa_tp_scatter_fwd_jvp");
+}
+
 }  // extern "C"
+
 
 

@@ -13,6 +13,7 @@ struct SpecArgs {
   const T* __restrict__ x;   // [N, din]        (fwd, bwd_edge)
   const T* __restrict__ x2;  // [N, din] / y2 [E, S]: second operand set of the dual pair kernel (which = 6)
   const T* __restrict__ y2;
+  const T* __restrict__ w2;  // forward JVP (which = 7): cotangent of the weights, rows as w
   const T* __restrict__ y;   // [E, S]
   const T* __restrict__ w;   // [E, wn]
   const T* __restrict__ g;   // [N, dout]       (bwd_edge, bwd_x)
@@ -35,7 +36,7 @@ struct SpecArgs {
 };
 
 // which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows,
-// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows, 6 = dual pair-centric edge gradients;  wpn: requested wavefronts per (node, chunk)
+// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows, 6 = dual pair-centric edge gradients, 7 = forward JVP;  wpn: requested wavefronts per (node, chunk)
 using SpecLaunchFn = int (*)(int which, int wpn, const SpecArgs<float>& a, hipStream_t stream);
 
 struct SpecEntry {

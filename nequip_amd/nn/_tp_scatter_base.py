@@ -18,6 +18,7 @@ three kernels.
 
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -220,6 +221,34 @@ class _Kernels:
         _lib.check(rc, "nqa_tp_scatter_bwd_pairs")
         return gx, gw, gy
 
+    def has_fwd_jvp(self, dtype: torch.dtype) -> bool:
+        cache = self.__dict__.setdefault("_has_jvp", {})
+        if dtype not in cache:
+            cache[dtype] = bool(_lib.load().nqa_tp_fwd_jvp_supported(self.plan.handle, _nqa_dtype(dtype)))
+        return cache[dtype]
+
+    def fwd_jvp(self, x, y, w, c_x, c_y, c_w, topo: EdgeTopology, pairing=None) -> torch.Tensor:
+        """``F(c_x, y, w) + F(x, c_y, w) + F(x, y, c_w)`` in one pass (``nqa_tp_scatter_fwd_jvp``); a cotangent that is
+        None drops its term."""
+        self._check(x, y, w, topo, pairing)
+        lib = _lib.load()
+        out = torch.empty((topo.num_nodes, self.dim_out), dtype=x.dtype, device=x.device)
+        rowptr, eid, nbr = topo.by_dst
+        es = x.element_size()
+        nterms = sum(t is not None for t in (c_x, c_y, c_w))
+        nbytes = topo.num_edges * (es * (self.weight_numel * (2 if c_w is not None else 1) + 2 * self.dim_in2) + 16) + \
+            topo.num_nodes * es * (2 * self.dim_in1 + self.dim_out)
+        with torch.cuda.device(x.device), ktimer.region("tp_fwd", nbytes):
+            rc = lib.nqa_tp_scatter_fwd_jvp(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(c_x), _ptr(c_y),
+                _ptr(c_w), _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(out), topo.num_nodes, topo.num_edges,
+                _ptr(pairing.slots_dst) if pairing is not None else ctypes.c_void_p(),
+                pairing.num_pairs if pairing is not None else 0, current_stream_ptr(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_fwd_jvp")
+        assert nterms > 0
+        return out
+
     def has_dual_pairs_kernel(self, dtype: torch.dtype) -> bool:
         cache = self.__dict__.setdefault("_has_dual", {})
         if dtype not in cache:
@@ -356,7 +385,10 @@ class _TPScatterBwdFn(torch.autograd.Function):
             return b if a is None else (a if b is None else a + b)
 
         gg = gxx = gyy = gww = None
-        if need_g:
+        if need_g and sum(t is not None for t in (c_x, c_y, c_w)) > 1 and k.has_fwd_jvp(x.dtype) and \
+                os.environ.get("NQA_NO_FWD_JVP", "") in ("", "0"):
+            gg = k.fwd_jvp(x, y, w, c_x, c_y, c_w, topo, pr)  # the three terms in one pass
+        elif need_g:
             if c_x is not None:
                 gg = add(gg, k.fwd(c_x, y, w, topo, pr))
             if c_y is not None:

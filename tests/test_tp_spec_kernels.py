@@ -142,6 +142,14 @@ def test_spec_kernels_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul):
         _close(rgx, fx, f"bwd_fused gx {tag}")
         _close(rgw, fw, f"bwd_fused gw {tag}")
         _close(rgy, fy, f"bwd_fused gy {tag}")
+        # forward JVP (second-order backward): the three bilinear terms in one pass, and every subset of them
+        xc, yc = d(torch.randn(N, k.dim_in1, generator=g)), d(torch.randn(E, k.dim_in2, generator=g))
+        wc = d(torch.randn(wd.shape, generator=g))
+        for cx_, cy_, cw_ in ((xc, yc, wc), (xc, yc, None), (None, yc, wc), (xc, None, None)):
+            want = sum(t for t in ((k.fwd(cx_, yd, wd, topo, pr) if cx_ is not None else None),
+                                   (k.fwd(xd, cy_, wd, topo, pr) if cy_ is not None else None),
+                                   (k.fwd(xd, yd, cw_, topo, pr) if cw_ is not None else None)) if t is not None)
+            _close(want.cpu(), k.fwd_jvp(xd, yd, wd, cx_, cy_, cw_, topo, pr), f"fwd_jvp {tag}")
         if symmetric and k.has_pairs_kernel(torch.float32):
             # pair-centric backward: grad_w comes out summed over the two directed edges of every pair
             px, pw, py = k.bwd_pairs(xd, yd, wd, god, topo, pr)
