@@ -477,6 +477,12 @@ int nqa_tp_scatter_fwd_jvp(const nqa_plan* plan, const void* plan_image, int32_t
                            const int32_t* rowptr_dst, const int32_t* edge_id_dst, const int32_t* src_sorted, void* out,
                            int64_t num_nodes, int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs,
                            nqa_stream stream);
+/* ... and the gradient w.r.t. x:  grad_x = Bx(y_cot, w, grad_out) + Bx(y, w_cot, grad_out)  in one pass over the source
+ *   CSR (operands as nqa_tp_scatter_bwd_x / _paired; plans for which nqa_tp_fwd_jvp_supported holds). */
+int nqa_tp_scatter_bwd_x_dual(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
+                              const void* y_cot, const void* w_cot, const void* grad_out, const int32_t* rowptr_src,
+                              const int32_t* edge_id_src, const int32_t* dst_sorted, void* grad_x, int64_t num_nodes,
+                              int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Parameter gradients of the dense maps of the path (training; in the reference these come out of autograd as the

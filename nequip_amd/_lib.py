@@ -136,6 +136,11 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int32] + [c_void_p] * 6  # plan, image, dtype, x, y, w, x_cot, y_cot, w_cot
         + [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
     ),
+    "nqa_tp_scatter_bwd_x_dual": (
+        c_int32,
+        [c_void_p, c_void_p, c_int32] + [c_void_p] * 5  # plan, image, dtype, y, w, y_cot, w_cot, grad_out
+        + [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p],
+    ),
     "nqa_tp_bwd_pairs_dual_supported": (c_int32, [c_void_p, c_int32]),
     "nqa_tp_scatter_bwd_pairs_dual": (
         c_int32,

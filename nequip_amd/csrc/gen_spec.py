@@ -596,7 +596,8 @@ def _emit(st: Structure) -> str:
     A("}")
 
     # ------------------------------------------------------------------ backward (node features)
-    A("template <typename T, int WPN>")
+    A("// DUAL (second-order backward of training): out = Bx(y2, w, g) + Bx(y, w2, g) in one pass (a.y2 / a.w2 = the cotangents)")
+    A("template <typename T, int WPN, bool DUAL = false>")
     A(f"__global__ {lb} void bwd_x_kernel(const SpecArgs<T> a) {{")
     A("  const int lane = threadIdx.x & 63;")
     A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -627,6 +628,12 @@ def _emit(st: Structure) -> str:
     A("    const T* __restrict__ wr = a.w + (int64_t)r * a.wn;")
     A("    const T* __restrict__ yr = a.y + (int64_t)e * kS;")
     L.extend(load_w("    ", "wr", scale=True))
+    A("    T wv2[kNP];")
+    L.extend(decl_y("    ", "2"))
+    A("    if (DUAL) {")
+    L.extend(load_w("      ", "(a.w2 + (int64_t)r * a.wn)", scale=True, sfx="2", decl=False))
+    L.extend(load_y("      ", "(a.y2 + (int64_t)e * kS)", sfx="2", decl=False))
+    A("    }")
     used_slots = sorted({s for _, _, s in st.instr})
     for s in used_slots:
         d3 = 2 * st.out_ls[s] + 1
@@ -637,9 +644,14 @@ def _emit(st: Structure) -> str:
     for p, (b, j, s) in enumerate(st.instr):
         l1, l2, l3 = st.in1_ls[b], st.in2_ls[j], st.out_ls[s]
         d1 = 2 * l1 + 1
-        A(f"    {{ T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}, gs{s}, t);")
+        A("    if (!DUAL) {")
+        A(f"      T t[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}, gs{s}, t);")
         for i in range(d1):
             A(f"      acc[{xpre[b] + i}] += wv[{p}] * t[{i}];")
+        A("    } else {")
+        A(f"      T t[{d1}], t2[{d1}]; CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}2, gs{s}, t); CGT<{l1},{l2},{l3}>::template bc_a<T>(yb{j}, gs{s}, t2);")
+        for i in range(d1):
+            A(f"      acc[{xpre[b] + i}] += wv[{p}] * t[{i}] + wv2[{p}] * t2[{i}];")
         A("    }")
     A("    idx = nidx; e = e_n; d = d_n; r = r_n;")
     A("  }")
@@ -1235,6 +1247,13 @@ def _emit(st: Structure) -> str:
     else:
         A("    return 1;  // not generated for this structure (register budget)")
     A("  }")
+    A("  if (which == 8) {  // dual bwd_x (second-order backward): out = Bx(y2, w, g) + Bx(y, w2, g)")
+    A("    if (a.y2 == nullptr || a.w2 == nullptr) return 1;")
+    A("    const int64_t blocks8 = WPN == 1 ? (items + 3) / 4 : items;")
+    A("    const size_t smem8 = WPN > 1 ? (size_t)(WPN - 1) * kXD * 64 * sizeof(float) : 0;")
+    A("    hipLaunchKernelGGL((bwd_x_kernel<float, WPN, true>), dim3((unsigned)blocks8), dim3(256), smem8, stream, a);")
+    A("    return 0;")
+    A("  }")
     A("  if (which == 7) {  // forward JVP (second-order backward): out = F(x2, y, w) + F(x, y2, w) + F(x, y, w2)")
     A("    const int64_t blocks7 = WPN == 1 ? (items + 3) / 4 : items;")
     A("    const size_t smem7 = WPN > 1 ? (size_t)(WPN - 1) * kOD * 64 * sizeof(float) : 0;")
@@ -1261,7 +1280,7 @@ def _emit(st: Structure) -> str:
     A("    hipLaunchKernelGGL((fwd_kernel<float, WPN, false>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
     A("  } else {")
     A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kXD * 64 * sizeof(float) : 0;")
-    A("    hipLaunchKernelGGL((bwd_x_kernel<float, WPN>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
+    A("    hipLaunchKernelGGL((bwd_x_kernel<float, WPN, false>), dim3((unsigned)blocks), dim3(256), smem, stream, a);")
     A("  }")
     A("  return 0;")
     A("}")

@@ -971,7 +971,46 @@ int nqa_tp_scatter_fwd_jvp(const nqa_plan* plan, const void* plan_image, int32_t
   return check_launch("nqa_tp_scatter_fwd_jvp");
 }
 
+int nqa_tp_scatter_bwd_x_dual(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* y, const void* w,
+                              const void* y_cot, const void* w_cot, const void* grad_out, const int32_t* rowptr_src,
+                              const int32_t* edge_id_src, const int32_t* dst_sorted, void* grad_x, int64_t num_nodes,
+                              int64_t num_edges, const int32_t* weight_rows, int64_t num_pairs, nqa_stream stream) {
+  int rc = check_common(plan, plan_image, dtype, "nqa_tp_scatter_bwd_x_dual");
+  if (rc != NQA_OK) return rc;
+  if (!use_spec(plan, dtype)) {
+    set_error("nqa_tp_scatter_bwd_x_dual: no structure-specialised float32 kernel for this plan");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if ((num_nodes > 0 && (!grad_x || !rowptr_src)) ||
+      (num_edges > 0 && (!y || !w || !y_cot || !w_cot || !grad_out || !edge_id_src || !dst_sorted)) ||
+      (weight_rows != nullptr && (num_pairs <= 0 || num_pairs > 1073741823))) {
+    set_error("nqa_tp_scatter_bwd_x_dual: NULL operand");
+    return NQA_ERR_INVALID;
+  }
+  if (num_nodes == 0) return NQA_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SpecArgs<float> a{};
+  spec_fill(a, plan, num_nodes);
+  a.y = static_cast<const float*>(y);
+  a.w = static_cast<const float*>(w);
+  a.y2 = static_cast<const float*>(y_cot);
+  a.w2 = static_cast<const float*>(w_cot);
+  a.g = static_cast<const float*>(grad_out);
+  a.out = static_cast<float*>(grad_x);
+  a.rowptr = rowptr_src;
+  a.eid = edge_id_src;
+  a.nbr = dst_sorted;
+  a.wid = weight_rows ? weight_rows : edge_id_src;
+  a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
+  if (plan->spec->launch(8, spec_wpn(plan, num_nodes), a, s) != 0) {
+    set_error("nqa_tp_scatter_bwd_x_dual: kernel not available");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  return check_launch("nqa_tp_scatter_bwd_x_dual");
+}
+
 }  // extern "C"
+
 
 
 

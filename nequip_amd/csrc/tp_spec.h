@@ -36,7 +36,7 @@ struct SpecArgs {
 };
 
 // which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows,
-// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows, 6 = dual pair-centric edge gradients, 7 = forward JVP;  wpn: requested wavefronts per (node, chunk)
+// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows, 6 = dual pair-centric edge gradients, 7 = forward JVP, 8 = dual bwd_x;  wpn: requested wavefronts per (node, chunk)
 using SpecLaunchFn = int (*)(int which, int wpn, const SpecArgs<float>& a, hipStream_t stream);
 
 struct SpecEntry {

@@ -249,6 +249,25 @@ class _Kernels:
         assert nterms > 0
         return out
 
+    def bwd_x_dual(self, y, w, c_y, c_w, g, topo: EdgeTopology, pairing=None) -> torch.Tensor:
+        """``Bx(c_y, w, g) + Bx(y, c_w, g)`` in one pass (``nqa_tp_scatter_bwd_x_dual``)."""
+        self._check(None, y, w, topo, pairing)
+        lib = _lib.load()
+        gx = torch.empty((topo.num_nodes, self.dim_in1), dtype=g.dtype, device=g.device)
+        rowptr, eid, nbr = topo.by_src
+        es = g.element_size()
+        nbytes = topo.num_edges * (es * 2 * (self.weight_numel + self.dim_in2) + 16) + topo.num_nodes * es * (
+            self.dim_in1 + self.dim_out)
+        with torch.cuda.device(g.device), ktimer.region("tp_bwd_x", nbytes):
+            rc = lib.nqa_tp_scatter_bwd_x_dual(
+                self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(c_y), _ptr(c_w), _ptr(g),
+                _ptr(rowptr), _ptr(eid), _ptr(nbr), _ptr(gx), topo.num_nodes, topo.num_edges,
+                _ptr(pairing.slots_src) if pairing is not None else ctypes.c_void_p(),
+                pairing.num_pairs if pairing is not None else 0, current_stream_ptr(g.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_tp_scatter_bwd_x_dual")
+        return gx
+
     def has_dual_pairs_kernel(self, dtype: torch.dtype) -> bool:
         cache = self.__dict__.setdefault("_has_dual", {})
         if dtype not in cache:
@@ -395,7 +414,10 @@ class _TPScatterBwdFn(torch.autograd.Function):
                 gg = add(gg, k.fwd(x, c_y, w, topo, pr))
             if c_w is not None:
                 gg = add(gg, k.fwd(x, y, c_w, topo, pr))
-        if need_x:
+        if need_x and c_y is not None and c_w is not None and k.has_fwd_jvp(x.dtype) and \
+                os.environ.get("NQA_NO_FWD_JVP", "") in ("", "0"):
+            gxx = k.bwd_x_dual(y, w, c_y, c_w, g, topo, pr)  # both terms in one pass
+        elif need_x:
             if c_y is not None:
                 gxx = add(gxx, k.bwd_x(c_y, w, g, topo, pr))
             if c_w is not None:

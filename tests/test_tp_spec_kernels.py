@@ -150,6 +150,8 @@ def test_spec_kernels_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul):
                                    (k.fwd(xd, cy_, wd, topo, pr) if cy_ is not None else None),
                                    (k.fwd(xd, yd, cw_, topo, pr) if cw_ is not None else None)) if t is not None)
             _close(want.cpu(), k.fwd_jvp(xd, yd, wd, cx_, cy_, cw_, topo, pr), f"fwd_jvp {tag}")
+        _close((k.bwd_x(yc, wd, god, topo, pr) + k.bwd_x(yd, wc, god, topo, pr)).cpu(),
+               k.bwd_x_dual(yd, wd, yc, wc, god, topo, pr), f"bwd_x_dual {tag}")
         if symmetric and k.has_pairs_kernel(torch.float32):
             # pair-centric backward: grad_w comes out summed over the two directed edges of every pair
             px, pw, py = k.bwd_pairs(xd, yd, wd, god, topo, pr)
