@@ -454,13 +454,13 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
 /* Second-order companion (force-matching training differentiates the backward once more, nequip/nn/grad_output.py:217-221):
  *   with cotangents x_cot [N, dim_in1] of grad_x and y_cot [E, dim_in2] of grad_y,
  *     grad_w = Bw(x_cot, y, grad_out) + Bw(x, y_cot, grad_out)   [num_pairs, weight_numel], summed over each pair,
- *     grad_y = By(x_cot, w, grad_out)                             [E, dim_in2]
+ *     grad_y = By(x_cot, w, grad_out) (+ By(x, w_cot, grad_out) when w_cot [num_pairs, weight_numel] is given)  [E, dim_in2]
  *   in ONE pair-centric pass (the intermediate sum_k C_ijk grad_out_k serves both products) instead of two calls of
  *   nqa_tp_scatter_bwd_pairs and an addition.  Plans with a single-wavefront pair kernel only
  *   (nqa_tp_bwd_pairs_dual_supported); workspace as nqa_tp_bwd_pairs_workspace_bytes. */
 int32_t nqa_tp_bwd_pairs_dual_supported(const nqa_plan* plan, int32_t dtype);
 int nqa_tp_scatter_bwd_pairs_dual(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
-                                  const void* x_cot, const void* y, const void* y_cot, const void* w,
+                                  const void* x_cot, const void* y, const void* y_cot, const void* w, const void* w_cot,
                                   const void* grad_out, const int32_t* owner_rowptr, const int32_t* pair_other,
                                   const int32_t* pair_row, const int32_t* pair_edge_in, const int32_t* pair_edge_out,
                                   void* grad_w, void* grad_y, void* workspace, int64_t workspace_bytes,

@@ -144,7 +144,7 @@ SIGNATURES = {
     "nqa_tp_bwd_pairs_dual_supported": (c_int32, [c_void_p, c_int32]),
     "nqa_tp_scatter_bwd_pairs_dual": (
         c_int32,
-        [c_void_p, c_void_p, c_int32] + [c_void_p] * 6  # plan, image, dtype, x, x_cot, y, y_cot, w, grad_out
+        [c_void_p, c_void_p, c_int32] + [c_void_p] * 7  # plan, image, dtype, x, x_cot, y, y_cot, w, w_cot, grad_out
         + [c_void_p] * 5  # owner_rowptr, pair_other, pair_row, pair_edge_in, pair_edge_out
         + [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p],
     ),

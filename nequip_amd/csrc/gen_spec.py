@@ -794,6 +794,9 @@ def _emit(st: Structure) -> str:
                 out += load_g("      ", f"a.g + (int64_t)jn{sfx} * a.dout", "gvJ")
             out += load_y("      ", "yi", sfx="I" + sfx, decl=False)
             out += load_y("      ", "yo", sfx="X" + sfx, decl=False)
+            out.append("      if (DUAL && a.w2 != nullptr) {")
+            out += load_w("        ", f"(a.w2 + (int64_t)pr{sfx} * a.wn)", sfx="2" + sfx, decl=False)
+            out.append("      }")
             out.append("      if (DUAL) {")
             out += load_x("        ", f"(a.x2 + (int64_t)jn{sfx} * a.din)", sfx="J" + sfx + "2", decl=False)
             out += load_y("        ", f"(a.y2 + (int64_t)ei{sfx} * kS)", sfx="I" + sfx + "2", decl=False)
@@ -806,7 +809,7 @@ def _emit(st: Structure) -> str:
             return load_g("    ", f"a.g + (int64_t)jn{sfx} * a.dout", "gvJ")
 
         def pair_decls(sfx):
-            return ([f"  T wv{sfx}[kNP];", f"  int jn{sfx} = 0, pr{sfx} = 0, ei{sfx} = 0, eo{sfx} = 0;"]
+            return ([f"  T wv{sfx}[kNP], wv2{sfx}[kNP];", f"  int jn{sfx} = 0, pr{sfx} = 0, ei{sfx} = 0, eo{sfx} = 0;"]
                     + decl_x("  ", "J" + sfx) + decl_y("  ", "I" + sfx) + decl_y("  ", "X" + sfx)
                     + decl_x("  ", "J" + sfx + "2") + decl_y("  ", "I" + sfx + "2") + decl_y("  ", "X" + sfx + "2"))
 
@@ -848,6 +851,13 @@ def _emit(st: Structure) -> str:
                     out.append(f"        qI[{ypre[j] + jj}] += wv{sfx}[{pth}] * Bi{jj};")
                 for jj in live_x:
                     out.append(f"        qX[{ypre[j] + jj}] += wv{sfx}[{pth}] * Bx{jj};")
+                # DUAL with a weight cotangent (a.w2): grad_y += By(x, w2, g) rides on the D intermediates
+                out.append("        if (DUAL && a.w2 != nullptr) {")
+                for jj in live_i:
+                    out.append(f"          qI[{ypre[j] + jj}] += wv2{sfx}[{pth}] * Di{jj};")
+                for jj in live_x:
+                    out.append(f"          qX[{ypre[j] + jj}] += wv2{sfx}[{pth}] * Dx{jj};")
+                out.append("        }")
                 out.append("      }")
                 if last_path_of_block[b_] == pth:
                     out.append("      if (GX && act) {")

@@ -868,7 +868,7 @@ int32_t nqa_tp_bwd_pairs_dual_supported(const nqa_plan* plan, int32_t dtype) {
 }
 
 int nqa_tp_scatter_bwd_pairs_dual(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
-                                  const void* x_cot, const void* y, const void* y_cot, const void* w,
+                                  const void* x_cot, const void* y, const void* y_cot, const void* w, const void* w_cot,
                                   const void* grad_out, const int32_t* owner_rowptr, const int32_t* pair_other,
                                   const int32_t* pair_row, const int32_t* pair_edge_in, const int32_t* pair_edge_out,
                                   void* grad_w, void* grad_y, void* workspace, int64_t workspace_bytes,
@@ -900,6 +900,7 @@ int nqa_tp_scatter_bwd_pairs_dual(const nqa_plan* plan, const void* plan_image, 
   a.y = static_cast<const float*>(y);
   a.y2 = static_cast<const float*>(y_cot);
   a.w = static_cast<const float*>(w);
+  a.w2 = static_cast<const float*>(w_cot);  // optional: grad_y += By(x, w_cot, grad_out)
   a.g = static_cast<const float*>(grad_out);
   a.gw = static_cast<float*>(grad_w);
   a.rowptr = owner_rowptr;

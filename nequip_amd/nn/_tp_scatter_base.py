@@ -274,10 +274,10 @@ class _Kernels:
             cache[dtype] = bool(_lib.load().nqa_tp_bwd_pairs_dual_supported(self.plan.handle, _nqa_dtype(dtype)))
         return cache[dtype]
 
-    def edge_grads_dual(self, x, x_cot, y, y_cot, w, g, topo: EdgeTopology, pairing):
-        """``(Bw(x_cot, y, g) + Bw(x, y_cot, g), By(x_cot, w, g))`` in one pair-centric pass
+    def edge_grads_dual(self, x, x_cot, y, y_cot, w, g, topo: EdgeTopology, pairing, w_cot=None):
+        """``(Bw(x_cot, y, g) + Bw(x, y_cot, g), By(x_cot, w, g) [+ By(x, w_cot, g)])`` in one pair-centric pass
         (``nqa_tp_scatter_bwd_pairs_dual``): the two weight-gradient terms of the second-order backward, summed over the
-        directed edges of every pair."""
+        directed edges of every pair, and its grad_y terms."""
         lib = _lib.load()
         E, N = topo.num_edges, topo.num_nodes
         self._check(x, y, w, topo, pairing)
@@ -291,7 +291,7 @@ class _Kernels:
         with torch.cuda.device(x.device), ktimer.region("tp_bwd_edge", nbytes):
             rc = lib.nqa_tp_scatter_bwd_pairs_dual(
                 self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(x_cot), _ptr(y), _ptr(y_cot),
-                _ptr(w), _ptr(g), _ptr(orow), _ptr(oth), _ptr(prow), _ptr(ein), _ptr(eout), _ptr(gw), _ptr(gy),
+                _ptr(w), _ptr(w_cot), _ptr(g), _ptr(orow), _ptr(oth), _ptr(prow), _ptr(ein), _ptr(eout), _ptr(gw), _ptr(gy),
                 _ptr(ws), ws_bytes, N, E, current_stream_ptr(x.device),
             )  # fmt: skip
         _lib.check(rc, "nqa_tp_scatter_bwd_pairs_dual")
@@ -425,8 +425,10 @@ class _TPScatterBwdFn(torch.autograd.Function):
         if (need_w and c_x is not None and c_y is not None and k.use_pairs(x.dtype, pr)
                 and k.has_dual_pairs_kernel(x.dtype) and os.environ.get("NQA_NO_DUAL_PAIR_BWD", "") in ("", "0")):
             # both weight-gradient terms (and By(c_x, w, g)) in one pair-centric pass over the shared intermediate
-            gww, a_y = k.edge_grads_dual(x, c_x, y, c_y, w, g, topo, pr)
+            gww, a_y = k.edge_grads_dual(x, c_x, y, c_y, w, g, topo, pr, w_cot=c_w if need_y else None)
             gyy = add(gyy, a_y if need_y else None)
+            if c_w is not None and need_y:
+                c_w = None  # its grad_y term is in a_y already
         elif need_w and c_x is not None and c_y is not None and k.use_pairs(x.dtype, pr):
             # pair-centric kernels: both contributions arrive summed over the directed edges of every pair
             a_w1, a_y = k.edge_grads_folded(c_x, y, w, g, topo, pr, need_gw=True, need_gy=need_y)

@@ -168,6 +168,10 @@ def test_spec_kernels_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul):
                 dw, dy = k.edge_grads_dual(xd, x2d, yd, y2d, wd, god, topo, pr)
                 _close((w_a + w_b).cpu(), dw, f"dual gw {tag}")
                 _close(y_a.cpu(), dy, f"dual gy {tag}")
+                _, y_c = k.bwd_edge(xd, yd, wc, god, topo, need_gw=False, need_gy=True, pairing=pr)
+                dw3, dy3 = k.edge_grads_dual(xd, x2d, yd, y2d, wd, god, topo, pr, w_cot=wc)
+                _close((w_a + w_b).cpu(), dw3, f"dual gw (with w_cot) {tag}")
+                _close((y_a + y_c).cpu(), dy3, f"dual gy (with w_cot) {tag}")
             none_x, pw2, py2 = k.bwd_pairs(xd, yd, wd, god, topo, pr, need_gx=False)  # the edge gradients only
             assert none_x is None
             _close(rgw_pairs, pw2, f"bwd_pairs<no gx> gw {tag}")
