@@ -125,6 +125,32 @@ class EdgeTopology:
         return self._by_src
 
 
+def build_owner_csr(edge_dst: torch.Tensor, edge_src: torch.Tensor, rows: torch.Tensor, num_pairs: int, num_nodes: int):
+    """Owner lists of the pair-centric backward from a paired edge list (``rows[e]`` = p for the representative edge of pair
+    p, p + P for its reverse).  Pure index arithmetic (a few sorts, no synchronisation; runs on any device -- the host
+    logic is tested on the CPU).  Owner of the pair {i <- j, j <- i}: i when ``(i < j) xor (i + j odd)``, a self image
+    pair (i == j) belongs to i.  Returns int32 tensors ``(owner_rowptr [N+1], pair_other, pair_row, edge_in, edge_out,
+    other_rowptr [N+1], other_slot)``: slots grouped by owner (within an owner by the other node), ``edge_in`` /
+    ``edge_out`` the directed edges with dst = owner / dst = other, ``other_slot`` the slots grouped by their other node."""
+    P, N = int(num_pairs), int(num_nodes)
+    dev = rows.device
+    order = torch.argsort(rows.to(torch.int64))  # rows are a permutation of 0 .. 2P-1
+    ea, eb = order[:P], order[P:]  # representative edge and its reverse, in pair order
+    i, j = edge_dst.index_select(0, ea), edge_src.index_select(0, ea)
+    own_i = (i == j) | ((i < j) ^ (((i + j) & 1) == 1))
+    owner, other = torch.where(own_i, i, j), torch.where(own_i, j, i)
+    e_in, e_out = torch.where(own_i, ea, eb), torch.where(own_i, eb, ea)  # dst = owner / dst = other
+    perm = torch.argsort(owner * N + other)
+    owner_s, other_s = owner.index_select(0, perm), other.index_select(0, perm)
+    nodes = torch.arange(N + 1, dtype=torch.int64, device=dev)
+    owner_rowptr = torch.searchsorted(owner_s, nodes).to(torch.int32)
+    perm2 = torch.argsort(other_s, stable=True)
+    other_rowptr = torch.searchsorted(other_s.index_select(0, perm2), nodes).to(torch.int32)
+    i32 = lambda t: t.to(torch.int32).contiguous()  # noqa: E731
+    return (owner_rowptr.contiguous(), i32(other_s), i32(perm), i32(e_in.index_select(0, perm)),
+            i32(e_out.index_select(0, perm)), other_rowptr.contiguous(), i32(perm2))
+
+
 class EdgePairing:
     """Weight rows of a paired edge list: ``rows[e]`` (see include/nequip_amd.h ``nqa_edge_pairs``), gathered into the
     slot order of the two CSRs on first use, and the representative edge of every pair."""
@@ -162,23 +188,7 @@ class EdgePairing:
         Built once per neighbour list with a handful of ATen sorts (no synchronisation)."""
         if self._owner_csr is None:
             topo = self._topo()
-            P, N = self.num_pairs, topo.num_nodes
-            dev = self.rows.device
-            order = torch.argsort(self.rows.to(torch.int64))  # rows are a permutation of 0 .. 2P-1
-            ea, eb = order[:P], order[P:]  # representative edge and its reverse, in pair order
-            i, j = topo._dst.index_select(0, ea), topo._src.index_select(0, ea)
-            own_i = (i == j) | ((i < j) ^ (((i + j) & 1) == 1))
-            owner, other = torch.where(own_i, i, j), torch.where(own_i, j, i)
-            e_in, e_out = torch.where(own_i, ea, eb), torch.where(own_i, eb, ea)  # dst = owner / dst = other
-            perm = torch.argsort(owner * N + other)
-            owner_s, other_s = owner.index_select(0, perm), other.index_select(0, perm)
-            nodes = torch.arange(N + 1, dtype=torch.int64, device=dev)
-            owner_rowptr = torch.searchsorted(owner_s, nodes).to(torch.int32)
-            perm2 = torch.argsort(other_s, stable=True)
-            other_rowptr = torch.searchsorted(other_s.index_select(0, perm2), nodes).to(torch.int32)
-            i32 = lambda t: t.to(torch.int32).contiguous()  # noqa: E731
-            self._owner_csr = (owner_rowptr.contiguous(), i32(other_s), i32(perm), i32(e_in.index_select(0, perm)),
-                               i32(e_out.index_select(0, perm)), other_rowptr.contiguous(), i32(perm2))
+            self._owner_csr = build_owner_csr(topo._dst, topo._src, self.rows, self.num_pairs, topo.num_nodes)
         return self._owner_csr
 
 

@@ -246,3 +246,47 @@ def test_model_survives_deepcopy_and_pickle():
     m3 = torch.load(buf, weights_only=False)
     for (k, a), (_, b) in zip(m.state_dict().items(), m3.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_owner_lists_of_the_pair_centric_backward():
+    """`build_owner_csr` (host-side index arithmetic, device agnostic): the owner lists are a partition of the pairs, every
+    slot carries the two directed edges of its pair with the right roles, the other-node lists index the same slots, self
+    image pairs belong to their node, and the owner rule hands every node about half of its pairs."""
+    import torch
+
+    from nequip_amd.nn._topology import build_owner_csr
+
+    g = torch.Generator().manual_seed(0)
+    N = 40
+    und = set()
+    for _ in range(400):
+        a, b = (int(v) for v in torch.randint(0, N, (2,), generator=g))
+        if a != b:
+            und.add((min(a, b), max(a, b)))
+    und = sorted(und)
+    self_pairs = [3, 17]  # an atom and its own periodic images: two directed edges i <- i with opposite shifts
+    P = len(und) + len(self_pairs)
+    dst = [a for a, b in und] + self_pairs + [b for a, b in und] + self_pairs
+    src = [b for a, b in und] + self_pairs + [a for a, b in und] + self_pairs
+    rows = torch.arange(2 * P)  # representative edge of pair p = edge p, its reverse = edge p + P
+    perm = torch.randperm(2 * P, generator=g)  # edges in arbitrary order
+    dst, src, rows = torch.tensor(dst)[perm], torch.tensor(src)[perm], rows[perm]
+
+    orow, oth, prow, ein, eout, trow, tslot = (t.long() for t in build_owner_csr(dst, src, rows.to(torch.int32), P, N))
+    assert orow[0] == 0 and orow[-1] == P and trow[0] == 0 and trow[-1] == P
+    assert sorted(prow.tolist()) == list(range(P)) and sorted(tslot.tolist()) == list(range(P))
+    owner = torch.repeat_interleave(torch.arange(N), orow[1:] - orow[:-1])
+    assert torch.equal(dst[ein], owner) and torch.equal(src[ein], oth)      # edge_in:  other -> owner
+    assert torch.equal(dst[eout], oth) and torch.equal(src[eout], owner)    # edge_out: owner -> other
+    assert torch.equal(rows[ein] % P, prow) and torch.equal(rows[eout] % P, prow) and not torch.equal(ein, eout)
+    assert torch.equal(oth[tslot], torch.repeat_interleave(torch.arange(N), trow[1:] - trow[:-1]))
+    for node in self_pairs:  # owner == other
+        assert int(((owner == node) & (oth == node)).sum()) == 1
+    # within an owner the slots are ordered by the other node (locality of the gathered rows)
+    for n in range(N):
+        seg = oth[orow[n]:orow[n + 1]]
+        assert torch.equal(seg, seg.sort().values)
+    degree = torch.bincount(torch.cat([dst, src]), minlength=N).float() / 2  # pairs per node (self pairs count twice / 2)
+    owned = (orow[1:] - orow[:-1]).float()
+    assert float((owned - degree / 2).abs().max()) <= 0.3 * float(degree.max()) + 2
+    assert abs(float(owned.sum()) - P) < 1e-6
