@@ -33,7 +33,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), same guide
 # committed PMC summary (scripts/profile.sh): only used for `roofline.traffic` when the live measurement below is
 # unavailable, and then labelled as static in `traffic_source`
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_summary.json") for r in (3, 2)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r2_pmc_summary.json"))
 
 TRAIN_WORKLOADS = {
     # BASELINE config 4: DDP training on synthetic 5-species 256-atom frames, l_max=2, batch=32 per rank
@@ -190,26 +191,47 @@ TP_REGIONS = ("tp_fwd", "tp_bwd_edge", "tp_bwd_x", "tp_bwd_fused", "tp_fwd_mlp",
 def kernel_roofline(kname, ks, kernel_steps):
     launches = ks["calls"] / max(kernel_steps, 1)
     if ks.get("flops_per_call", 0) > 0 and kname.startswith("radial_mlp"):
-        # GEMM on the matrix cores.  `achieved` = algorithmic fp32 FLOP/s against the dense fp32-MFMA peak (the path's
-        # arithmetic type); the default kernels execute 6 bf16 MFMA partial products per fp32 product (split operands,
-        # fp32-accurate), reported against the bf16 peak as well.
+        # GEMM on the matrix cores.  The default kernels execute 6 bf16 MFMA partial products per fp32 product (split
+        # operands, fp32-accurate): `achieved` / `frac` are the EXECUTED bf16 MFMA rate against the dense bf16 peak -- the
+        # pipe the kernel runs on.  The algorithmic fp32 FLOP rate (what the reference's fp32 GEMM would be credited
+        # with) is reported next to it; with NQA_MLP_EXACT_FP32=1 the kernels run on the fp32 MFMA pipe and that is the
+        # roofline.
         split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
         r = {
-            "bound": "mfma", "kernel": kname, "achieved": ks["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
+            "bound": "mfma", "kernel": kname, "unit": "TFLOP/s",
             "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],
             "algorithmic_bytes_per_launch": ks["bytes_per_call"], "hbm_gbps": ks["gbps"],
-            "launches_per_step": launches,
+            "launches_per_step": launches, "algorithmic_fp32_tflops": ks["tflops"],
+            "frac_of_fp32_mfma_peak": ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
         }
         if split:
-            r["executed_bf16_tflops"] = 6.0 * ks["tflops"]
-            r["frac_of_bf16_peak"] = 6.0 * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS
+            r.update(achieved=6.0 * ks["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, frac=6.0 * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                     pipe="bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 partial products per fp32 product")
+        else:
+            r.update(achieved=ks["tflops"], peak=MFMA_F32_PEAK_TFLOPS, frac=ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
+                     pipe="fp32 MFMA (v_mfma_f32_32x32x2_f32)")
         return r
     return {
         "bound": "hbm", "kernel": kname, "achieved": ks["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": ks["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ks["avg_ms"],
         "algorithmic_bytes_per_launch": ks["bytes_per_call"], "launches_per_step": launches,
     }
+
+
+def add_traffic(r, pmc):
+    """`traffic` = counter-measured HBM bytes per launch of the region; `frac_traffic` = those bytes / the launch time /
+    the HBM peak -- the rate the kernel really sustains (`frac` is computed on the boundary's algorithmic bytes, which a
+    kernel that reads a shared row once per pair does not move)."""
+    t = pmc.get(r["kernel"], {}).get("hbm_bytes_per_launch")
+    r["traffic"] = t
+    if t is not None and r["avg_launch_ms"] > 0:
+        r["traffic_gbps"] = t / 1e9 / (r["avg_launch_ms"] / 1e3)
+        r["frac_traffic"] = r["traffic_gbps"] / HBM_PEAK_GBPS
+        if r.get("algorithmic_bytes_per_launch"):
+            r["traffic_over_algorithmic"] = t / r["algorithmic_bytes_per_launch"]
+    else:
+        r["traffic_gbps"] = r["frac_traffic"] = None
+    return r
 
 
 def measure_traffic_live(workload: str, timeout_s: float = 240.0):
@@ -278,14 +300,12 @@ def roofline_objects(kernels, kernel_steps, ms_per_step, workload, live_pmc):
         if why:
             source += f" [live measurement: {why}]"
     name, s = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
-    roofline = kernel_roofline(name, s, kernel_steps)
-    roofline["traffic"] = pmc.get(name, {}).get("hbm_bytes_per_launch")
+    roofline = add_traffic(kernel_roofline(name, s, kernel_steps), pmc)
     roofline["traffic_source"] = source
     others = {}
     for kname, ks in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])[:8]:
         if kname != name:
-            others[kname] = kernel_roofline(kname, ks, kernel_steps)
-            others[kname]["traffic"] = pmc.get(kname, {}).get("hbm_bytes_per_launch")
+            others[kname] = add_traffic(kernel_roofline(kname, ks, kernel_steps), pmc)
     roofline["other_kernels"] = others
     tp_bytes = sum(v["bytes_per_call"] * v["calls"] for k, v in kernels.items() if k in TP_REGIONS) / max(kernel_steps, 1)
     step = {

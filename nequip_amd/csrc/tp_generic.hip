@@ -859,7 +859,10 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
   b.out = static_cast<float*>(grad_x);
   b.rowptr = other_rowptr;
   b.eid = other_slot;
-  plan->spec->launch(5, 1, b, s);
+  if (plan->spec->launch(5, 1, b, s) != 0) {
+    set_error("nqa_tp_scatter_bwd_pairs: this structure has no grad_x row-sum kernel");
+    return NQA_ERR_UNSUPPORTED;
+  }
   return check_launch("nqa_tp_scatter_bwd_pairs(sum)");
 }
 
@@ -968,7 +971,10 @@ int nqa_tp_scatter_fwd_jvp(const nqa_plan* plan, const void* plan_image, int32_t
   a.nbr = src_sorted;
   a.wid = weight_rows ? weight_rows : edge_id_dst;
   a.wP = weight_rows ? (int32_t)num_pairs : 2147483647;
-  plan->spec->launch(7, spec_wpn(plan, num_nodes), a, s);
+  if (plan->spec->launch(7, spec_wpn(plan, num_nodes), a, s) != 0) {
+    set_error("nqa_tp_scatter_fwd_jvp: this structure has no forward-JVP kernel");
+    return NQA_ERR_UNSUPPORTED;
+  }
   return check_launch("nqa_tp_scatter_fwd_jvp");
 }
 

@@ -28,12 +28,20 @@ def _ptr(t: Optional[torch.Tensor]):
 
 def _complete_cell(cell64: torch.Tensor, pbc: Tuple[bool, bool, bool]) -> torch.Tensor:
     """Cells with zero lattice vectors along non-periodic directions (ASE slabs / wires / molecules with pbc = (T, T, F)
-    and c = 0): complete them with unit vectors orthogonal to the others, as ``ase.geometry.complete_cell`` does and the
-    reference's backends accept -- the kernel inverts the cell.  A zero (or linearly dependent) vector along a
-    *periodic* direction is an error."""
-    c = cell64.detach().cpu().numpy().copy()
+    and c = 0): complete them with unit vectors orthogonal to the span of the others, as ``ase.geometry.complete_cell``
+    does and the reference's backends accept -- the kernel inverts the cell.  A zero (or linearly dependent) vector
+    along a *periodic* direction is an error.
+
+    The check reads the nine numbers on the host: one small copy per call, next to the one synchronisation the
+    neighbour list needs anyway (the data-dependent edge count).  Deliberately not memoised on the tensor's storage:
+    a recycled allocation would look like the same cell."""
+    return _complete_cell_host(cell64, pbc)
+
+
+def _complete_cell_host(cell64: torch.Tensor, pbc: Tuple[bool, bool, bool]) -> torch.Tensor:
     import numpy as np
 
+    c = cell64.detach().cpu().numpy().copy()
     norms = np.linalg.norm(c, axis=1)
     missing = [i for i in range(3) if norms[i] < 1e-12]
     if not missing:
@@ -43,20 +51,33 @@ def _complete_cell(cell64: torch.Tensor, pbc: Tuple[bool, bool, bool]) -> torch.
     for i in missing:
         if pbc[i]:
             raise ValueError(f"lattice vector {i} is zero but the direction is periodic")
-    present = [i for i in range(3) if i not in missing]
-    basis = [c[i] / norms[i] for i in present]
+    # orthonormal basis of the span of the present vectors (Gram-Schmidt), then unit vectors orthogonal to it
+    basis = []
+    for i in range(3):
+        if i in missing:
+            continue
+        v = c[i].copy()
+        for b in basis:
+            v -= np.dot(v, b) * b
+        n = np.linalg.norm(v)
+        if n < 1e-12 * norms[i]:
+            raise ValueError("cell vectors are linearly dependent")
+        basis.append(v / n)
     for i in missing:
-        # a unit vector orthogonal to everything chosen so far (Gram-Schmidt on the coordinate axes)
-        best = None
-        for axis in np.eye(3):
-            v = axis.copy()
-            for b in basis:
-                v -= np.dot(v, b) * b
-            n = np.linalg.norm(v)
-            if best is None or n > best[0]:
-                best = (n, v)
-        v = best[1] / best[0]
-        # orthonormalise the running basis so that later completions stay orthogonal
+        if len(basis) == 2:
+            v = np.cross(basis[0], basis[1])
+        else:
+            # the coordinate axis with the largest component orthogonal to the basis so far
+            best = None
+            for axis in np.eye(3):
+                w = axis.copy()
+                for b in basis:
+                    w -= np.dot(w, b) * b
+                n = np.linalg.norm(w)
+                if best is None or n > best[0]:
+                    best = (n, w)
+            v = best[1]
+        v = v / np.linalg.norm(v)
         c[i] = v
         basis.append(v)
     if abs(np.linalg.det(c)) < 1e-12:

@@ -119,15 +119,23 @@ class _PairedRadialTPFn(torch.autograd.Function):
             q.layers -= 1
         if need_emb and q is not None:
             cur = torch.cuda.current_stream(g.device)
-            q.stream.wait_stream(cur)  # grad_w is complete
-            with torch.cuda.stream(q.stream):
-                if folded:
-                    part = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache)
-                else:
-                    part = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
-                q.acc = part if q.acc is None else q.acc.add_(part)
-            G.record_stream(q.stream)
+            try:
+                q.stream.wait_stream(cur)  # grad_w is complete
+                with torch.cuda.stream(q.stream):
+                    if folded:
+                        part = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache)
+                    else:
+                        part = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
+                    q.acc = part if q.acc is None else q.acc.add_(part)
+                for t in (G, emb_half, w0, w1):  # read on the side stream: the allocator must not recycle them earlier
+                    t.record_stream(q.stream)
+            except BaseException:
+                # never leave an un-joined fork behind (it would invalidate a hipGraph capture) nor a stale partial sum
+                cur.wait_stream(q.stream)
+                q.acc, q.layers = None, 0
+                raise
             if q.layers <= 0:  # first layer of the model = last backward of the evaluation: join
+                assert q.acc is not None and q.layers == 0, "radial backward queue out of step with the layers"
                 cur.wait_stream(q.stream)
                 g_emb, q.acc = q.acc, None
                 g_emb.record_stream(cur)

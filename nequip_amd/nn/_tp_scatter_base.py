@@ -306,8 +306,10 @@ class _Kernels:
         """(gw, gy) of the edge operands with ``gw`` per weight ROW (per pair when ``pairing`` is given, summed over its
         two directed edges): the pair-centric kernel when it applies, else ``bwd_edge`` + the fold of the two halves."""
         if need_gw and self.use_pairs(x.dtype, pairing):
-            _, gw, gy = self.bwd_pairs(x, y, w, g, topo, pairing, need_gx=False)
-            return gw, (gy if need_gy else None)
+            res = self.bwd_pairs(x, y, w, g, topo, pairing, need_gx=False)
+            if res is not None:  # (None: the pair kernel does not apply to this call after all)
+                _, gw, gy = res
+                return gw, (gy if need_gy else None)
         gw, gy = self.bwd_edge(x, y, w, g, topo, need_gw=need_gw, need_gy=need_gy, pairing=pairing)
         return _fold(gw, pairing), gy
 

@@ -10,6 +10,12 @@ from ...utils.wgrad import differentiable_parameters
 from .._graph_mixin import GraphModuleMixin
 
 
+def _tracing() -> bool:
+    from ...utils.tracing import traceable
+
+    return traceable()
+
+
 class NodeTypeEmbed(GraphModuleMixin, torch.nn.Module):
     def __init__(self, type_names: List[str], num_features: int, set_features: bool = True, irreps_in=None):
         super().__init__()
@@ -23,6 +29,13 @@ class NodeTypeEmbed(GraphModuleMixin, torch.nn.Module):
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         atom_types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)
+        # Out-of-range types: `F.embedding` (eval path; the reference's only path) raises / faults on them, the one-hot
+        # product of the training path below would silently give a zero row.  Host tensors are checked here (free);
+        # device tensors are not (the check would synchronise every step) -- validate type maps where the data is built.
+        if not atom_types.is_cuda and atom_types.numel() > 0 and not _tracing():
+            lo, hi = int(atom_types.min()), int(atom_types.max())
+            if lo < 0 or hi >= self.num_types:
+                raise IndexError(f"atom type index out of range: [{lo}, {hi}] for {self.num_types} types")
         # eval mode: parameters are constants (same convention as o3.Linear) -- keeps autograd from carrying the
         # position-independent embedding through every backward kernel when only forces are requested
         w = self.embed_module.weight

@@ -5,6 +5,7 @@ with the instruction list, sorted ``irreps_mid`` and parameter names of the refe
 gather / scatter is the fused HIP ``TensorProductScatter``.
 """
 
+import contextlib
 import os
 from typing import Dict, Optional, Sequence, Union
 
@@ -160,7 +161,9 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
                 sc_stream = _paired_radial.side_stream(x.device, 1)
                 sc_stream.wait_stream(torch.cuda.current_stream(x.device))
                 x.record_stream(sc_stream)
-            with torch.cuda.stream(sc_stream):  # (None: current stream)
+            # (no side stream -- always the case while a compiler traces -- means no stream context at all: Dynamo
+            # rejects `torch.cuda.stream(None)`)
+            with (torch.cuda.stream(sc_stream) if sc_stream is not None else contextlib.nullcontext()):
                 if table is not None and table.shape[0] <= 16:
                     sc = self.sc.forward_typed(x, data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: x.shape[0]], table)
                 else:

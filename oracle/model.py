@@ -105,7 +105,7 @@ def energy_model(data, cfg, weights, specs=None):
         mlp_w = [weights[pre + f"edge_mlp.mlp.{2 * k}.weight"] for k in range(S.radial_depth + 1)]
         w = onn.scalar_mlp(edge_emb, mlp_w, "silu")
         x = otp.tp_scatter(x, edge_attrs, w, edge_index[0], edge_index[1], S.feature_irreps_in, S.edge_sh,
-                           S.irreps_mid, S.instructions)
+                           S.irreps_mid, S.instructions, edge_chunk=cfg.get("oracle_edge_chunk"))
         x = onn.o3_linear(x, weights[pre + "linear_2.weight"], ir.simplify(S.irreps_mid), S.conv_irreps_out)
         if S.use_sc:
             x = x + sc

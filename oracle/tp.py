@@ -92,9 +92,31 @@ def scatter(src, index, dim_size):
 
 
 def tp_scatter(x, edge_attr, edge_weight, edge_dst, edge_src, feature_irreps_in, irreps_edge_attr, irreps_mid,
-               instructions):
-    """TensorProductScatter.forward, nequip/nn/_tp_scatter_base.py:35-38."""
-    edge_features = tensor_product_uvu(
-        x[edge_src], edge_attr, edge_weight, feature_irreps_in, irreps_edge_attr, irreps_mid, instructions
-    )
-    return scatter(edge_features, edge_dst, x.size(0))
+               instructions, edge_chunk=None):
+    """TensorProductScatter.forward, nequip/nn/_tp_scatter_base.py:35-38.
+
+    ``edge_chunk`` (test infrastructure for the full-size parity tests): evaluate the same two lines over consecutive
+    ranges of ``edge_chunk`` edges -- the per-edge arithmetic is untouched (same einsum chain per edge), the ranges are
+    added to the node rows in edge order like the sequential ``scatter_add_`` -- with every range under
+    ``torch.utils.checkpoint`` so that autograd keeps the range's operands instead of the ``[E, mul, d1, d2]``
+    temporaries (the reference formulation of the 10k-atom / l_max = 3 boxes does not fit a host otherwise, SURVEY
+    App. B note iv)."""
+    E = edge_dst.shape[0]
+    if edge_chunk is None or E <= edge_chunk:
+        edge_features = tensor_product_uvu(
+            x[edge_src], edge_attr, edge_weight, feature_irreps_in, irreps_edge_attr, irreps_mid, instructions
+        )
+        return scatter(edge_features, edge_dst, x.size(0))
+    from torch.utils.checkpoint import checkpoint
+
+    def piece(x_, y_, w_, dst_, src_):
+        f = tensor_product_uvu(x_[src_], y_, w_, feature_irreps_in, irreps_edge_attr, irreps_mid, instructions)
+        return scatter(f, dst_, x_.size(0))
+
+    out = None
+    for a in range(0, E, edge_chunk):
+        b = min(E, a + edge_chunk)
+        part = checkpoint(piece, x, edge_attr[a:b], edge_weight[a:b], edge_dst[a:b], edge_src[a:b],
+                          use_reentrant=False)
+        out = part if out is None else out + part
+    return out

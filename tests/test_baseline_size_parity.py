@@ -1,0 +1,155 @@
+"""HIP path vs the CPU oracle AT the BASELINE.json workloads themselves.
+
+The kernels choose their launch shapes by problem size (1 or 4 wavefronts per node, owner lists of the pair-centric
+backward, input-block split of the l_max = 3 structures), so parity on the small boxes of ``test_model_parity.py``
+does not cover what ``bench.py`` times.  Here:
+
+* (a) the *full* cfg-3 bench workload -- ``bench.build_box / build_model`` of ``water10k``: 10 125 atoms, 400 558
+  edges, l_max 2, 64 features, 3 layers -- energy, forces, virial against ``oracle.model.energy_forces``;
+* (b) a cfg-4-shaped training step: 64 features, radial MLP width 128, 5 species, 4 frames x 256 atoms batched,
+  parameter gradients of the force-matching loss against autograd-through-autograd of the oracle;
+* (c) the cfg-5 model (l_max 3, 128 features) on a 1008-atom fcc Cu box.
+
+The oracle evaluates the reference's gather -> einsum chain -> scatter over ranges of edges under activation
+checkpointing (``oracle_edge_chunk``; same arithmetic per edge), because the reference formulation's
+``[E, mul, d1, d2]`` temporaries of these boxes do not fit a host otherwise.  Bars: energy 5e-5 per atom abs / 5e-5
+rel, forces <= 1e-4 eV/A absolute (BASELINE.json north_star) and 5e-5 relative to the largest force
+(nequip/utils/dtype.py:35-42); training gradients 2e-4 (as tests/test_training_step.py).
+"""
+
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import model as omodel  # noqa: E402
+
+
+def _weights(model):
+    return {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def _oracle_threads():
+    # the oracle is a chain of ATen ops on [chunk, ...] tensors: all 256 host cores of the GPU box oversubscribe it
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
+def _compare(what, data, out, ref):
+    n = data["pos"].shape[0]
+    f_ref, f_out = ref["forces"], out["forces"].cpu()
+    fscale = float(f_ref.abs().max())
+    df = float((f_ref - f_out).abs().max())
+    de = float((ref["total_energy"] - out["total_energy"].cpu()).abs().max())
+    dv = float((ref["virial"] - out["virial"].cpu()).abs().max())
+    print(f"[{what}] N={n} E={data['edge_index'].shape[1]} |dE|={de:.3e} max|dF|={df:.3e} eV/A "
+          f"(max|F|={fscale:.3e}) max|dV|={dv:.3e}")
+    torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=5e-5 * n, rtol=5e-5)
+    assert df < 1e-4, f"forces differ from the oracle by {df:.3e} eV/A (bar 1e-4)"
+    torch.testing.assert_close(f_ref, f_out, atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+    torch.testing.assert_close(ref["virial"], out["virial"].cpu(), atol=5e-5 * n * max(1.0, fscale), rtol=5e-4)
+
+
+@pytest.mark.gpu
+def test_cfg3_full_bench_workload_water_10125_atoms(device):
+    """(a) exactly what ``python bench.py`` times: same box, same model, same seeds."""
+    import bench
+    from nequip_amd.data import AtomicDataDict
+
+    w = bench.WORKLOADS["water10k"]
+    data, names = bench.build_box(w, seed=0)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 10125 and e > 390000
+    cfg = bench.model_cfg(w, e / n)
+    model = bench.build_model(cfg, names, device)
+    out = model(AtomicDataDict.to_device(data, device))
+    torch.cuda.synchronize()
+    _oracle_threads()
+    t0 = time.perf_counter()
+    ref = omodel.energy_forces(data, dict(cfg, oracle_edge_chunk=16384), _weights(model), with_virial=True)
+    print(f"[cfg-3 full] oracle: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    _compare("cfg-3 water10k (bench workload)", data, out, ref)
+
+
+@pytest.mark.gpu
+def test_cfg5_model_cu_1008_atoms(device):
+    """(c) cfg-5's model -- l_max 3, 128 features (two 64-channel chunks), 23-path middle layer with the pair kernel
+    split by input block -- on 6 x 6 x 7 fcc cells = 1008 atoms, ~38 500 edges."""
+    import bench
+    from nequip_amd.data import AtomicDataDict
+
+    w = dict(bench.WORKLOADS["cu100k"], reps=(6, 6, 7))
+    data, names = bench.build_box(w, seed=0)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 1008
+    cfg = bench.model_cfg(w, e / n)
+    model = bench.build_model(cfg, names, device)
+    out = model(AtomicDataDict.to_device(data, device))
+    torch.cuda.synchronize()
+    _oracle_threads()
+    t0 = time.perf_counter()
+    ref = omodel.energy_forces(data, dict(cfg, oracle_edge_chunk=4096), _weights(model), with_virial=True)
+    print(f"[cfg-5 cu1008] oracle: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    _compare("cfg-5 cu1008", data, out, ref)
+
+
+@pytest.mark.gpu
+def test_cfg4_shaped_training_step_parameter_gradients(device):
+    """(b) cfg-4's shape: 64 features (the all-lanes-active kernel instantiations), radial MLP 8-128-W (fused MFMA
+    training epilogues, split-bf16 ``nqa_wgrad``), 5 species, 4 frames x 256 atoms in one batch (multi-frame sums,
+    pair-centric dual backward, forward JVP).  Parameter gradients of the energy + force MSE loss."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+
+    frames = []
+    for f in range(4):
+        pos, types, cell, names = syn.random_frame(256, 5, seed=100 + f)
+        frames.append(syn.make_data(pos, types, 4.5, cell))
+    data = AtomicDataDict.batched_from_list(frames)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 1024
+    cfg = dict(r_max=4.5, num_layers=3, l_max=2, parity=False, num_features=64, radial_mlp_depth=1,
+               radial_mlp_width=128, num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=e / n,
+               model_dtype="float32")
+    model = NequIPGNNModel(seed=5, model_dtype="float32", type_names=names, per_type_energy_scales=1.0,
+                           per_type_energy_shifts=0.0, **{k: v for k, v in cfg.items() if k != "model_dtype"})
+    gen = torch.Generator().manual_seed(0)
+    f_target = torch.randn(n, 3, generator=gen, dtype=torch.float64)
+    e_target = torch.randn(4, 1, generator=gen, dtype=torch.float64)
+
+    def loss_of(out, ft, et):  # bench.py's train256 loss (nequip EnergyForceLoss, coefficients 1:1)
+        return (out["forces"] - ft).square().mean() + (out["total_energy"] - et).square().mean()
+
+    _oracle_threads()
+    t0 = time.perf_counter()
+    param_names = {k for k, _ in model.named_parameters()}
+    weights = {k.replace("model.func.", ""): v.detach().clone().requires_grad_(k in param_names)
+               for k, v in model.state_dict().items()}
+    out_ref = omodel.energy_forces(data, cfg, weights, create_graph=True)
+    loss_ref = loss_of(out_ref, f_target, e_target)
+    names_w = [k for k, v in weights.items() if v.requires_grad]
+    grads_ref = dict(zip(names_w, torch.autograd.grad(loss_ref, [weights[k] for k in names_w])))
+    print(f"[cfg-4 train] oracle double backward: {time.perf_counter() - t0:.1f} s, N={n} E={e}")
+
+    model = model.to(device).train()
+    out = model(AtomicDataDict.to_device(data, device))
+    loss = loss_of(out, f_target.to(device), e_target.to(device))
+    loss.backward()
+    tol = 2e-4
+    torch.testing.assert_close(loss_ref.detach(), loss.detach().cpu(), atol=tol, rtol=tol)
+    torch.testing.assert_close(out_ref["forces"].detach(), out["forces"].detach().cpu(), atol=1e-4, rtol=5e-5)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        key = k.replace("model.func.", "")
+        assert p.grad is not None, f"no gradient for {k}"
+        r = grads_ref[key]
+        scale = max(1e-3, float(r.abs().max()))
+        worst = max(worst, float((r - p.grad.cpu()).abs().max()) / scale)
+        torch.testing.assert_close(r, p.grad.cpu(), atol=tol * scale, rtol=tol * 10, msg=lambda m: f"{k}: {m}")
+    print(f"[cfg-4 train] {len(grads_ref)} parameter tensors, worst |dgrad| / max|grad| = {worst:.2e}")

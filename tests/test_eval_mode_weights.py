@@ -91,6 +91,10 @@ def test_cell_completion_for_non_periodic_directions():
     c = _complete_cell(wire, (False, False, True))
     assert abs(float(torch.linalg.det(c))) > 1e-6
     assert abs(float(c[0] @ c[2])) < 1e-12 and abs(float(c[1] @ c[2])) < 1e-12 and abs(float(c[0] @ c[1])) < 1e-12
+    # tilted, non-orthogonal a / b (neither along an axis): the completed vector is orthogonal to BOTH
+    tilted = torch.tensor([[3.0, 1.0, 0.5], [1.0, 4.0, -0.7], [0, 0, 0]], dtype=torch.float64)
+    c = _complete_cell(tilted, (True, True, False))
+    assert abs(float(c[2] @ c[0])) < 1e-12 and abs(float(c[2] @ c[1])) < 1e-12 and abs(float(c[2].norm()) - 1) < 1e-12
     with pytest.raises(ValueError):
         _complete_cell(slab, (True, True, True))
     with pytest.raises(ValueError):

@@ -190,3 +190,43 @@ def test_traced_benchmark_shaped_model_keeps_the_fused_kernels(device):
     out = gm(params, buffers, inputs)
     for k in ("total_energy", "forces", "virial"):
         torch.testing.assert_close(out[k], ref[k], rtol=1e-5, atol=3e-5 * max(1.0, float(ref[k].abs().max())))
+
+
+def test_interaction_block_compiles_under_dynamo_on_cpu():
+    """`torch.compile(dynamic=True)` (the reference's train-time compile path, nequip/nn/compile.py:176-191) must be able to
+    trace InteractionBlock.forward -- including the self-connection branch, which runs inside a side-stream context in
+    eager mode and must not enter `torch.cuda.stream(None)` while Dynamo traces.  The backend below never executes the graph
+    (the kernels have no CPU form): it returns shape-faithful zeros from the fake-tensor metadata."""
+    from nequip_amd.nn.interaction_block import InteractionBlock
+
+    model, inputs = _model_and_data(torch.device("cpu"))
+    block = [m for m in model.modules() if isinstance(m, InteractionBlock) and m.sc is not None][0]
+    n, e = inputs["pos"].shape[0], inputs["edge_index"].shape[1]
+    irr = block.irreps_in
+    g = torch.Generator().manual_seed(0)
+    data = {
+        "node_features": torch.randn(n, irr["node_features"].dim, generator=g),
+        "node_attrs": torch.randn(n, irr["node_attrs"].dim, generator=g),
+        "edge_attrs": torch.randn(e, irr["edge_attrs"].dim, generator=g),
+        "edge_embedding": torch.randn(e, irr["edge_embedding"].dim, generator=g),
+        "edge_index": inputs["edge_index"], "atom_types": inputs["atom_types"], "pos": inputs["pos"],
+    }
+    graphs = []
+
+    def backend(gm, example_inputs):
+        graphs.append(gm)
+        outs = [nd for nd in gm.graph.nodes if nd.op == "output"][0].args[0]
+
+        def run(*args):
+            return tuple(torch.zeros([int(s) for s in o.meta["example_value"].shape], dtype=o.meta["example_value"].dtype)
+                         for o in outs)
+
+        return run
+
+    def f(d):
+        return block(dict(d))["node_features"]
+
+    out = torch.compile(f, backend=backend, dynamic=True, fullgraph=True)(data)
+    assert out.shape == (n, block.irreps_out["node_features"].dim)
+    targets = {str(nd.target) for gm in graphs for nd in gm.graph.nodes if nd.op == "call_function"}
+    assert any("tp_scatter_fwd" in t for t in targets), targets
