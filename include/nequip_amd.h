@@ -325,63 +325,24 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
              void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
- * nqa_node_chain: the node-side chain across one layer boundary in ONE launch (float32, inference):
- *     forward   h = linear_2(a) + sc_prev;  x' = Gate(h);  y = scale * linear_1'(x');  s = sc'(x', atom type)
- *     backward  g' = scale * linear_1'^T(g_y) + sc'^T(g_s);  g_h = Gate'(g', h);  g_a = linear_2^T(g_h)
- *   replacing e3nn `o3.Linear` (+ sc) -> `Gate` -> {`FullyConnectedTensorProduct`, `o3.Linear`} as they are called at
- *   the end of one InteractionBlock, in the ConvNetLayer and at the start of the next InteractionBlock
- *   (nequip/nn/interaction_block.py:175-177,201-204; nequip/nn/convnetlayer.py:156-170), i.e. three nqa_node_linear
- *   launches and one nqa_gate launch each way.
- *   The launch is a list of phases (phase p = chunks [phase_begin[p], phase_begin[p+1])); every workgroup runs all
- *   phases for its 16 atoms, with a device-scope fence in between, so phase p + 1 may read rows phase p wrote.
- *   chunk (32 bytes, DEVICE table): {int32 dst, o_off, d, mul_out, c0, instr_begin, instr_end, flags} -- one <= 64-channel
- *     chunk [c0, c0 + 64) of the mul_out x d output block at column o_off of destination `dst`; flags bit 0: add the
- *     destination's addend rows.
- *   instr (64 bytes, DEVICE table): {int32 src, x_off, mul_in, wset, w_off, kind, act, store_off; float scale, cst;
- *     int32 aux0, aux1, aux2, len, pad, pad} -- adds (scale * operand) @ W, W = the row-major [mul_in, mul_out] matrix at
- *     offset w_off of weight set `wset` (one per atom type when the set has n_types > 1), operand = a mul_in x d block of
- *     source `src` (u = channel, m = component), evaluated while it is staged:
- *       kind 0 plain        rows[x_off + u d + m]
- *       kind 1 gate fwd, scalar   act(rows[x_off + u])
- *       kind 2 gate fwd, gated    act(rows[aux0 + u]) * rows[x_off + u d + m]            (rows = the gate INPUT)
- *       kind 3 gate bwd, scalar   rows[aux1 + u] * act'(gate_input[x_off + u])          (rows = grad w.r.t. gate OUTPUT)
- *       kind 4 gate bwd, gated    act(gate_input[aux0 + u]) * rows[aux1 + u d + m]
- *       kind 5 gate bwd, gate     act'(gate_input[x_off + u]) * sum_{m<len} rows[aux1 + u len + m] gate_input[aux2 + u len + m]
- *     (act 0 identity, 1 silu, 2 tanh, times the e3nn normalize2mom constant cst -- the formulas of nqa_gate);
- *     store_off >= 0: the staged values are also written to the source's `store` rows at column store_off + u d + m (so
- *     that the gate-input gradient exists as a tensor for the self-connection of the layer below).
- *   All pointers are device pointers; chunks / instr are device tables built once per model.
+ * Split-bf16 form of nqa_node_linear (float32 tensors, default): the same maps -- e3nn `o3.Linear` / the type-contracted
+ *   `FullyConnectedTensorProduct` of nequip/nn/interaction_block.py:82-87,129-146,175-177,201 -- with every fp32 operand
+ *   written as the sum of three bf16 numbers and each product accumulated in fp32 from its six leading partial products on
+ *   v_mfma_f32_32x32x16_bf16 (fp32 accuracy at 2.7x the fp32-MFMA rate).
+ * nqa_node_weights_pack: weights [n_types][weight_stride] (the layout nqa_node_linear reads) -> `packed`
+ *   (nqa_node_weights_pack_bytes bytes): [type][instruction][16-row K block][32-column tile][plane hi/mid/lo][lane] of
+ *   16 bytes = 8 bf16 W[16 kb + 8 (lane >> 5) + e][32 tile + (lane & 31)], zero beyond the matrix.  Once per weight version.
+ * nqa_node_linear_packed: out = scale * sum_instr x_block @ W (+ addend), tables as for nqa_node_linear (chunks must
+ *   start at multiples of 64 channels); one 64-lane workgroup per (64-channel chunk, floor(32 / d) atoms) unit.
  * ------------------------------------------------------------------------------------------- */
-typedef struct nqa_chain_source {
-  const void* rows;
-  const void* gate_input;
-  void* store;
-  int32_t dim, gate_input_dim, store_dim, pad;
-} nqa_chain_source;
-typedef struct nqa_chain_dest {
-  void* rows;
-  const void* addend;
-  double scale;
-  int32_t dim, pad;
-} nqa_chain_dest;
-typedef struct nqa_chain_weights {
-  const void* data;
-  int64_t stride;
-  int32_t n_types, pad;
-} nqa_chain_weights;
-typedef struct nqa_chain_desc {
-  nqa_chain_source src[3];
-  nqa_chain_dest dst[3];
-  nqa_chain_weights weights[3];
-  const void* chunks;
-  const void* instr;
-  const int64_t* atom_types;
-  int64_t num_nodes;
-  int32_t phase_begin[4];
-  int32_t n_phases;
-  int32_t max_irrep_dim;
-} nqa_chain_desc;
-int nqa_node_chain(const nqa_chain_desc* desc, nqa_stream stream);
+int64_t nqa_node_weights_pack_bytes(const void* chunk_table, int32_t n_chunks, const void* instr_table, int32_t n_instr,
+                                    int32_t n_types);
+int nqa_node_weights_pack(const void* weights, const void* chunk_table, int32_t n_chunks, const void* instr_table,
+                          int32_t n_instr, int32_t n_types, int64_t weight_stride, void* packed, nqa_stream stream);
+int nqa_node_linear_packed(const void* x, const void* packed, const void* addend, void* out, const int64_t* atom_types,
+                           const void* chunk_table, int32_t n_chunks, const void* instr_table, int32_t n_instr,
+                           int32_t n_types, int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale,
+                           nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Paired radial weights.  InteractionBlock.edge_mlp (nequip/nn/interaction_block.py:119-127,190-192) is a function of

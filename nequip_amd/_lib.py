@@ -35,26 +35,6 @@ NQA_PLAN_HAS_SPECIALIZED = 7
 _P32 = POINTER(c_int32)
 
 
-# nqa_chain_desc of include/nequip_amd.h (nqa_node_chain)
-class ChainSource(ctypes.Structure):
-    _fields_ = [("rows", c_void_p), ("gate_input", c_void_p), ("store", c_void_p), ("dim", c_int32),
-                ("gate_input_dim", c_int32), ("store_dim", c_int32), ("pad", c_int32)]
-
-
-class ChainDest(ctypes.Structure):
-    _fields_ = [("rows", c_void_p), ("addend", c_void_p), ("scale", c_double), ("dim", c_int32), ("pad", c_int32)]
-
-
-class ChainWeights(ctypes.Structure):
-    _fields_ = [("data", c_void_p), ("stride", c_int64), ("n_types", c_int32), ("pad", c_int32)]
-
-
-class ChainDesc(ctypes.Structure):
-    _fields_ = [("src", ChainSource * 3), ("dst", ChainDest * 3), ("weights", ChainWeights * 3), ("chunks", c_void_p),
-                ("instr", c_void_p), ("atom_types", c_void_p), ("num_nodes", c_int64), ("phase_begin", c_int32 * 4),
-                ("n_phases", c_int32), ("max_irrep_dim", c_int32)]
-
-
 # name -> (restype, argtypes); must list every symbol include/nequip_amd.h declares
 SIGNATURES = {
     "nqa_abi_version": (c_int32, []),
@@ -194,13 +174,21 @@ SIGNATURES = {
         [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32]
         + [c_int64, c_int32, c_int32, c_int64, c_double, c_int32, c_void_p],
     ),
+    "nqa_node_weights_pack_bytes": (c_int64, [c_void_p, c_int32, c_void_p, c_int32, c_int32]),
+    "nqa_node_weights_pack": (
+        c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p],
+    ),
+    "nqa_node_linear_packed": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32]
+        + [c_int64, c_double, c_void_p],
+    ),
     "nqa_neighbor_list_workspace_bytes": (c_int64, [c_int64]),
     "nqa_neighbor_list_count": (
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "nqa_neighbor_list_fill": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
-    "nqa_node_chain": (c_int32, [POINTER(ChainDesc), c_void_p]),
     "nqa_gate": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],

@@ -16,10 +16,12 @@
 // sum_v W[u,v,w] emb[t,v]); AvgNumNeighborsNorm rides on linear_1 as the `scale` argument.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "plan.h"
 
@@ -177,54 +179,66 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const NodeLinearArgs<T
 }
 
 // ---- float32 on the matrix cores ---------------------------------------------------------------------------------
-// Transposed product  D[i = w][j = (z, m)] = sum_u A[i][u] B[u][j]  on v_mfma_f32_32x32x2_f32 (exact fp32):
-//   A[i = w][k = u]   = W_t[u][c0 + w]          weight slab, staged once per workgroup in LDS
-//   B[k = u][j = z,m] = x[z, x_off + u*d + m]    node-row slab, staged per wavefront in LDS
-// A workgroup owns one 64-channel chunk of one output irrep block; each of its 4 wavefronts owns floor(32/d) atoms
-// (their d components fill the 32 MFMA columns).  The loop runs over "stages" = (instruction, atom type, 64-channel
-// K slab): a stage's weight slab [64][64] is fetched coalesced by the whole workgroup (double-buffered in LDS,
-// requested one stage ahead into registers), its x slab -- for every atom one *contiguous* run of 64*d floats --
-// coalesced by the owning wavefront.  All MFMA operands then come from LDS with conflict-free strides, so HBM/L2
-// only ever sees full-line requests (the first version read x and wrote out as scattered dwords: 3-4x off the
-// roofline).  The result tile goes back through the wavefront's LDS slab and leaves as contiguous 64*d-float runs
-// per atom, fused with the scale and the optional addend (self-connection / residual).  Ragged edges (odd mul,
-// partial atom groups) are handled by zero-filled slabs and masked stores; for the per-type self-connection the
-// columns of atoms whose type differs from the staged weight set are zeroed in the B operand.
+// Transposed product  D[i = w][j = (z, m)] = sum_u A[i][u] B[u][j]:
+//   A[i = w][k = u]   = W_t[u][c0 + w]          weight rows
+//   B[k = u][j = z,m] = x[z, x_off + u*d + m]    node rows: for every atom one *contiguous* run of mul_in*d floats
+// A work unit owns one 64-channel chunk of one output irrep block for floor(32/d) atoms (their d components fill the 32
+// MFMA columns).  The loop runs over "stages" = (instruction, atom type, K slab); the x slab of a stage goes global ->
+// registers -> LDS with a padded per-atom stride (conflict-free operand reads), the result tile goes back through the
+// same slab and leaves as contiguous 64*d-float runs per atom, fused with the scale and the optional addend
+// (self-connection / residual).  Ragged edges (odd mul, partial atom groups) are handled by zero-filled slabs and masked
+// stores; for the per-type self-connection the columns of atoms whose type differs from the staged weight set are zeroed
+// in the B operand.
+// (Round 1-2 ran this as 4-wavefront workgroups with the weight slab staged in LDS and barriers around every stage --
+// `node_linear_mfma_kernel`, 225 VGPRs, 2 wavefronts per SIMD; the per-wavefront kernels below replaced it in round 3:
+// same time in exact fp32, 0-18 % faster with split-bf16 operands depending on the box)
 using f32x16n = __attribute__((ext_vector_type(16))) float;
 
-__device__ __forceinline__ void nl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 constexpr int kNLW = 64;                       // output channels per chunk (two 32-row MFMA tiles)
-constexpr int kNLK = 64;                       // input channels per stage
-constexpr int kNLXS = 32 * (kNLK + 1);         // floats per wavefront slab: NZT atoms x (64+1)*d, NZT*d <= 32
+constexpr int kNLXS = 32 * (kNLW + 1);         // floats per wavefront slab: NZT atoms x (64+1)*d, NZT*d <= 32
+
+// ---- float32 on the matrix cores, one independent pipeline per wavefront (v2) ---------------------------------------
+// Same product as node_linear_mfma_kernel -- D[i = w][j = (z, m)] = sum_u W_t[u][c0 + w] x[z, x_off + u d + m] on
+// v_mfma_f32_32x32x2_f32, bitwise the same fma chain -- organised for the small N of a single box (10^4 atoms = a few
+// thousand tiles) instead of for a large GEMM:
+//   * a work unit = (64-channel output chunk, floor(32/d) atoms) belongs to ONE wavefront (64-thread workgroups): no
+//     workgroup barrier anywhere, the hardware dispatcher balances the units over the SIMDs, and with <= 128 VGPRs and
+//     8.2 KiB of LDS per wavefront four of them share a SIMD -- while one waits for its operands the others own the
+//     matrix pipe (the v1 kernel: 2 wavefronts per SIMD, 225 VGPRs, 65 KiB LDS per 4-wavefront workgroup, barriers
+//     around every stage, MFMA pipe 30 % busy);
+//   * the weight fragment A[i = w][k = u] = W[u][c0 + w] is read straight from global memory / L2 in MFMA layout: the 32
+//     lanes of a half-wave read 32 consecutive floats of one weight row -- full 128-byte requests without any staging;
+//     batches of 8 k-steps are requested two batches ahead of the MFMAs that consume them;
+//   * the x slab (for every atom one contiguous run of 64 d floats) goes global -> registers -> the wavefront's private
+//     LDS slab (padded stride: conflict-free B-operand reads) and is requested one stage ahead; LDS operations of one
+//     wavefront complete in order, so no waits besides the data dependencies;
+//   * the result tile leaves through the same slab as contiguous runs, fused with scale and addend.
+// Units are enumerated chunk by chunk, chunks with the most stages first (the long units start first).
+constexpr int kNLK2 = 32;                      // input channels per stage of the per-wavefront kernel
 
 template <int D>
-__device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<float>& a, const NodeChunk& ch, int bx,
-                                                       int nblk, float* __restrict__ ws, float* __restrict__ xs_all) {
-  constexpr int NZT = 32 / D;                               // atoms per wavefront
-  // padded slab stride per atom.  Columns (zl, m) of a k-step read xs[zl*S + u*d + m]: conflict-free iff zl*S + m
-  // are distinct mod 32.  d > 1: S = 64*d + P with P the multiple of 4 >= d (also keeps rows 16-byte aligned for
-  // 128-bit LDS access); d = 1 (32 atoms): S = 65.
+__device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float>& a, const NodeChunk& ch, int64_t g,
+                                                      float* __restrict__ xs) {
+  constexpr int NZT = 32 / D;                               // atoms per unit
   constexpr int P = D == 1 ? 1 : ((D + 3) / 4) * 4;
-  constexpr int S = kNLK * D + P;
+  constexpr int S = kNLK2 * D + P;                           // padded slab stride per atom (see v1)
   constexpr bool kVecLds = (S % 4) == 0;
-  constexpr int RUN4 = kNLK * D / 4;                        // float4 per atom run (64*d floats)
+  constexpr int RUN4 = kNLK2 * D / 4;                       // float4 per atom run (32*d floats)
   constexpr int XV4 = (NZT * RUN4 + 63) / 64;               // float4 per lane per slab
+  constexpr int KB = 4;                                     // k-steps per weight batch
+  constexpr int NB = kNLK2 / 2 / KB;                         // batches per stage (4)
   static_assert(NZT * S <= kNLXS, "slab too small");
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
   const int half = lane >> 5, j = lane & 31;
   const int zlr = j / D, m = j - zlr * D;
-  const int zl = min(zlr, NZT - 1);                         // clamped for addressing
+  const int zl = min(zlr, NZT - 1);
   const int cw = min(kNLW, ch.mul_out - ch.c0);
-  // atom groups (4 wavefronts x NZT atoms) of this chunk are dealt round-robin to its nblk workgroups: a workgroup
-  // that owns several groups requests the first slab of the next group before the last MFMAs of the current one, so
-  // only its very first operand fetch is exposed
-  const int64_t ngroups = (a.N + 4 * NZT - 1) / (4 * NZT);
-  float* __restrict__ xs = xs_all + wv * kNLXS;
+  const int cj0 = min(j, cw - 1), cj1 = min(j + 32, cw - 1);  // clamped weight columns (rows >= cw are never stored)
+  const int64_t zbase = g * NZT;
+  const int64_t z = zbase + zl;
+  const bool col_ok = (zlr < NZT) && (z < a.N);
+  const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
 
-  // per-lane slab coordinates (loop invariant): float4 v of this lane belongs to atom xz[v], offset 4*xo4[v]
   int xz[XV4], xo[XV4];
 #pragma unroll
   for (int v = 0; v < XV4; ++v) {
@@ -232,12 +246,16 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
     xz[v] = idx / RUN4;
     xo[v] = (idx - xz[v] * RUN4) * 4;
   }
+  auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
 
   // stage enumeration: (instruction q, type t, K slab k0)
   int q = ch.instr_begin, t = 0, k0 = 0;
+  if (q >= ch.instr_end) {  // no instruction feeds this block: zeros (+ addend)
+    // falls through to the epilogue with zero accumulators
+  }
   NodeInstr ins = q < ch.instr_end ? a.instr[q] : NodeInstr{0, 0, 0, 0};
-  auto advance = [&]() {  // -> false when the stages of one atom group are exhausted
-    k0 += kNLK;
+  auto advance = [&]() {
+    k0 += kNLK2;
     if (k0 >= ins.mul_in) {
       k0 = 0;
       if (++t >= a.n_types) {
@@ -248,253 +266,553 @@ __device__ __forceinline__ void node_linear_mfma_block(const NodeLinearArgs<floa
     return q < ch.instr_end;
   };
 
-  float4 wreg[4];
+  // x slab of a stage: XV4 UNCONDITIONAL loads per lane from clamped (always valid) addresses -- no branch, no
+  // per-element predicate, so the requests of the next stage really stay in flight behind the MFMAs of the current one
+  // (with predicated loads the compiler merged the paths through register copies and waited for every load right
+  // where it was issued).  What lies outside the slab (atoms beyond N, channels beyond mul_in) is zeroed when the
+  // registers are written to LDS.
   float4 xreg[XV4];
-  // lanes of float4 slot v that map to a real atom run: all of them except possibly in the last slot
-  auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
-  auto load_stage = [&](const NodeInstr& si, int st, int sk0, int64_t zbase, bool with_w) {
-    // weight slab rows u = sk0 .. sk0+63, columns c0 .. c0+63 of W_t [mul_in][mul_out]
-    const float* __restrict__ wb = a.w + (int64_t)st * a.wstride + si.w_off + ch.c0;
-    const bool wal = ((ch.mul_out | ch.c0 | si.w_off) & 3) == 0 && (a.wstride & 3) == 0;
-    if (!with_w) {
-      // single-stage chunk: the weight slab staged for the first atom group serves all of them
-    } else if (wal && cw == kNLW && sk0 + kNLK <= si.mul_in) {
-      // common case (wave-uniform): full aligned slab, no per-element predication
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int idx = tid + v * 256;  // float4 index in the [64][16] slab
-        wreg[v] = *reinterpret_cast<const float4*>(wb + (int64_t)(sk0 + (idx >> 4)) * ch.mul_out + (idx & 15) * 4);
-      }
-    } else {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int idx = tid + v * 256;
-        const int u = idx >> 4, c4 = (idx & 15) * 4;
-        const int ug = sk0 + u;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ug < si.mul_in) {
-          const float* __restrict__ p = wb + (int64_t)ug * ch.mul_out + c4;
-          if (wal && c4 + 3 < cw) {
-            r = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (c4 + 0 < cw) r.x = p[0];
-            if (c4 + 1 < cw) r.y = p[1];
-            if (c4 + 2 < cw) r.z = p[2];
-            if (c4 + 3 < cw) r.w = p[3];
-          }
-        }
-        wreg[v] = r;
-      }
-    }
-    // x slab: atom zz contributes the contiguous run x[zz, x_off + sk0*d .. + 64*d) (zero beyond mul_in)
-    const int kk = min(kNLK, si.mul_in - sk0) * D;  // valid floats per atom
-    const bool xal = ((a.din | si.x_off) & 3) == 0;  // (sk0*d is a multiple of 64)
-    if (xal && kk == kNLK * D && zbase + NZT <= a.N) {
-      // common case (wave-uniform): aligned full runs of a complete atom group
-      const float* __restrict__ xb0 = a.x + zbase * a.din + si.x_off + sk0 * D;
+  int xkk = 0;  // valid floats per atom of the slab held in xreg
+  const bool xal_all = (a.din & 3) == 0;
+  auto load_x = [&](const NodeInstr& si, int sk0) {
+    const int kk = min(kNLK2, si.mul_in - sk0) * D;
+    xkk = kk;
+    const float* __restrict__ xb0 = a.x + si.x_off + sk0 * D;
+    if (xal_all && ((si.x_off | kk) & 3) == 0) {  // wave-uniform: aligned runs, whole float4s
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        if (slot_ok(v)) xreg[v] = *reinterpret_cast<const float4*>(xb0 + (int64_t)xz[v] * a.din + xo[v]);
+        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int eo = min(xo[v], kk - 4);
+        xreg[v] = *reinterpret_cast<const float4*>(xb0 + zg * a.din + eo);
       }
-    } else {
+    } else {  // odd multiplicities / unaligned blocks: dword loads, each clamped on its own
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = zbase + xz[v];
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (xz[v] < NZT && zg < a.N && xo[v] < kk) {
-          const float* __restrict__ p = a.x + zg * a.din + si.x_off + sk0 * D + xo[v];
-          if (xal && xo[v] + 3 < kk) {
-            r = *reinterpret_cast<const float4*>(p);
-          } else {
-            r.x = p[0];
-            if (xo[v] + 1 < kk) r.y = p[1];
-            if (xo[v] + 2 < kk) r.z = p[2];
-            if (xo[v] + 3 < kk) r.w = p[3];
-          }
-        }
-        xreg[v] = r;
+        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const float* __restrict__ p = xb0 + zg * a.din;
+        xreg[v].x = p[min(xo[v] + 0, kk - 1)];
+        xreg[v].y = p[min(xo[v] + 1, kk - 1)];
+        xreg[v].z = p[min(xo[v] + 2, kk - 1)];
+        xreg[v].w = p[min(xo[v] + 3, kk - 1)];
       }
     }
   };
-  auto store_stage = [&](int buf, bool with_w) {
-    if (with_w) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(ws + buf * (kNLK * kNLW) + (tid + v * 256) * 4) = wreg[v];
-    }
+  auto store_x = [&]() {
 #pragma unroll
     for (int v = 0; v < XV4; ++v) {
       if (slot_ok(v)) {
+        const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
+        float4 r;
+        r.x = (zok && xo[v] + 0 < xkk) ? xreg[v].x : 0.f;
+        r.y = (zok && xo[v] + 1 < xkk) ? xreg[v].y : 0.f;
+        r.z = (zok && xo[v] + 2 < xkk) ? xreg[v].z : 0.f;
+        r.w = (zok && xo[v] + 3 < xkk) ? xreg[v].w : 0.f;
         float* __restrict__ d = xs + xz[v] * S + xo[v];
         if constexpr (kVecLds) {
-          *reinterpret_cast<float4*>(d) = xreg[v];
+          *reinterpret_cast<float4*>(d) = r;
         } else {
-          d[0] = xreg[v].x; d[1] = xreg[v].y; d[2] = xreg[v].z; d[3] = xreg[v].w;
+          d[0] = r.x; d[1] = r.y; d[2] = r.z; d[3] = r.w;
         }
       }
     }
   };
 
   f32x16n acc0 = {0}, acc1 = {0};
-  const bool any_stage = q < ch.instr_end;
-  int64_t g = bx;
-  int64_t zbase = (g * 4 + wv) * NZT;  // first atom of this wavefront in the current group
-  bool have = true;
-  // one stage per group (one instruction, one type, K <= 64 -- every backward launch and linear_1): the weight slab is
-  // loop invariant, later groups re-stage only their wavefront-private x slab and need no workgroup barrier at all
-  const bool single_stage = any_stage && ch.instr_end - ch.instr_begin == 1 && a.n_types == 1 && ins.mul_in <= kNLK;
-  if (any_stage) {
-    if (!(a.dbg & 1)) load_stage(ins, t, k0, zbase, true);
-    store_stage(0, true);
-  }
-  __syncthreads();
-  int buf = 0;
+  bool have = q < ch.instr_end;
+  if (have) load_x(ins, k0);
   while (have) {
-    const int64_t z = zbase + zl;
-    const bool col_ok = (zlr < NZT) && (z < a.N);
-    const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
-    const int cur_t = t;
-    // what comes next: the following stage of this group, else the first stage of this workgroup's next group
-    bool last_of_group = !any_stage || !advance();
-    int64_t zbase_next = zbase;
-    bool next_valid = !last_of_group;
-    if (last_of_group) {
-      const int64_t gn = g + nblk;
-      if (gn < ngroups) {
-        g = gn;
-        zbase_next = (gn * 4 + wv) * NZT;
-        q = ch.instr_begin; t = 0; k0 = 0;
-        if (any_stage) ins = a.instr[q];
-        next_valid = true;
+    // ---- this stage: (ins, t, k0) -> cur; then look ahead
+    const NodeInstr cur = ins;
+    const int cur_t = t, cur_k0 = k0;
+    store_x();  // (waits for the slab's global loads; earlier B reads of this slab were issued before: in-order LDS)
+    have = advance();
+    const float* __restrict__ wb = a.w + (int64_t)cur_t * a.wstride + cur.w_off + ch.c0;
+    const int ulast = cur.mul_in - 1;
+    float a0[2][KB], a1[2][KB];
+    auto load_w = [&](int b, int buf) {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int u = min(cur_k0 + 2 * (b * KB + i) + half, ulast);  // (rows beyond mul_in meet zero-filled x)
+        const float* __restrict__ wr = wb + (int64_t)u * ch.mul_out;
+        a0[buf][i] = wr[cj0];
+        a1[buf][i] = wr[cj1];
       }
+    };
+    load_w(0, 0);
+    load_w(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (have) load_x(ins, k0);  // next stage's slab: lands behind this stage's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    const bool bsel = col_ok && (a.n_types == 1 || tzj == cur_t);
+    const float* __restrict__ xb = xs + zl * S + m;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float bq[KB];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) bq[i] = xb[(2 * (b * KB + i) + half) * D];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const float bv = bsel ? bq[i] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[b & 1][i], bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[b & 1][i], bv, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (b + 2 < NB) load_w(b + 2, b & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (next_valid && any_stage && !(a.dbg & 1)) load_stage(ins, t, k0, zbase_next, !single_stage);  // lands behind the MFMAs
-    if (any_stage) {
-      const bool bsel = col_ok && (a.n_types == 1 || tzj == cur_t);
-      const float* __restrict__ wsb = ws + buf * (kNLK * kNLW) + j;
-      const float* __restrict__ xb = xs + zl * S + m;
-      // LDS operand reads of the next register batch are issued between the MFMAs of the current one
-      constexpr int TB = 4;
-      float bq[2][TB], a0[2][TB], a1[2][TB];
+  }
+  // ---- epilogue: result tile -> slab as [atom][w*d + m] (64 channels: stride SE), then contiguous runs per atom
+  constexpr int SE = kNLW * D + P;
+  constexpr bool kVecE = (SE % 4) == 0;
+  constexpr int RUN4E = kNLW * D / 4;
+  constexpr int XV4E = (NZT * RUN4E + 63) / 64;
+  static_assert(NZT * SE <= kNLXS, "result slab too small");
+  if (zlr < NZT) {
 #pragma unroll
-      for (int i = 0; i < TB; ++i) {
-        const int u = 2 * i + half;
-        bq[0][i] = xb[u * D];
-        a0[0][i] = wsb[u * kNLW];
-        a1[0][i] = wsb[u * kNLW + 32];
-      }
-#pragma unroll
-      for (int b = 0; b < ((a.dbg & 2) ? 1 : kNLK / 2 / TB); ++b) {
-        if (b + 1 < kNLK / 2 / TB) {
-#pragma unroll
-          for (int i = 0; i < TB; ++i) {
-            const int u = 2 * ((b + 1) * TB + i) + half;
-            bq[(b + 1) & 1][i] = xb[u * D];
-            a0[(b + 1) & 1][i] = wsb[u * kNLW];
-            a1[(b + 1) & 1][i] = wsb[u * kNLW + 32];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TB; ++i) {
-          const float bv = bsel ? bq[b & 1][i] : 0.f;
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[b & 1][i], bv, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[b & 1][i], bv, acc1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      xs[zl * SE + wl * D + m] = acc0[r];
+      xs[zl * SE + (wl + 32) * D + m] = acc1[r];
     }
-    if (last_of_group) {
-      // result tile -> this wavefront's slab as [atom][w*d + m] (same padded stride), then contiguous runs per atom
-      // (the x slab is free: all MFMAs of the group are issued; same wavefront, LDS operations complete in order)
-      if (zlr < NZT && (!(a.dbg & 8) || acc0[0] == 12345.f)) {
+  }
+  const int run = cw * D;
+  const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
+  const bool fast = oal && cw == kNLW && zbase + NZT <= a.N && kVecE;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
-          xs[zl * S + wl * D + m] = acc0[r];
-          xs[zl * S + (wl + 32) * D + m] = acc1[r];
-        }
+  for (int v = 0; v < XV4E; ++v) {
+    const int idx = lane + v * 64;
+    const int ez = idx / RUN4E;
+    const int eo = (idx - ez * RUN4E) * 4;
+    const int64_t zg = zbase + ez;
+    if (ez >= NZT) continue;
+    const float* __restrict__ sp = xs + ez * SE + eo;
+    const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + eo;
+    if (fast) {
+      float4 r = *reinterpret_cast<const float4*>(sp);
+      r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+      if (a.addend != nullptr) {
+        const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+        r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
       }
-      acc0 = (f32x16n){0};
-      acc1 = (f32x16n){0};
-      const int run = cw * D;  // valid floats per atom
-      const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
-      if (oal && cw == kNLW && zbase + NZT <= a.N && kVecLds) {
-        // common case (wave-uniform): full aligned runs of a complete atom group
-        const int64_t ob = zbase * a.dout + ch.o_off + (int64_t)ch.c0 * D;
-#pragma unroll
-        for (int v = 0; v < XV4; ++v) {
-          if (slot_ok(v)) {
-            float4 r = *reinterpret_cast<const float4*>(xs + xz[v] * S + xo[v]);
-            const int64_t o = ob + (int64_t)xz[v] * a.dout + xo[v];
-            r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
-            if (a.addend != nullptr) {
-              const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
-              r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
-            }
-            if (!(a.dbg & 4) || r.x == 12345.f) *reinterpret_cast<float4*>(a.out + o) = r;
-          }
-        }
+      *reinterpret_cast<float4*>(a.out + o) = r;
+    } else if (zg < a.N && eo < run) {
+      float4 r;
+      if constexpr (kVecE) {
+        r = *reinterpret_cast<const float4*>(sp);
       } else {
-#pragma unroll
-        for (int v = 0; v < XV4; ++v) {
-          const int64_t zg = zbase + xz[v];
-          if (xz[v] < NZT && zg < a.N && xo[v] < run) {
-            const float* __restrict__ sp = xs + xz[v] * S + xo[v];
-            float4 r;
-            if constexpr (kVecLds) {
-              r = *reinterpret_cast<const float4*>(sp);
-            } else {
-              r = make_float4(sp[0], sp[1], sp[2], sp[3]);
-            }
-            const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + xo[v];
-            r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
-            if (oal && xo[v] + 3 < run) {
-              if (a.addend != nullptr) {
-                const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
-                r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
-              }
-              *reinterpret_cast<float4*>(a.out + o) = r;
-            } else {
-              const float rv[4] = {r.x, r.y, r.z, r.w};
-              for (int e = 0; e < 4; ++e)
-                if (xo[v] + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
-            }
-          }
+        r = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      }
+      r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+      if (oal && eo + 3 < run) {
+        if (a.addend != nullptr) {
+          const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+          r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
         }
-      }
-    }
-    if (next_valid && any_stage) {
-      if (single_stage) {
-        store_stage(buf, false);  // wavefront-private slab: in-order LDS, no barrier
+        *reinterpret_cast<float4*>(a.out + o) = r;
       } else {
-        // LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain vmcnt, i.e. wait for
-        // the result stores just issued (CDNA4 counts stores in vmcnt) at every group boundary
-        if (!(a.dbg & 16)) nl_lds_barrier();  // all wavefronts are done with ws[buf ^ 1] and with their own slab
-        if (!(a.dbg & 32)) store_stage(buf ^ 1, true);
-        if (!(a.dbg & 16)) nl_lds_barrier();
-        buf ^= 1;
+        const float rv[4] = {r.x, r.y, r.z, r.w};
+        for (int e = 0; e < 4; ++e)
+          if (eo + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
       }
     }
-    zbase = zbase_next;
-    have = next_valid;
   }
 }
 
-__global__ __launch_bounds__(256, 2) void node_linear_mfma_kernel(const NodeLinearArgs<float> a) {
-  __shared__ __align__(16) float ws[2 * kNLK * kNLW];  // 32 KiB: double-buffered weight slab
-  __shared__ __align__(16) float xs[4 * kNLXS];        // 4 x 8.1 KiB: per-wavefront x / result slabs
-  // exact 1-D grid: chunk c owns workgroups [blk_begin[c], blk_begin[c+1])
+__global__ __launch_bounds__(64, 4) void node_linear_wave_kernel(const NodeLinearArgs<float> a) {
+  __shared__ __align__(16) float xs[kNLXS];  // staging slab (32-channel K slabs) and, at the end, the 64-channel result tile
+  // exact 1-D grid: chunk c owns the units [blk_begin[c], blk_begin[c+1]) (one unit = one wavefront = one workgroup)
   int c = 0;
   while (c + 1 < a.n_chunks && (int)blockIdx.x >= a.blk_begin[c + 1]) ++c;
   const NodeChunk ch = a.chunks[c];
-  const int bx = (int)blockIdx.x - a.blk_begin[c];
-  const int nblk = a.blk_begin[c + 1] - a.blk_begin[c];
+  const int64_t g = (int64_t)((int)blockIdx.x - a.blk_begin[c]);
   switch (ch.d) {
-    case 1: node_linear_mfma_block<1>(a, ch, bx, nblk, ws, xs); break;
-    case 3: node_linear_mfma_block<3>(a, ch, bx, nblk, ws, xs); break;
-    case 5: node_linear_mfma_block<5>(a, ch, bx, nblk, ws, xs); break;
-    case 7: node_linear_mfma_block<7>(a, ch, bx, nblk, ws, xs); break;
-    case 9: node_linear_mfma_block<9>(a, ch, bx, nblk, ws, xs); break;
+    case 1: node_linear_wave_unit<1>(a, ch, g, xs); break;
+    case 3: node_linear_wave_unit<3>(a, ch, g, xs); break;
+    case 5: node_linear_wave_unit<5>(a, ch, g, xs); break;
+    case 7: node_linear_wave_unit<7>(a, ch, g, xs); break;
+    case 9: node_linear_wave_unit<9>(a, ch, g, xs); break;
+    default: break;
+  }
+}
+
+// ---- float32 accuracy on the bf16 matrix pipe (split operands), per-wavefront pipeline (v3) -------------------------
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector rate -- 64 FLOP/clk/SIMD, ~125 TFLOP/s at the clock the chip
+// sustains with real operands -- and the per-wavefront kernel above is bound by exactly that pipe (timeline: 75-80 % busy
+// in steady state; 3.4 GFLOP of the cfg-3 linear_2 cannot take less than ~30 us, the 12672 -> 2432 map of the l_max = 3
+// model not less than 0.9 ms per 20 000 atoms).  As in the radial MLP (radial_mlp.hip, second half) every fp32 operand is
+// written as the exact sum of three bf16 numbers and a product is accumulated in fp32 from the six partial products of
+// weight >= 2^-16 on v_mfma_f32_32x32x16_bf16: 6 instructions x 32 cycles per 32x32x16 block instead of 8 x 64.
+//   * weights: split and laid out in A-fragment order ONCE per weight version by nqa_node_weights_pack
+//     (Wf[type][instr][k16][col tile][plane][lane] = 8 bf16 of W[16 k16 + 8 (lane >> 5) + e][32 tile + (lane & 31)]):
+//     one 1 KiB wave read per fragment, straight from L2 into the MFMA operand registers;
+//   * x: staged through the wavefront's LDS slab as before; the 8 k-values of a lane are read from the slab and split
+//     in registers (11 VALU per pair of values);
+//   * the rest (units, enumeration, epilogue) is the per-wavefront kernel above.
+__device__ __forceinline__ uint32_t nl_cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));  // round-to-nearest-even, lo -> bits [15:0]
+  return r;
+}
+__device__ __forceinline__ void nl_split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = nl_cvt_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(h << 16);
+  float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = nl_cvt_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(m << 16);
+  r1 -= __uint_as_float(m & 0xffff0000u);
+  l = nl_cvt_pk_bf16(r0, r1);
+}
+using nl_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using nl_u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+__device__ __forceinline__ f32x16n nl_mfma_bf16(const nl_u32x4& a, const nl_u32x4& b, const f32x16n& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nl_bf16x8, a), __builtin_bit_cast(nl_bf16x8, b), c,
+                                                 0, 0, 0);
+}
+
+struct NodePackArgs {
+  const float* __restrict__ w;  // [n_types][wstride]
+  nl_u32x4* __restrict__ out;   // [n_types][frag_stride]
+  int64_t wstride, frag_stride;
+  int32_t n_instr, n_types;
+  int32_t mul_in[kMaxNodeInstr], mul_out[kMaxNodeInstr], w_off[kMaxNodeInstr];
+  int32_t frag_off[kMaxNodeInstr + 1];  // first fragment-lane (uint4 index) of every instruction, within one type
+};
+
+__global__ __launch_bounds__(256) void node_weights_pack_kernel(const NodePackArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (type, fragment (q, k16, tile), lane)
+  const int64_t per_type = a.frag_stride / 3;                    // one thread writes the three planes
+  if (idx >= per_type * a.n_types) return;
+  const int t = (int)(idx / per_type);
+  const int64_t r = idx - (int64_t)t * per_type;
+  int q = 0;
+  while (q + 1 < a.n_instr && r * 3 >= a.frag_off[q + 1]) ++q;
+  const int64_t f = r - a.frag_off[q] / 3;  // (k16 * nct + tile) * 64 + lane
+  const int lane = (int)(f & 63);
+  const int nct = (a.mul_out[q] + 31) / 32;
+  const int tile = (int)((f >> 6) % nct), k16 = (int)((f >> 6) / nct);
+  const int c = 32 * tile + (lane & 31);
+  const int u0 = 16 * k16 + 8 * (lane >> 5);
+  const float* __restrict__ wq = a.w + (int64_t)t * a.wstride + a.w_off[q];
+  nl_u32x4 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int u = u0 + 2 * e;
+    const float v0 = (c < a.mul_out[q] && u < a.mul_in[q]) ? wq[(int64_t)u * a.mul_out[q] + c] : 0.f;
+    const float v1 = (c < a.mul_out[q] && u + 1 < a.mul_in[q]) ? wq[(int64_t)(u + 1) * a.mul_out[q] + c] : 0.f;
+    uint32_t x, y, z;
+    nl_split_pair(v0, v1, x, y, z);
+    h[e] = x; m[e] = y; l[e] = z;
+  }
+  nl_u32x4* __restrict__ o = a.out + (int64_t)t * a.frag_stride + a.frag_off[q] + ((f >> 6) * 3) * 64 + lane;
+  o[0] = h; o[64] = m; o[128] = l;
+}
+
+struct NodeLinearPackedArgs {
+  NodeLinearArgs<float> base;            // base.w is unused
+  const nl_u32x4* __restrict__ wf;       // packed weights
+  int64_t frag_stride;                   // uint4 per atom type
+  int32_t frag_off[kMaxNodeInstr];       // uint4 offset of every instruction's fragments
+  // unit enumeration: a group = the 64-channel chunks of ONE output block (same instructions, same x columns); unit u of a
+  // group is (atom group u / n, chunk u % n) -- the chunks that read the same x slab run next to each other (same
+  // workgroup / neighbouring workgroups), so the slab comes out of L1 / L2 for all but the first of them
+  int32_t n_groups;
+  int32_t grp_begin[kMaxNodeChunks + 1];  // first unit of every group
+  int32_t grp_chunk0[kMaxNodeChunks];     // first chunk of the group in base.chunks
+  int32_t grp_n[kMaxNodeChunks];          // chunks in the group
+};
+
+constexpr int kNLK3 = 32;  // input channels per stage of the split-bf16 kernel (64-channel slabs were measured: 148 spilled registers, slower)
+
+struct NodeStage {  // one (instruction, atom type, 32-channel K slab) step of a chunk
+  int q, t, k0, mul_in, x_off;
+  bool valid;
+};
+
+template <int D>
+__device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPackedArgs& pa, const NodeChunk& ch, int64_t g,
+                                                           float* __restrict__ xs, int unit) {
+  const NodeLinearArgs<float>& a = pa.base;
+  constexpr int NZT = 32 / D;
+  constexpr int P = D == 1 ? 1 : ((D + 3) / 4) * 4;
+  constexpr int S = kNLK3 * D + P;
+  constexpr bool kVecLds = (S % 4) == 0;
+  constexpr int RUN4 = kNLK3 * D / 4;
+  constexpr int XV4 = (NZT * RUN4 + 63) / 64;
+  static_assert(NZT * S <= kNLXS, "slab too small");
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, j = lane & 31;
+  const int zlr = j / D, m = j - zlr * D;
+  const int zl = min(zlr, NZT - 1);
+  const int cw = min(kNLW, ch.mul_out - ch.c0);
+  const int64_t zbase = g * NZT;
+  const int64_t z = zbase + zl;
+  const bool col_ok = (zlr < NZT) && (z < a.N);
+  const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
+  const int nct = (ch.mul_out + 31) / 32;   // column tiles of the whole output block
+  const int ct0 = ch.c0 / 32;               // first tile of this chunk (c0 is a multiple of 64)
+  const bool two_tiles = cw > 32;           // wave-uniform
+
+  int xz[XV4], xo[XV4];
+#pragma unroll
+  for (int v = 0; v < XV4; ++v) {
+    const int idx = lane + v * 64;
+    xz[v] = idx / RUN4;
+    xo[v] = (idx - xz[v] * RUN4) * 4;
+  }
+  auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
+
+  // stage enumeration
+  auto first_stage = [&]() {
+    NodeStage st{ch.instr_begin, 0, 0, 0, 0, ch.instr_begin < ch.instr_end};
+    if (st.valid) {
+      st.mul_in = a.instr[st.q].mul_in;
+      st.x_off = a.instr[st.q].x_off;
+    }
+    return st;
+  };
+  auto next_stage = [&](NodeStage st) {
+    if (!st.valid) return st;
+    st.k0 += kNLK3;
+    if (st.k0 >= st.mul_in) {
+      st.k0 = 0;
+      if (++st.t >= a.n_types) {
+        st.t = 0;
+        if (++st.q < ch.instr_end) {
+          st.mul_in = a.instr[st.q].mul_in;
+          st.x_off = a.instr[st.q].x_off;
+        } else {
+          st.valid = false;
+        }
+      }
+    }
+    return st;
+  };
+
+  // x slab of a stage: XV4 UNCONDITIONAL loads per lane from clamped (always valid) addresses; what lies outside the
+  // slab is zeroed when the registers go to LDS.  TWO slabs are kept in flight per wavefront (the stage being computed is
+  // in LDS, the next two are on their way): the loaded latency of these 128 d-byte row pieces is 2-6 us (timeline:
+  // first slab in LDS 7 k cycles after the unit starts), and with one 4 KiB slab in flight per wavefront the whole
+  // kernel ran at latency x occupancy = 2.4 TB/s.
+  const bool xal_all = (a.din & 3) == 0;
+  auto load_x = [&](float4 (&xr)[XV4], const NodeStage& st) {
+    const int kk = min(kNLK3, st.mul_in - st.k0) * D;
+    const float* __restrict__ xb0 = a.x + st.x_off + st.k0 * D;
+    if (xal_all && ((st.x_off | kk) & 3) == 0) {
+#pragma unroll
+      for (int v = 0; v < XV4; ++v) {
+        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int eo = min(xo[v], kk - 4);
+        xr[v] = *reinterpret_cast<const float4*>(xb0 + zg * a.din + eo);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < XV4; ++v) {
+        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const float* __restrict__ p = xb0 + zg * a.din;
+        xr[v].x = p[min(xo[v] + 0, kk - 1)];
+        xr[v].y = p[min(xo[v] + 1, kk - 1)];
+        xr[v].z = p[min(xo[v] + 2, kk - 1)];
+        xr[v].w = p[min(xo[v] + 3, kk - 1)];
+      }
+    }
+  };
+  auto store_x = [&](const float4 (&xr)[XV4], const NodeStage& st) {
+    const int xkk = min(kNLK3, st.mul_in - st.k0) * D;
+#pragma unroll
+    for (int v = 0; v < XV4; ++v) {
+      if (slot_ok(v)) {
+        const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
+        float4 r;
+        r.x = (zok && xo[v] + 0 < xkk) ? xr[v].x : 0.f;
+        r.y = (zok && xo[v] + 1 < xkk) ? xr[v].y : 0.f;
+        r.z = (zok && xo[v] + 2 < xkk) ? xr[v].z : 0.f;
+        r.w = (zok && xo[v] + 3 < xkk) ? xr[v].w : 0.f;
+        float* __restrict__ d = xs + xz[v] * S + xo[v];
+        if constexpr (kVecLds) {
+          *reinterpret_cast<float4*>(d) = r;
+        } else {
+          d[0] = r.x; d[1] = r.y; d[2] = r.z; d[3] = r.w;
+        }
+      }
+    }
+  };
+
+  // A fragments of one 16-row K block for the two column tiles of this chunk (3 planes each): requested for the first K
+  // block of the slab at the top of the stage, for the second one right after the MFMAs of the first have been issued
+  // (a stage whose slab holds 16 channels or fewer -- multiplicities that are not multiples of 32 -- repeats its block
+  // with B = 0: branch-free, wasted work only for such shapes).  They come out of the L2 (all wavefronts of a chunk read
+  // the same 12 KiB per stage) and land behind the LDS write / B split; double-buffering them (measured) buys nothing.
+  nl_u32x4 Af[1][2][3];
+  auto load_a = [&](int buf, const NodeStage& st, int k16) {
+    const nl_u32x4* __restrict__ p = pa.wf + (int64_t)st.t * pa.frag_stride + pa.frag_off[st.q] + lane +
+                                     ((int64_t)(k16 * nct + ct0) * 3) * 64;
+    Af[buf][0][0] = p[0]; Af[buf][0][1] = p[64]; Af[buf][0][2] = p[128];
+    if (two_tiles) { Af[buf][1][0] = p[192]; Af[buf][1][1] = p[256]; Af[buf][1][2] = p[320]; }
+  };
+  f32x16n acc0 = {0}, acc1 = {0};
+  auto block = [&](int buf, int s, bool on) {
+    // B fragment: the 8 k-values 16 s + 8 half + e of this lane's column, split in registers
+    const float* __restrict__ xb = xs + zl * S + m;
+    float bq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bq[e] = xb[(16 * s + 8 * half + e) * D];
+    nl_u32x4 Bh, Bm, Bl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = on ? bq[2 * e] : 0.f, v1 = on ? bq[2 * e + 1] : 0.f;
+      uint32_t x, y, zz;
+      nl_split_pair(v0, v1, x, y, zz);
+      Bh[e] = x; Bm[e] = y; Bl[e] = zz;
+    }
+    // six partial products per tile, smallest first (hi.lo, lo.hi, mid.mid, mid.hi, hi.mid, hi.hi); the two tiles
+    // alternate so that consecutive MFMAs never wait for each other's accumulator
+    if (two_tiles) {
+      acc0 = nl_mfma_bf16(Af[buf][0][0], Bl, acc0);
+      acc1 = nl_mfma_bf16(Af[buf][1][0], Bl, acc1);
+      acc0 = nl_mfma_bf16(Af[buf][0][2], Bh, acc0);
+      acc1 = nl_mfma_bf16(Af[buf][1][2], Bh, acc1);
+      acc0 = nl_mfma_bf16(Af[buf][0][1], Bm, acc0);
+      acc1 = nl_mfma_bf16(Af[buf][1][1], Bm, acc1);
+      acc0 = nl_mfma_bf16(Af[buf][0][1], Bh, acc0);
+      acc1 = nl_mfma_bf16(Af[buf][1][1], Bh, acc1);
+      acc0 = nl_mfma_bf16(Af[buf][0][0], Bm, acc0);
+      acc1 = nl_mfma_bf16(Af[buf][1][0], Bm, acc1);
+      acc0 = nl_mfma_bf16(Af[buf][0][0], Bh, acc0);
+      acc1 = nl_mfma_bf16(Af[buf][1][0], Bh, acc1);
+    } else {
+      acc0 = nl_mfma_bf16(Af[buf][0][0], Bl, acc0);
+      acc0 = nl_mfma_bf16(Af[buf][0][2], Bh, acc0);
+      acc0 = nl_mfma_bf16(Af[buf][0][1], Bm, acc0);
+      acc0 = nl_mfma_bf16(Af[buf][0][1], Bh, acc0);
+      acc0 = nl_mfma_bf16(Af[buf][0][0], Bm, acc0);
+      acc0 = nl_mfma_bf16(Af[buf][0][0], Bh, acc0);
+    }
+  };
+
+  int nst = 0;
+  const bool tl = (a.dbg & 64) != 0;
+  unsigned* tl_dst = reinterpret_cast<unsigned*>(a.out) + (int64_t)unit * 16;
+  unsigned long long tl_t0 = 0;
+  auto stamp = [&]() {
+    if (nst < 13) {
+      const unsigned long long tt = __builtin_readcyclecounter();
+      if (nst == 0) tl_t0 = tt;
+      if (lane == 0) tl_dst[1 + nst] = nst == 0 ? (unsigned)(tt & 0xffffffffu) : (unsigned)(tt - tl_t0);
+      ++nst;
+    }
+  };
+  if (tl) stamp();
+
+  // one stage: slab registers -> LDS, request the next slab into the same registers, then the K blocks of the slab
+  float4 xr0[XV4];
+  NodeStage cur = first_stage();
+  NodeStage ld = cur;  // the stage whose slab is requested next
+  if (ld.valid) { load_x(xr0, ld); ld = next_stage(ld); }
+  while (cur.valid) {
+    store_x(xr0, cur);
+    if (tl) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(); }
+    const int k16a = cur.k0 >> 4;
+    load_a(0, cur, k16a);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ld.valid) { load_x(xr0, ld); ld = next_stage(ld); }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool bsel = col_ok && (a.n_types == 1 || tzj == cur.t);
+#pragma unroll
+    for (int s16 = 0; s16 < kNLK3 / 16; ++s16) {
+      const bool exists = cur.k0 + 16 * s16 < cur.mul_in;  // (wave-uniform; a missing block repeats the last one with B = 0)
+      block(0, s16, bsel && exists);
+      if (s16 + 1 < kNLK3 / 16) {
+        __builtin_amdgcn_sched_barrier(0);
+        const bool nexists = cur.k0 + 16 * (s16 + 1) < cur.mul_in;
+        load_a(0, cur, nexists ? k16a + s16 + 1 : k16a);  // (same registers: the MFMAs above have read them)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    cur = next_stage(cur);
+  }
+  if (tl) {
+    stamp();
+    if (lane == 0) tl_dst[0] = (unsigned)nst;
+    return;
+  }
+  // ---- epilogue (as in node_linear_wave_unit)
+  constexpr int SE = kNLW * D + P;
+  constexpr bool kVecE = (SE % 4) == 0;
+  constexpr int RUN4E = kNLW * D / 4;
+  constexpr int XV4E = (NZT * RUN4E + 63) / 64;
+  static_assert(NZT * SE <= kNLXS, "result slab too small");
+  if (zlr < NZT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int wl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      xs[zl * SE + wl * D + m] = acc0[r];
+      xs[zl * SE + (wl + 32) * D + m] = acc1[r];
+    }
+  }
+  const int run = cw * D;
+  const bool oal = ((a.dout | ch.o_off | (ch.c0 * D)) & 3) == 0;
+  const bool fast = oal && cw == kNLW && zbase + NZT <= a.N && kVecE;
+#pragma unroll
+  for (int v = 0; v < XV4E; ++v) {
+    const int idx = lane + v * 64;
+    const int ez = idx / RUN4E;
+    const int eo = (idx - ez * RUN4E) * 4;
+    const int64_t zg = zbase + ez;
+    if (ez >= NZT) continue;
+    const float* __restrict__ sp = xs + ez * SE + eo;
+    const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + eo;
+    if (fast) {
+      float4 r = *reinterpret_cast<const float4*>(sp);
+      r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+      if (a.addend != nullptr) {
+        const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+        r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+      }
+      *reinterpret_cast<float4*>(a.out + o) = r;
+    } else if (zg < a.N && eo < run) {
+      float4 r;
+      if constexpr (kVecE) {
+        r = *reinterpret_cast<const float4*>(sp);
+      } else {
+        r = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      }
+      r.x *= a.scale; r.y *= a.scale; r.z *= a.scale; r.w *= a.scale;
+      if (oal && eo + 3 < run) {
+        if (a.addend != nullptr) {
+          const float4 ad = *reinterpret_cast<const float4*>(a.addend + o);
+          r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+        }
+        *reinterpret_cast<float4*>(a.out + o) = r;
+      } else {
+        const float rv[4] = {r.x, r.y, r.z, r.w};
+        for (int e = 0; e < 4; ++e)
+          if (eo + e < run) a.out[o + e] = rv[e] + (a.addend != nullptr ? a.addend[o + e] : 0.f);
+      }
+    }
+  }
+}
+
+constexpr int kNLWavesPerWG = 4;  // independent wavefronts (units) per workgroup: no barrier, only fewer dispatches
+
+__global__ __launch_bounds__(64 * kNLWavesPerWG, 3) void node_linear_wave_bf16_kernel(const NodeLinearPackedArgs pa) {
+  __shared__ __align__(16) float xs_all[kNLWavesPerWG * kNLXS];
+  const NodeLinearArgs<float>& a = pa.base;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int unit = (int)blockIdx.x * kNLWavesPerWG + wv;
+  if (unit >= pa.grp_begin[pa.n_groups]) return;
+  float* xs = xs_all + wv * kNLXS;
+  int gi = 0;
+  while (gi + 1 < pa.n_groups && unit >= pa.grp_begin[gi + 1]) ++gi;
+  const int local = unit - pa.grp_begin[gi];
+  const int n = pa.grp_n[gi];
+  const NodeChunk ch = a.chunks[pa.grp_chunk0[gi] + local % n];
+  const int64_t g = (int64_t)(local / n);
+  switch (ch.d) {
+    case 1: node_linear_wave_bf16_unit<1>(pa, ch, g, xs, unit); break;
+    case 3: node_linear_wave_bf16_unit<3>(pa, ch, g, xs, unit); break;
+    case 5: node_linear_wave_bf16_unit<5>(pa, ch, g, xs, unit); break;
+    case 7: node_linear_wave_bf16_unit<7>(pa, ch, g, xs, unit); break;
+    case 9: node_linear_wave_bf16_unit<9>(pa, ch, g, xs, unit); break;
     default: break;
   }
 }
@@ -757,36 +1075,39 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
       a.dbg = dbg;
     }
     if (use_mfma) {
-      // atom groups per workgroup: enough workgroups to fill the chip a few times over, few enough that each
-      // amortises its first (exposed) operand fetch over several groups
-      int64_t total_groups = 0;
+      // per-wavefront kernel: one 64-thread workgroup per (chunk, floor(32/d) atoms) unit; chunks with the most stages
+      // (instruction x type x 32-channel K slab) first, so that the long units are dispatched first
+      int order[kMaxNodeChunks];
+      int stages[kMaxNodeChunks];
       for (int c = 0; c < n_chunks; ++c) {
         const int d = a.chunks[c].d;
         if (d != 1 && d != 3 && d != 5 && d != 7 && d != 9) {
           set_error("nqa_node_linear: irrep dimension above 9 (l > 4)");
           return NQA_ERR_UNSUPPORTED;
         }
-        const int per_grp = 4 * (32 / d);
-        total_groups += (num_nodes + per_grp - 1) / per_grp;
+        int st = 0;
+        for (int q = a.chunks[c].instr_begin; q < a.chunks[c].instr_end; ++q)
+          st += n_types * ((a.instr[q].mul_in + kNLK2 - 1) / kNLK2);
+        stages[c] = st;
+        order[c] = c;
       }
-      static const int gpb_env = [] {
-        const char* e = std::getenv("NQA_NODE_GPB");
-        return e ? std::atoi(e) : 0;
-      }();
-      int64_t gpb = gpb_env > 0 ? gpb_env : (total_groups + 1023) / 1024;
-      if (gpb < 1) gpb = 1;
-      if (gpb > 8) gpb = 8;
+      std::stable_sort(order, order + n_chunks, [&](int l, int r) { return stages[l] > stages[r]; });
+      NodeChunk sorted[kMaxNodeChunks];
+      for (int c = 0; c < n_chunks; ++c) sorted[c] = a.chunks[order[c]];
       int64_t nblk = 0;
       for (int c = 0; c < n_chunks; ++c) {
+        a.chunks[c] = sorted[c];
         a.blk_begin[c] = (int32_t)nblk;
-        const int per_grp = 4 * (32 / a.chunks[c].d);
-        const int64_t groups = (num_nodes + per_grp - 1) / per_grp;
-        nblk += (groups + gpb - 1) / gpb;
+        const int per_unit = 32 / a.chunks[c].d;
+        nblk += (num_nodes + per_unit - 1) / per_unit;
       }
       a.blk_begin[n_chunks] = (int32_t)nblk;
+      if (nblk > 2147483647LL) {
+        set_error("nqa_node_linear: too many work units for one launch");
+        return NQA_ERR_UNSUPPORTED;
+      }
       if (nblk == 0) return NQA_OK;
-      const dim3 mgrid((unsigned)nblk);
-      hipLaunchKernelGGL(node_linear_mfma_kernel, mgrid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(node_linear_wave_kernel, dim3((unsigned)nblk), dim3(64), 0, s, a);
     } else {
       if (smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(node_linear_kernel<float>),
@@ -817,6 +1138,177 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
   err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_node_linear: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+// ---- packed (split-bf16) weights ------------------------------------------------------------------------------------
+namespace {
+// fragment layout of one atom type: per instruction ceil(mul_in / 16) x ceil(mul_out / 32) fragments of 3 planes x 64 lanes
+// (uint4 each); mul_out is that of the output block the instruction feeds.  Returns the uint4 count per type, -1 on error.
+int64_t node_frag_layout(const nqa::NodeChunk* chunks, int32_t n_chunks, const nqa::NodeInstr* instr, int32_t n_instr,
+                         int32_t* frag_off, int32_t* mul_out) {
+  for (int q = 0; q < n_instr; ++q) mul_out[q] = 0;
+  for (int c = 0; c < n_chunks; ++c)
+    for (int q = chunks[c].instr_begin; q < chunks[c].instr_end; ++q) {
+      if (q < 0 || q >= n_instr) return -1;
+      mul_out[q] = chunks[c].mul_out;
+    }
+  int64_t off = 0;
+  for (int q = 0; q < n_instr; ++q) {
+    frag_off[q] = (int32_t)off;
+    off += (int64_t)((instr[q].mul_in + 15) / 16) * ((mul_out[q] + 31) / 32) * 3 * 64;
+    if (off > 2147483647LL) return -1;
+  }
+  frag_off[n_instr] = (int32_t)off;
+  return off;
+}
+}  // namespace
+
+int64_t nqa_node_weights_pack_bytes(const void* chunk_table, int32_t n_chunks, const void* instr_table, int32_t n_instr,
+                                    int32_t n_types) {
+  if (n_instr < 0 || n_instr > nqa::kMaxNodeInstr || n_chunks < 0 || n_types < 1 || (n_chunks > 0 && !chunk_table) ||
+      (n_instr > 0 && !instr_table))
+    return -1;
+  int32_t frag_off[nqa::kMaxNodeInstr + 1], mul_out[nqa::kMaxNodeInstr];
+  const int64_t per_type = node_frag_layout(static_cast<const nqa::NodeChunk*>(chunk_table), n_chunks,
+                                            static_cast<const nqa::NodeInstr*>(instr_table), n_instr, frag_off, mul_out);
+  return per_type < 0 ? -1 : per_type * 16 * n_types;
+}
+
+int nqa_node_weights_pack(const void* weights, const void* chunk_table, int32_t n_chunks, const void* instr_table,
+                          int32_t n_instr, int32_t n_types, int64_t weight_stride, void* packed, nqa_stream stream) {
+  using namespace nqa;
+  if (n_instr < 0 || n_instr > kMaxNodeInstr || n_chunks < 0 || n_types < 1 || !weights || !packed ||
+      (n_chunks > 0 && !chunk_table) || (n_instr > 0 && !instr_table)) {
+    set_error("nqa_node_weights_pack: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  NodePackArgs a{};
+  const NodeInstr* instr = static_cast<const NodeInstr*>(instr_table);
+  const int64_t per_type = node_frag_layout(static_cast<const NodeChunk*>(chunk_table), n_chunks, instr, n_instr,
+                                            a.frag_off, a.mul_out);
+  if (per_type < 0) {
+    set_error("nqa_node_weights_pack: inconsistent tables");
+    return NQA_ERR_INVALID;
+  }
+  if (per_type == 0) return NQA_OK;
+  for (int q = 0; q < n_instr; ++q) {
+    a.mul_in[q] = instr[q].mul_in;
+    a.w_off[q] = instr[q].w_off;
+  }
+  a.w = static_cast<const float*>(weights);
+  a.out = static_cast<nl_u32x4*>(packed);
+  a.wstride = weight_stride;
+  a.frag_stride = per_type;
+  a.n_instr = n_instr;
+  a.n_types = n_types;
+  const int64_t threads = per_type / 3 * n_types;
+  hipLaunchKernelGGL(node_weights_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_node_weights_pack: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_node_linear_packed(const void* x, const void* packed, const void* addend, void* out, const int64_t* atom_types,
+                           const void* chunk_table, int32_t n_chunks, const void* instr_table, int32_t n_instr,
+                           int32_t n_types, int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale,
+                           nqa_stream stream) {
+  using namespace nqa;
+  if (n_instr < 0 || n_instr > kMaxNodeInstr || num_nodes < 0 || n_chunks < 0 || n_types < 1 || dim_in <= 0 ||
+      dim_out <= 0 || (num_nodes > 0 && (!x || !packed || !out || !chunk_table || (n_instr > 0 && !instr_table))) ||
+      (n_types > 1 && atom_types == nullptr)) {
+    set_error("nqa_node_linear_packed: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  if (num_nodes == 0 || n_chunks == 0) return NQA_OK;
+  const NodeChunk* chunks = static_cast<const NodeChunk*>(chunk_table);
+  const NodeInstr* instr = static_cast<const NodeInstr*>(instr_table);
+  NodeLinearPackedArgs pa{};
+  int32_t frag_off[kMaxNodeInstr + 1], mul_out[kMaxNodeInstr];
+  const int64_t per_type = node_frag_layout(chunks, n_chunks, instr, n_instr, frag_off, mul_out);
+  if (per_type < 0) {
+    set_error("nqa_node_linear_packed: inconsistent tables");
+    return NQA_ERR_INVALID;
+  }
+  for (int q = 0; q < n_instr; ++q) pa.frag_off[q] = frag_off[q];
+  pa.frag_stride = per_type;
+  pa.wf = static_cast<const nl_u32x4*>(packed);
+  NodeLinearArgs<float>& a = pa.base;
+  a.x = static_cast<const float*>(x);
+  a.addend = static_cast<const float*>(addend);
+  a.out = static_cast<float*>(out);
+  a.types = n_types > 1 ? atom_types : nullptr;
+  if (n_instr > 0) std::memcpy(a.instr, instr, sizeof(NodeInstr) * (size_t)n_instr);
+  a.n_types = n_types;
+  a.din = dim_in;
+  a.dout = dim_out;
+  a.N = num_nodes;
+  a.scale = (float)scale;
+  {
+    static const int dbg = [] {
+      const char* e = std::getenv("NQA_NODE_DBG");
+      return e ? std::atoi(e) : 0;
+    }();
+    a.dbg = dbg;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // chunks with the most stages first; more than kMaxNodeChunks chunks (wide l_max = 3 layers) in several launches
+  std::vector<int> order(n_chunks), stages(n_chunks);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int d = chunks[c].d;
+    if (d != 1 && d != 3 && d != 5 && d != 7 && d != 9) {
+      set_error("nqa_node_linear_packed: irrep dimension above 9 (l > 4)");
+      return NQA_ERR_UNSUPPORTED;
+    }
+    if (chunks[c].c0 % 64 != 0) {
+      set_error("nqa_node_linear_packed: chunks must start at multiples of 64 channels");
+      return NQA_ERR_INVALID;
+    }
+    int st = 0;
+    for (int q = chunks[c].instr_begin; q < chunks[c].instr_end; ++q) st += n_types * ((instr[q].mul_in + kNLK3 - 1) / kNLK3);
+    stages[c] = st;
+    order[c] = c;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return stages[l] > stages[r]; });
+  for (int c0 = 0; c0 < n_chunks; c0 += kMaxNodeChunks) {
+    const int nc = std::min(n_chunks - c0, kMaxNodeChunks);
+    int64_t nblk = 0;
+    int ng = 0;
+    for (int c = 0; c < nc; ++c) {
+      a.chunks[c] = chunks[order[c0 + c]];
+      const NodeChunk& cc = a.chunks[c];
+      const bool same = c > 0 && cc.instr_begin == a.chunks[c - 1].instr_begin &&
+                        cc.instr_end == a.chunks[c - 1].instr_end && cc.d == a.chunks[c - 1].d &&
+                        cc.o_off == a.chunks[c - 1].o_off;
+      const int per_unit = 32 / cc.d;
+      if (!same) {
+        pa.grp_begin[ng] = (int32_t)nblk;
+        pa.grp_chunk0[ng] = c;
+        pa.grp_n[ng] = 0;
+        ++ng;
+      }
+      ++pa.grp_n[ng - 1];
+      nblk += (num_nodes + per_unit - 1) / per_unit;
+    }
+    pa.grp_begin[ng] = (int32_t)nblk;
+    pa.n_groups = ng;
+    a.n_chunks = nc;
+    if (nblk > 2147483647LL) {
+      set_error("nqa_node_linear_packed: too many work units for one launch");
+      return NQA_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(node_linear_wave_bf16_kernel, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
+                       dim3(64 * kNLWavesPerWG), 0, s, pa);
+  }
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_node_linear_packed: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

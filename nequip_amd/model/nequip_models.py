@@ -224,10 +224,4 @@ def _full_nequip_energy_model(
         out_field=AtomicDataDict.TOTAL_ENERGY_KEY,
     )
     energy_model = SequentialGraphNetwork(modules)
-    # (extension) consecutive convolutions know each other: in eval mode the node-side chain across their boundary
-    # (linear_2 + sc -> Gate -> {linear_1, sc}) runs as one fused launch (nn/interaction_block.py `set_chain_next`)
-    seq = list(modules.values())
-    for a, b in zip(seq, seq[1:]):
-        if isinstance(a, ConvNetLayer) and isinstance(b, ConvNetLayer):
-            a.conv.set_chain_next(b.conv)
     return ForceStressOutput(energy_model, do_derivatives)

@@ -69,14 +69,6 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         old_x = data[AtomicDataDict.NODE_FEATURES_KEY]
         data = self.conv(data)
-        pending = data.get("_nqa_pending_stage")
-        if pending is not None and pending.block is self.conv:
-            if not self.resnet:
-                # the convolution deferred its linear_2: our Gate joins the note, the next block's fused launch runs both
-                pending.gate = self.equivariant_nonlin
-                return data
-            del data["_nqa_pending_stage"]
-            data[AtomicDataDict.NODE_FEATURES_KEY] = pending.materialise()
         data[AtomicDataDict.NODE_FEATURES_KEY] = self.equivariant_nonlin(data[AtomicDataDict.NODE_FEATURES_KEY])
         if self.resnet:
             data[AtomicDataDict.NODE_FEATURES_KEY] = old_x + data[AtomicDataDict.NODE_FEATURES_KEY]

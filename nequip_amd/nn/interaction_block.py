@@ -6,7 +6,6 @@ gather / scatter is the fused HIP ``TensorProductScatter``.
 """
 
 import contextlib
-import os
 from typing import Dict, Optional, Sequence, Union
 
 import torch
@@ -95,36 +94,6 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         )
         self.is_first_layer = is_first_layer
 
-    def set_chain_next(self, block: "InteractionBlock") -> None:
-        """(extension) the convolution evaluated after this one, with nothing but this layer's Gate in between.  Lets the
-        two blocks hand the node-side chain ``linear_2 (+ sc) -> Gate -> {linear_1, sc}`` to one fused launch
-        (``nqa_node_chain``) in eval mode.  Kept in a plain list: not a submodule (no duplicate parameters / state-dict
-        entries), yet it follows deepcopy and pickling of the model."""
-        self._chain_next = [block]
-
-    def _chain_partner(self, data, x) -> Optional["InteractionBlock"]:
-        """The next block if the fused chain applies to this evaluation, else None."""
-        nxt = getattr(self, "_chain_next", None)
-        nxt = nxt[0] if nxt else None
-        # Off by default: the fused launch is correct (tests/test_node_chain.py) but, as measured on cfg-3, not yet faster than
-        # the four launches it replaces (340-500 us against ~140 us: DESIGN.md section 4) -- NQA_CHAIN=1 enables it.
-        if nxt is None or os.environ.get("NQA_CHAIN", "") in ("", "0"):
-            return None
-        if not x.is_cuda or x.dtype != torch.float32 or traceable():
-            return None
-        if AtomicDataDict.LMP_MLIAP_DATA_KEY in data:
-            return None
-        params = [self.linear_2.weight, nxt.linear_1.weight] + ([nxt.sc.weight] if nxt.sc is not None else [])
-        if differentiable_parameters(self.training or nxt.training, *params):
-            return None
-        norm = nxt.avg_num_neighbors_norm
-        if not norm.norm_shortcut or norm.norm_key in data:
-            return None
-        table = data.get("_nqa_node_attrs_table")
-        if nxt.sc is not None and (table is None or table.shape[0] > 16):
-            return None
-        return nxt
-
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         if AtomicDataDict.LMP_MLIAP_DATA_KEY in data:
             num_local_nodes = int(data[AtomicDataDict.LMP_MLIAP_DATA_KEY].nlocal)
@@ -136,19 +105,9 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         if not self.is_first_layer and x.shape[0] != num_local_nodes:
             x = x[:num_local_nodes]
 
-        # the previous block left its linear_2 / Gate undone for us: one launch does them together with our sc / linear_1
-        pending = data.pop("_nqa_pending_stage", None)
-        chained = None
-        if pending is not None:
-            chained = pending.run(self, data)
-            if chained is None:  # (cannot happen with the builder's links; materialise the deferred modules)
-                x = pending.materialise()
-
         sc = None
         sc_stream = None
-        if chained is not None:
-            x, sc = chained
-        elif self.sc is not None:
+        if self.sc is not None:
             node_attrs = data[AtomicDataDict.NODE_ATTRS_KEY]
             if not self.is_first_layer and node_attrs.shape[0] != num_local_nodes:
                 node_attrs = node_attrs[:num_local_nodes]
@@ -170,9 +129,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
                     sc = self.sc(x, node_attrs)
 
         norm = self.avg_num_neighbors_norm
-        if chained is not None:
-            pass  # x = scale * linear_1(Gate(...)) came out of the fused launch
-        elif norm.norm_shortcut and x.is_cuda and not traceable() and norm.norm_key not in data:
+        if norm.norm_shortcut and x.is_cuda and not traceable() and norm.norm_key not in data:
             # one avg_num_neighbors for all types: 1/sqrt(avg) rides on the linear_1 launch (no separate N x D pass)
             x = self.linear_1(x, scale=norm.norm_scalar)
         else:
@@ -235,44 +192,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             cur = torch.cuda.current_stream(x.device)
             cur.wait_stream(sc_stream)
             sc.record_stream(cur)
-        nxt = self._chain_partner(data, x)
-        if nxt is not None:
-            # leave linear_2 (+ sc) to the fused launch of the next block; the ConvNetLayer adds its Gate to the note
-            data["_nqa_pending_stage"] = _PendingStage(self, nxt, x, sc if self.sc is not None else None)
-            data[AtomicDataDict.NODE_FEATURES_KEY] = x  # (placeholder: nobody reads it before the next block)
-            return data
         # linear_2 with the residual `+ sc` fused into the same launch
         x = self.linear_2(x, addend=sc if self.sc is not None else None)
         data[AtomicDataDict.NODE_FEATURES_KEY] = x
         return data
-
-
-class _PendingStage:
-    """A deferred ``linear_2 (+ sc) -> Gate`` of one block, to be evaluated together with the next block's
-    ``sc`` / ``linear_1`` by ``nqa_node_chain`` (``o3/_node_chain.py``)."""
-
-    def __init__(self, block: InteractionBlock, nxt: InteractionBlock, a: torch.Tensor, addend: Optional[torch.Tensor]):
-        self.block, self.nxt, self.a, self.addend = block, nxt, a, addend
-        self.gate = None
-
-    def materialise(self) -> torch.Tensor:
-        x = self.block.linear_2(self.a, addend=self.addend)
-        return self.gate(x) if self.gate is not None else x
-
-    def run(self, consumer: InteractionBlock, data):
-        from ..o3._node_chain import NodeStage, node_stage, stage_supported
-
-        if consumer is not self.nxt or self.gate is None:
-            return None
-        stage = self.block.__dict__.get("_chain_stage")
-        if stage is None or stage.gate is not self.gate or stage.lin1 is not consumer.linear_1 or stage.sc is not consumer.sc:
-            if not stage_supported(self.block.linear_2, self.gate, consumer.linear_1, consumer.sc):
-                self.block.__dict__["_chain_stage"] = None
-                self.block._chain_next = []  # do not try again
-                return None
-            stage = NodeStage(self.block.linear_2, self.gate, consumer.linear_1, consumer.sc,
-                              float(consumer.avg_num_neighbors_norm.norm_scalar))
-            self.block.__dict__["_chain_stage"] = stage
-        types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: self.a.shape[0]].contiguous()
-        table = data.get("_nqa_node_attrs_table")
-        return node_stage(stage, self.a, self.addend, types, table)

@@ -11,6 +11,7 @@ Builds the chunk / instruction tables from irreps bookkeeping and wraps the laun
 from __future__ import annotations
 
 import ctypes
+import os
 import struct
 from typing import List, Optional, Sequence, Tuple
 
@@ -111,14 +112,60 @@ class NodeLinearMeta:
         return wp.index_select(1, perm)
 
 
+def exact_fp32() -> bool:
+    """``NQA_NODE_EXACT_FP32=1``: the channel-mixing products on the fp32 MFMA (bitwise an fma chain) instead of split-bf16
+    operands on the bf16 MFMA (fp32-accurate: six partial products per fp32 product, as the radial MLP's default mode)."""
+    return os.environ.get("NQA_NODE_EXACT_FP32", "") not in ("", "0")
+
+
+def packed_weights(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.Tensor:
+    """``wp [T, wstride]`` split into three bf16 planes in MFMA-fragment order (``nqa_node_weights_pack``).  Constant
+    weights (eval mode: the modules keep ``wp`` alive across steps) are packed once per version of the tensor; a ``wp``
+    that is part of an autograd graph (training: rebuilt from the parameter every step) is packed per call."""
+    lib = _lib.load()
+    ct, nchunks, it, ninstr = meta.host_tables(which)
+    key = (id(meta), which)
+    cache = None
+    if not wp.requires_grad:
+        cache = wp.__dict__.setdefault("_nqa_packed", {}) if hasattr(wp, "__dict__") else None
+        if cache is not None:
+            hit = cache.get(key)
+            if hit is not None and hit[0] == wp._version:
+                return hit[1]
+    T = wp.shape[0]
+    nbytes = lib.nqa_node_weights_pack_bytes(ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p),
+                                             ninstr, T)
+    if nbytes < 0:
+        raise RuntimeError("nqa_node_weights_pack_bytes: inconsistent tables")
+    w = wp.detach().contiguous()
+    out = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=wp.device)
+    with torch.cuda.device(wp.device):
+        rc = lib.nqa_node_weights_pack(_ptr(w), ctypes.cast(ct, ctypes.c_void_p), nchunks,
+                                       ctypes.cast(it, ctypes.c_void_p), ninstr, T, w.shape[1], _ptr(out),
+                                       _stream(wp.device))
+    _lib.check(rc, "nqa_node_weights_pack")
+    if cache is not None:
+        cache[key] = (wp._version, out)
+    return out
+
+
 def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale: float):
     lib = _lib.load()
-    width = 64  # 64-channel chunks: float32 on the fp32-MFMA kernel, float64 on the VALU kernel
+    width = 64  # 64-channel chunks: float32 on the MFMA kernels, float64 on the VALU kernel
     ct, nchunks, it, ninstr = meta.host_tables(which)
     din, dout = (meta.din, meta.dout) if which == "fwd" else (meta.dout, meta.din)
     N = x.shape[0]
     out = torch.empty((N, dout), dtype=x.dtype, device=x.device)
     flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
+    if x.dtype == torch.float32 and not exact_fp32() and ninstr > 0:
+        wf = packed_weights(wp, meta, which)
+        with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
+            rc = lib.nqa_node_linear_packed(
+                _ptr(x), _ptr(wf), _ptr(addend), _ptr(out), _ptr(types), ctypes.cast(ct, ctypes.c_void_p), nchunks,
+                ctypes.cast(it, ctypes.c_void_p), ninstr, wp.shape[0], din, dout, N, float(scale), _stream(x.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_node_linear_packed")
+        return out
     with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
         rc = lib.nqa_node_linear(
             _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types),
