@@ -108,6 +108,19 @@ class NequIPCalculator(Calculator):
         if not self._type_of_symbol:
             raise ValueError("no chemical species mapping: pass chemical_symbols or a model with type_names")
 
+    @classmethod
+    def from_compiled_model(cls, compile_path: str, device: Union[str, torch.device] = "cuda",
+                            chemical_symbols: Optional[Union[Sequence[str], Dict[str, str]]] = None, **kwargs):
+        """Calculator around an AOTInductor package made by ``nequip_amd.utils.aot.aot_export_model`` (the reference's
+        recommended route: ``NequIPCalculator.from_compiled_model`` on a ``nequip-compile --target ase`` artefact,
+        nequip/integrations/ase.py:16-19).  Cutoff and type names come from the package metadata."""
+        from ..utils.aot import load_aotinductor_model
+
+        model, metadata = load_aotinductor_model(str(compile_path), device=device)
+        model = model.eval()
+        model.type_names = metadata["type_names"].split()
+        return cls(model, device=device, r_max=float(metadata["r_max"]), chemical_symbols=chemical_symbols, **kwargs)
+
     # ---- data ----------------------------------------------------------------------------------------------------
     def atoms_to_data(self, atoms) -> AtomicDataDict.Type:
         """``from_ase`` + species mapping + neighbour list (``nequip/integrations/ase.py:142-150``), on the device."""

@@ -67,7 +67,12 @@ def make_modifier(base_cls):
         persistent=False,
         private=False,
         unsupported_devices=["cpu"],
-        supported_compile_modes=[],
+        # `nequip-compile --mode aotinductor --modifiers enable_NequipAMD`: the module then runs as torch.ops.nequip_amd.*
+        # dispatcher ops, which make_fx / torch.export / AOTInductor carry as extern calls; the package records
+        # `nequip_amd` in its custom-ops entry (`_nequip_custom_ops_libs`), imported by the reference's loader before
+        # `aoti_load_package` (nequip/utils/aoti_metadata.py:40-54).  Exercised end to end on the GPU by
+        # tests/test_aot_inductor.py with this package's own mirror of that flow.  (No TorchScript form.)
+        supported_compile_modes=["aotinductor"],
     )(classmethod(enable_NequipAMD))
 
 

@@ -73,7 +73,7 @@ def _build(builder, seed: int, model_dtype, **kwargs) -> GraphModel:
             model = builder(**kwargs)
     finally:
         torch.set_rng_state(cpu_state)
-    return GraphModel(model, type_names=kwargs.get("type_names", ()), model_dtype=dtype)
+    return GraphModel(model, type_names=kwargs.get("type_names", ()), model_dtype=dtype, r_max=kwargs.get("r_max"))
 
 
 def PresetNequIPGNNModel(preset: str, **kwargs) -> GraphModel:

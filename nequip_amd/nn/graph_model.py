@@ -12,11 +12,13 @@ from ._graph_mixin import GraphModuleMixin
 class GraphModel(GraphModuleMixin, torch.nn.Module):
     is_compile_graph_model: bool = False
 
-    def __init__(self, model: GraphModuleMixin, type_names: List[str] = (), model_dtype=torch.float32) -> None:
+    def __init__(self, model: GraphModuleMixin, type_names: List[str] = (), model_dtype=torch.float32,
+                 r_max: float = None) -> None:
         super().__init__()
         self.model = model
         self.type_names = list(type_names)
         self.model_dtype = model_dtype
+        self.r_max = r_max
         self.model_input_fields = [
             AtomicDataDict.POSITIONS_KEY, AtomicDataDict.EDGE_INDEX_KEY, AtomicDataDict.ATOM_TYPE_KEY,
             AtomicDataDict.CELL_KEY, AtomicDataDict.EDGE_CELL_SHIFT_KEY, AtomicDataDict.BATCH_KEY,
@@ -34,6 +36,22 @@ class GraphModel(GraphModuleMixin, torch.nn.Module):
                 if lib not in libs:
                     libs.append(lib)
         return tuple(libs)
+
+    @property
+    def metadata(self):
+        """String-valued model metadata for compiled artefacts (nequip/nn/graph_model.py:20-36,100-146): model dtype,
+        type names, cutoff, and the libraries whose import registers the custom ops the model calls."""
+        out = {
+            "model_dtype": {torch.float32: "float32", torch.float64: "float64"}.get(self.model_dtype, str(self.model_dtype)),
+            "type_names": " ".join(self.type_names),
+            "num_types": str(len(self.type_names)),
+        }
+        if self.r_max is not None:
+            out["r_max"] = str(self.r_max)
+        libs = self.nequip_custom_ops_libs
+        if libs:
+            out["nequip_custom_ops_libs"] = " ".join(sorted(libs))
+        return out
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         new_data: AtomicDataDict.Type = {k: v for k, v in data.items() if k in self.model_input_fields}

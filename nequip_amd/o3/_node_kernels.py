@@ -157,7 +157,9 @@ def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale
     N = x.shape[0]
     out = torch.empty((N, dout), dtype=x.dtype, device=x.device)
     flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
-    if x.dtype == torch.float32 and not exact_fp32() and ninstr > 0:
+    # (weights that are part of an autograd graph -- training -- change every step: the exact-fp32 kernel reads them as
+    # they are, packing them per call would cost a launch per module and direction)
+    if x.dtype == torch.float32 and not exact_fp32() and ninstr > 0 and not wp.requires_grad:
         wf = packed_weights(wp, meta, which)
         with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
             rc = lib.nqa_node_linear_packed(

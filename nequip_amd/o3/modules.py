@@ -235,8 +235,14 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)
         if (traceable() and x.is_cuda and x.dtype == torch.float32 and self._meta is not None
                 and not differentiable_parameters(self.training, self.weight)):
-            perm, scale = self._contract_index(self.weight.device, self.weight.dtype)
-            wp = torch.mm(table.detach(), self.weight.detach().index_select(0, perm).view(table.shape[1], -1) * scale)
+            # (per-instruction einsums on slices of the flat weight: no cached index tensors -- a real constant tensor is
+            # not allowed next to fake weights while make_fx traces symbolically)
+            tb = table.detach()
+            parts = []
+            for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+                W = self.weight.detach()[sl].view(shape)
+                parts.append((torch.einsum("tv,uvw->tuw", tb[:, self._s2[i2]], W) * self._scale[io]).reshape(tb.shape[0], -1))
+            wp = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
             return _node_ops.node_linear_op(x, wp, self._op_key, types=types.view(-1).contiguous())
         Z = x.shape[0]
         T = table.shape[0]

@@ -75,3 +75,31 @@ def test_calculator_matches_direct_model_call(device, periodic):
         assert "stress" not in calc.results
     with pytest.raises(ValueError):
         calc.calculate(FakeAtoms(["Xx"] * 3, pos[:3]))
+
+
+@pytest.mark.gpu
+def test_calculator_from_compiled_model(device, tmp_path):
+    """`NequIPCalculator.from_compiled_model` on an AOTInductor package (the route the reference recommends,
+    nequip/integrations/ase.py:16-19): same energy / forces / stress as the calculator around the eager model, on a box
+    of another size than the one the package was compiled with."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import aot
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=2, seed=3)
+    model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.0, type_names=names, num_layers=2, l_max=2,
+                           parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=64,
+                           avg_num_neighbors=20.0).to(device).eval()
+    example = AtomicDataDict.to_device(syn.make_data(pos, types, 4.0, cell), device)
+    path = aot.aot_export_model(model, example, str(tmp_path / "m.nequip.pt2"))
+    pos, types, cell, names = syn.water_box(n_side=3, seed=8)
+    atoms = FakeAtoms([names[t] for t in types], pos, cell, pbc=True)
+    eager = NequIPCalculator(model, device, r_max=4.0)
+    comp = NequIPCalculator.from_compiled_model(path, device="cuda")
+    assert comp.r_max == 4.0
+    e0, f0, s0 = eager.get_potential_energy(atoms), eager.get_forces(atoms), eager.get_stress(atoms)
+    e1, f1, s1 = comp.get_potential_energy(atoms), comp.get_forces(atoms), comp.get_stress(atoms)
+    np.testing.assert_allclose(e1, e0, rtol=2e-5, atol=2e-5 * len(pos))
+    np.testing.assert_allclose(f1, f0, rtol=0, atol=2e-5 * max(1.0, np.abs(f0).max()))
+    np.testing.assert_allclose(s1, s0, rtol=0, atol=2e-5 * max(1e-3, np.abs(s0).max()))

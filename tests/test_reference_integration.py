@@ -65,7 +65,7 @@ def test_register_follows_the_reference_modifier_protocol(ref):
     assert mmu.is_persistent_model_modifier(fn) is False
     assert mmu.is_private_model_modifier(fn) is False
     assert mmu.get_model_modifier_unsupported_devices(fn) == ["cpu"]
-    assert mmu.get_model_modifier_supported_compile_modes(fn) == []
+    assert mmu.get_model_modifier_supported_compile_modes(fn) == ["aotinductor"]
     # the shape of the upstream adapters is the template: same decorator settings as enable_OpenEquivariance
     oeq = RefTPS.enable_OpenEquivariance
     assert mmu.is_persistent_model_modifier(oeq) == mmu.is_persistent_model_modifier(fn)
