@@ -10,6 +10,7 @@ device by ``nqa_csr_build`` and reused by the three convolution layers and their
 from __future__ import annotations
 
 import ctypes
+import contextlib
 import os
 import weakref
 from typing import Optional, Tuple
@@ -193,12 +194,30 @@ class EdgePairing:
 
 
 class _TopologyCache:
-    """Reuse the CSR across the layers of one forward: keyed on the identity/version of the index storage."""
+    """Reuse of the CSRs / pairing of an edge list: across the layers of one forward, and across forwards for as long as
+    the caller keeps handing in the SAME index tensor (static neighbour list: benchmark loops, MD between list rebuilds).
+
+    An entry is keyed on the identity of the index storage -- the very tensor object must still be alive (weak
+    reference, so a recycled ``id`` cannot alias), with the same version counter, data pointer, size and strides.  What
+    this cannot see is a caller that rewrites the index memory behind PyTorch's back (a DLPack / Kokkos view refilled
+    by LAMMPS, ``.data`` writes, raw-pointer kernels): the version counter does not move and a stale CSR would give
+    silently wrong forces.  Three guards:
+
+    * ``scope(trust_identity=False)``: inside, nothing is taken from or left in the cross-call cache -- the topology is
+      built on first use and shared by the layers of that one evaluation only.  ``GraphModel.forward`` opens such a
+      scope for callers known to alias buffers (LAMMPS ML-IAP data) and when ``NQA_TOPOLOGY_CACHE=0``.
+    * ``invalidate()`` / ``clear()`` for callers that know they rewrote a list in place.
+    * ``NQA_TOPOLOGY_VERIFY=1``: every cache hit is checked against a checksum of the index values taken when the
+      entry was built (one reduction + a host synchronisation per hit: a debugging mode) and raises on a mismatch.
+
+    A few entries are kept (least recently used first out), so alternating graphs do not rebuild on every call."""
+
+    MAX_ENTRIES = 4
 
     def __init__(self):
-        self._key = None
-        self._ref = None
-        self._topo: Optional[EdgeTopology] = None
+        self._entries = []  # [(key, (ref_dst, ref_src), topo, checksum)] most recent last
+        self._scope = None  # dict while an untrusted scope is open
+        self._hint = None
 
     @staticmethod
     def _base(t: torch.Tensor) -> torch.Tensor:
@@ -219,24 +238,68 @@ class _TopologyCache:
             return None  # not row 0 of the hinted tensor
         return hint[3]
 
+    @staticmethod
+    def _checksum(edge_dst: torch.Tensor, edge_src: torch.Tensor) -> int:
+        if edge_dst.numel() == 0:
+            return 0
+        pos = torch.arange(1, edge_dst.numel() + 1, device=edge_dst.device, dtype=torch.int64)
+        return int(((edge_dst.to(torch.int64) * 1000003 + edge_src.to(torch.int64)) * pos).sum().item())
+
+    @contextlib.contextmanager
+    def scope(self, trust_identity: bool = True):
+        """One model evaluation.  ``trust_identity=False``: build on first use, share within the scope, forget afterwards."""
+        if trust_identity or self._scope is not None:
+            yield self
+            return
+        self._scope = {}
+        try:
+            yield self
+        finally:
+            self._scope = None
+
     def get(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int) -> EdgeTopology:
         bd, bs = self._base(edge_dst), self._base(edge_src)
         key = (
             id(bd), id(bs), bd._version, bs._version, edge_dst.data_ptr(), edge_src.data_ptr(),
             edge_dst.numel(), edge_dst.stride(0), edge_src.stride(0), int(num_nodes), str(edge_dst.device),
         )  # fmt: skip
-        alive = self._ref is not None and self._ref[0]() is bd and self._ref[1]() is bs
-        if self._topo is not None and alive and key == self._key:
-            return self._topo
+        if self._scope is not None:  # untrusted caller: per-evaluation sharing only
+            topo = self._scope.get(key)
+            if topo is None:
+                topo = self._scope[key] = EdgeTopology(edge_dst, edge_src, num_nodes)
+            return topo
+        verify = os.environ.get("NQA_TOPOLOGY_VERIFY", "") not in ("", "0")
+        for i, (k, refs, topo, csum) in enumerate(self._entries):
+            if k == key and refs[0]() is bd and refs[1]() is bs:
+                if verify:
+                    now = self._checksum(edge_dst, edge_src)
+                    if csum is None:
+                        self._entries[i] = (k, refs, topo, now)
+                    elif now != csum:
+                        raise RuntimeError(
+                            "nequip_amd: the edge index tensor was rewritten in place without PyTorch noticing (same "
+                            "tensor, same version counter, different contents): the cached CSR is stale.  Call "
+                            "nequip_amd.nn.topology_cache.invalidate() after such writes, or hand in a new tensor.")
+                if i != len(self._entries) - 1:
+                    self._entries.append(self._entries.pop(i))
+                return topo
         topo = EdgeTopology(edge_dst, edge_src, num_nodes, rowptr_dst=self._rowptr_hint(bd, edge_dst, num_nodes))
-        self._key = key
-        self._ref = (weakref.ref(bd), weakref.ref(bs))
-        self._topo = topo
+        self._entries = [e for e in self._entries if e[1][0]() is not None and e[1][1]() is not None]
+        self._entries.append((key, (weakref.ref(bd), weakref.ref(bs)), topo,
+                              self._checksum(edge_dst, edge_src) if verify else None))
+        if len(self._entries) > self.MAX_ENTRIES:
+            self._entries.pop(0)
         return topo
 
-    def clear(self):
-        self._key = self._ref = self._topo = None
+    def invalidate(self) -> None:
+        """Forget every cached topology (after rewriting an index tensor in place)."""
+        self._entries = []
         self._hint = None
+        if self._scope is not None:
+            self._scope.clear()
+
+    def clear(self):
+        self.invalidate()
 
 
 topology_cache = _TopologyCache()

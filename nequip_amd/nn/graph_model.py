@@ -1,6 +1,7 @@
 """``GraphModel``: top-level wrapper (mirror of ``nequip/nn/graph_model.py:37-155``): copies the input dict,
 keeps only the model's input fields and exposes the custom-ops metadata of accelerated submodules."""
 
+import os
 from typing import List
 
 import torch
@@ -55,4 +56,14 @@ class GraphModel(GraphModuleMixin, torch.nn.Module):
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         new_data: AtomicDataDict.Type = {k: v for k, v in data.items() if k in self.model_input_fields}
-        return self.model(new_data)
+        # callers that are known to refill their index buffers in place (LAMMPS ML-IAP hands in views of its own arrays)
+        # never get a topology cached across calls; NQA_TOPOLOGY_CACHE=0 extends that to everybody
+        from ..utils.tracing import traceable
+        from ._topology import topology_cache
+
+        if traceable():  # (a tracer follows the model only; topologies are built inside the ops at run time)
+            return self.model(new_data)
+        trust = (AtomicDataDict.LMP_MLIAP_DATA_KEY not in new_data
+                 and os.environ.get("NQA_TOPOLOGY_CACHE", "1") not in ("0",))
+        with topology_cache.scope(trust_identity=trust):
+            return self.model(new_data)
