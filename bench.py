@@ -47,6 +47,12 @@ WORKLOADS = {
     "water81k": dict(box="water", n_side=30, l_max=2, num_features=64, num_layers=3),  # 8 x the default box
     "si1k": dict(box="si", reps=5, l_max=2, num_features=64, num_layers=3),
     "water_small": dict(box="water", n_side=5, l_max=2, num_features=64, num_layers=3),
+    # the reference's model presets (nequip/model/nequip_models.py:30-58: non-uniform multiplicities) on the cfg-3 box
+    "water10k_S": dict(box="water", n_side=15, l_max=1, num_features=[128, 64], num_layers=2, type_embed_num_features=32),
+    "water10k_M": dict(box="water", n_side=15, l_max=2, num_features=[128, 64, 32], num_layers=4,
+                       type_embed_num_features=32),
+    "water10k_L": dict(box="water", n_side=15, l_max=3, num_features=[128, 64, 32, 32], num_layers=6,
+                       type_embed_num_features=32),
     # BASELINE config 5: 100k-atom fcc Cu, l_max=3, 128 features (cu20k: same model on a fifth of the box)
     "cu100k": dict(box="cu", reps=(25, 25, 40), l_max=3, num_features=128, num_layers=3),
     "cu20k": dict(box="cu", reps=(25, 25, 8), l_max=3, num_features=128, num_layers=3),
@@ -70,6 +76,7 @@ def model_cfg(w, avg_num_neighbors):
         num_features=w["num_features"], radial_mlp_depth=w.get("radial_mlp_depth", 1),
         radial_mlp_width=w.get("radial_mlp_width", 128), num_bessels=8, polynomial_cutoff_p=6,
         avg_num_neighbors=float(avg_num_neighbors), model_dtype="float32",
+        **({"type_embed_num_features": w["type_embed_num_features"]} if "type_embed_num_features" in w else {}),
     )  # fmt: skip
 
 

@@ -95,6 +95,13 @@ def baseline_irreps() -> List[Tuple[str, str, int, str]]:
             else:
                 out.append((f"{tag}_mid", hidden, lmax, hidden))
                 out.append((f"{tag}_last", hidden, lmax, "1x0e"))
+                # channel segments of non-uniform multiplicities (the reference's S / M / L presets: num_features
+                # [128, 64], [128, 64, 32], [128, 64, 32, 32]; nn/_segmented.py): in the channel range where only the
+                # first k input irreps are live the convolution is the uniform one over those k irreps
+                hs = hidden.split("+")
+                for k in range(1, lmax + 1):
+                    out.append((f"{tag}_mid_k{k}", "+".join(hs[:k]), lmax, hidden))
+                    out.append((f"{tag}_last_k{k}", "+".join(hs[:k]), lmax, "1x0e"))
     # experiments: NQA_GEN_EXTRA="name:irreps_in:lmax:irreps_out;..." adds structures (scripts/r2_split_probe.py)
     for rec in filter(None, os.environ.get("NQA_GEN_EXTRA", "").split(";")):
         name, f_in, lmax, f_out = rec.split(":")

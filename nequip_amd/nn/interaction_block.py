@@ -6,6 +6,7 @@ gather / scatter is the fused HIP ``TensorProductScatter``.
 """
 
 import contextlib
+import os
 from typing import Dict, Optional, Sequence, Union
 
 import torch
@@ -14,7 +15,7 @@ from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
 from ..o3.modules import FullyConnectedTensorProduct, Linear
 from ..utils.wgrad import differentiable_parameters
-from . import _paired_radial
+from . import _paired_radial, _segmented
 from ._ghost_exchange import NoOpGhostExchangeModule
 from ._graph_mixin import GraphModuleMixin
 from ._topology import topology_cache
@@ -70,6 +71,16 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         irreps_mid, instructions = uvu_paths(feature_irreps_in, irreps_edge_attr, feature_irreps_out)
 
         self.tp_scatter = TensorProductScatter(feature_irreps_in, irreps_edge_attr, irreps_mid, instructions)
+        # non-uniform multiplicities (S / M / L presets): the convolution as uniform pieces over channel ranges, each on the
+        # structure-specialised kernels (nn/_segmented.py).  The pieces own no parameters and no persistent buffers.
+        segs = _segmented.channel_segments(
+            feature_irreps_in, irreps_edge_attr, irreps_mid, instructions,
+            lambda a, b, c, d: TensorProductScatter(a, b, c, d))
+        self._segments = segs
+        if segs is not None:
+            self.segment_tps = torch.nn.ModuleList([sg.tp for sg in segs])
+            self.register_buffer("_segment_out_perm", _segmented.output_permutation(segs, Irreps(str(irreps_mid)).dim),
+                                 persistent=False)
 
         self.edge_mlp = ScalarMLPFunction(
             input_dim=self.irreps_in[AtomicDataDict.EDGE_EMBEDDING_KEY].num_irreps,
@@ -80,6 +91,10 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             bias=False,
             forward_weight_init=True,
         )
+
+        if self._segments is not None:
+            for sg in self._segments:
+                sg.mlp = _segmented._SegmentMLP(self.edge_mlp, sg.w_cols) if radial_mlp_depth >= 1 else None
 
         self.linear_2 = Linear(irreps_in=irreps_mid.simplify(), irreps_out=feature_irreps_out)
 
@@ -93,6 +108,49 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             field=AtomicDataDict.NODE_FEATURES_KEY, irreps_in={AtomicDataDict.NODE_FEATURES_KEY: feature_irreps_in}
         )
         self.is_first_layer = is_first_layer
+
+    def _use_segments(self, x: torch.Tensor, emb: torch.Tensor) -> bool:
+        """Channel-segment evaluation: float32 on the GPU, not while tracing (the dispatcher-op form takes any irreps), every
+        piece has a structure-specialised kernel and a radial-MLP view."""
+        segs = self._segments
+        if segs is None or not x.is_cuda or x.dtype != torch.float32 or emb.dtype != torch.float32 or traceable():
+            return False
+        ok = self.__dict__.get("_segments_ok")
+        if ok is None:
+            ok = all(sg.mlp is not None and sg.tp._get_kernels().has_spec(torch.float32) for sg in segs)
+            self.__dict__["_segments_ok"] = ok
+        return ok and os.environ.get("NQA_NO_SEGMENTS", "") in ("", "0")
+
+    def _segmented_conv(self, data, x, emb, edge_index) -> torch.Tensor:
+        attrs = data[AtomicDataDict.EDGE_ATTRS_KEY]
+        topo = pairing = emb_half = queue = None
+        outs = []
+        for sg in self._segments:
+            sg.to(x.device)
+            mlp = sg.mlp.sync()
+            x_s = x.index_select(1, sg.x_cols)
+            if (self.paired_radial_ok and AtomicDataDict.POSITIONS_KEY in data
+                    and _paired_radial.available(mlp, sg.tp, x_s, emb)):
+                if topo is None:
+                    topo = topology_cache.get(edge_index[0], edge_index[1], x.size(0))
+                    pairing = topo.pairing(data.get(AtomicDataDict.EDGE_CELL_SHIFT_KEY))
+                if pairing is not None:
+                    if emb_half is None:
+                        emb_half = data.get("_nqa_edge_embedding_pairs")
+                        if emb_half is None or emb_half.shape[0] != pairing.num_pairs:
+                            emb_half = _paired_radial.pair_rows(emb, pairing)
+                            data["_nqa_edge_embedding_pairs"] = emb_half
+                    if (queue is None and emb_half.requires_grad and _paired_radial.RadialBackwardQueue.enabled()
+                            and not differentiable_parameters(self.training, self.edge_mlp.mlp[2].weight)):
+                        queue = data.get("_nqa_radial_queue")
+                        if queue is None:
+                            queue = data["_nqa_radial_queue"] = _paired_radial.RadialBackwardQueue(x.device)
+                    outs.append(_paired_radial.paired_radial_tp(mlp, sg.tp, emb, x_s, attrs, topo, pairing, emb_half,
+                                                                queue))
+                    continue
+            outs.append(sg.tp(x=x_s, edge_attr=attrs, edge_weight=mlp(emb), edge_dst=edge_index[0],
+                              edge_src=edge_index[1]))
+        return torch.cat(outs, dim=1).index_select(1, self._segment_out_perm)
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         if AtomicDataDict.LMP_MLIAP_DATA_KEY in data:
@@ -147,6 +205,16 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
 
         emb = data[AtomicDataDict.EDGE_EMBEDDING_KEY]
         edge_index = data[AtomicDataDict.EDGE_INDEX_KEY]
+        if self._use_segments(x, emb):
+            x = self._segmented_conv(data, x, emb, edge_index)
+            if x.shape[0] != num_local_nodes:
+                x = x[:num_local_nodes]
+            if sc_stream is not None:
+                cur = torch.cuda.current_stream(x.device)
+                cur.wait_stream(sc_stream)
+                sc.record_stream(cur)
+            data[AtomicDataDict.NODE_FEATURES_KEY] = self.linear_2(x, addend=sc if self.sc is not None else None)
+            return data
         pairing = None
         # Pairing evaluates the radial MLP once per (i <- j) / (j <- i) pair: valid because this model's edge embedding is
         # a function of the edge length alone (`paired_radial_ok`; a builder with per-edge-type or otherwise asymmetric

@@ -1,0 +1,134 @@
+"""The reference's model presets (``nequip/model/nequip_models.py:30-58``: S / M / L with non-uniform ``num_features``)
+on the structure-specialised kernels through channel segments (nn/_segmented.py)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+from oracle import model as omodel  # noqa: E402
+
+PRESETS = {
+    "S": dict(num_layers=2, l_max=1, num_features=[128, 64]),
+    "M": dict(num_layers=4, l_max=2, num_features=[128, 64, 32]),
+    "L": dict(num_layers=6, l_max=3, num_features=[128, 64, 32, 32]),
+}
+
+
+def test_segments_partition_the_columns_and_are_prebuilt_structures():
+    """Every channel segment of the preset convolutions (middle and last layer) is a uniform convolution whose structure
+    key is in the generator's prebuilt set; the segments' columns partition x, the weights and the output."""
+    sys.path.insert(0, os.path.join(ROOT, "nequip_amd", "csrc"))
+    import gen_spec
+    from nequip_amd.nn._segmented import channel_segments, output_permutation
+    from nequip_amd.nn.interaction_block import uvu_paths
+    from nequip_amd.o3.irreps import Irreps
+
+    built = {s.key() for s in gen_spec.baseline_structures()}
+    for name, p in PRESETS.items():
+        L = p["l_max"]
+        hidden = Irreps([(p["num_features"][l], (l, 1 if l % 2 == 0 else -1)) for l in range(L + 1)])
+        sh = Irreps.spherical_harmonics(L)
+        for f_out in (hidden, Irreps([(p["num_features"][0], (0, 1))])):
+            mid, ins = uvu_paths(hidden, sh, f_out)
+            segs = channel_segments(hidden, sh, mid, ins, lambda a, b, c, d: (a, b, c, d))
+            assert segs is not None and segs[0].c0 == 0 and segs[-1].c1 == max(p["num_features"])
+            wn = sum(hidden[a].mul for a, _, _, *_ in ins)
+            for cols, n in ((torch.cat([s.x_cols for s in segs]), hidden.dim), (torch.cat([s.w_cols for s in segs]), wn),
+                            (torch.cat([s.out_cols for s in segs]), mid.dim)):
+                assert torch.equal(torch.sort(cols).values, torch.arange(n)), name
+            assert output_permutation(segs, mid.dim).numel() == mid.dim
+            for s in segs:
+                a, b, c, d = s.tp
+                assert len({m.mul for m in a}) == 1 and all(m.mul == s.c1 - s.c0 for m in c)
+                st = gen_spec.Structure([m.ir.l for m in a], [m.ir.l for m in b], [m.ir.l for m in c],
+                                        [(i, j, k) for i, j, k, *_ in d])
+                assert st.key() in built, (name, str(a), st.key())
+
+
+def test_uniform_models_have_no_segments():
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn.interaction_block import InteractionBlock
+
+    m = NequIPGNNModel(seed=0, r_max=4.0, type_names=["H"], num_layers=2, l_max=2, parity=False, num_features=8,
+                       avg_num_neighbors=10.0)
+    assert all(b._segments is None for b in m.modules() if isinstance(b, InteractionBlock))
+
+
+def _cfg(preset, n_avg):
+    p = PRESETS[preset]
+    return dict(r_max=4.5, num_layers=p["num_layers"], l_max=p["l_max"], parity=False, num_features=p["num_features"],
+                type_embed_num_features=32, radial_mlp_depth=1, radial_mlp_width=128, num_bessels=8,
+                polynomial_cutoff_p=6, avg_num_neighbors=n_avg, model_dtype="float32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["S", "M", "L"])
+def test_preset_model_matches_the_oracle(device, preset, monkeypatch):
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import PresetNequIPGNNModel
+    from nequip_amd.nn.interaction_block import InteractionBlock
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=2)
+    data = syn.make_data(pos, types, 4.5, cell)
+    n, e = len(pos), data["edge_index"].shape[1]
+    cfg = _cfg(preset, e / n)
+    model = PresetNequIPGNNModel(preset, seed=1, model_dtype="float32", r_max=4.5, type_names=names,
+                                 avg_num_neighbors=e / n).to(device).eval()
+    dev_data = AtomicDataDict.to_device(data, device)
+    out = model(dict(dev_data))
+    blocks = [b for b in model.modules() if isinstance(b, InteractionBlock) and b._segments is not None]
+    assert blocks and all(b.__dict__.get("_segments_ok") for b in blocks), "the segmented path did not run"
+    weights = {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = omodel.energy_forces(data, dict(cfg, oracle_edge_chunk=8192), weights, with_virial=True)
+    fscale = max(1.0, float(ref["forces"].abs().max()))
+    df = float((ref["forces"] - out["forces"].cpu()).abs().max())
+    print(f"[preset {preset}] N={n} E={e} max|dF|={df:.3e} (max|F|={fscale:.3e})")
+    torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=5e-5 * n, rtol=5e-5)
+    torch.testing.assert_close(ref["forces"], out["forces"].cpu(), atol=5e-5 * fscale, rtol=5e-5)
+    torch.testing.assert_close(ref["virial"], out["virial"].cpu(), atol=5e-5 * n * fscale, rtol=5e-4)
+    # the same model on the generic any-irreps kernels (what round 2 ran the presets on)
+    monkeypatch.setenv("NQA_NO_SEGMENTS", "1")
+    out2 = model(dict(dev_data))
+    torch.testing.assert_close(out2["forces"], out["forces"], atol=2e-5 * fscale, rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_preset_training_step_parameter_gradients(device):
+    """Force-matching parameter gradients through the segments (column-sliced last MLP layer, per-segment double
+    backward) against autograd-through-autograd of the oracle, preset M shape with fewer layers."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=2, seed=7)
+    data = syn.make_data(pos, types, 4.0, cell)
+    n, e = len(pos), data["edge_index"].shape[1]
+    cfg = dict(r_max=4.0, num_layers=3, l_max=2, parity=False, num_features=[128, 64, 32], type_embed_num_features=32,
+               radial_mlp_depth=1, radial_mlp_width=128, num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=e / n,
+               model_dtype="float32")
+    model = NequIPGNNModel(seed=5, model_dtype="float32", type_names=names,
+                           **{k: v for k, v in cfg.items() if k != "model_dtype"})
+    gen = torch.Generator().manual_seed(0)
+    f_t = torch.randn(n, 3, generator=gen, dtype=torch.float64)
+    e_t = torch.randn(1, 1, generator=gen, dtype=torch.float64)
+    pn = {k for k, _ in model.named_parameters()}
+    weights = {k.replace("model.func.", ""): v.detach().clone().requires_grad_(k in pn)
+               for k, v in model.state_dict().items()}
+    out = omodel.energy_forces(data, cfg, weights, create_graph=True)
+    loss_ref = (out["forces"] - f_t).square().mean() + (out["total_energy"] - e_t).square().mean() / n
+    names_w = [k for k, v in weights.items() if v.requires_grad]
+    grads_ref = dict(zip(names_w, torch.autograd.grad(loss_ref, [weights[k] for k in names_w])))
+    model = model.to(device).train()
+    out = model(AtomicDataDict.to_device(data, device))
+    loss = (out["forces"] - f_t.to(device)).square().mean() + (out["total_energy"] - e_t.to(device)).square().mean() / n
+    loss.backward()
+    torch.testing.assert_close(loss_ref.detach(), loss.detach().cpu(), atol=2e-4, rtol=2e-4)
+    for k, p in model.named_parameters():
+        r = grads_ref[k.replace("model.func.", "")]
+        assert p.grad is not None, k
+        torch.testing.assert_close(r, p.grad.cpu(), atol=2e-4 * max(1e-3, float(r.abs().max())), rtol=2e-3,
+                                   msg=lambda m: f"{k}: {m}")
