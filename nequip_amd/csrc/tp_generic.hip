@@ -522,7 +522,16 @@ static int nqa_tp_scatter_fwd_impl(const nqa_plan* plan, const void* plan_image,
 int64_t nqa_tp_bwd_edge_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges) {
   if (plan == nullptr || num_edges < 0) return -1;
   const int64_t es = dtype == NQA_F64 ? 8 : 4;
-  return num_edges * (int64_t)plan->ypart_width * es;
+  // generic kernels: one partial per (instruction, 64-channel chunk) and component of its in2 irrep (ypart_width);
+  // structure-specialised kernels: dim_in2 partials per channel chunk.  The larger of the two: for a structure with few
+  // paths the second exceeds the first (one 0e x 0e path, l_max = 1 harmonics, 128 channels: 8 floats per edge against
+  // 2) -- found when the truncated-input structures of the channel segments were added; no round-2 structure hit it.
+  int64_t per_edge = plan->ypart_width;
+  if (use_spec(plan, dtype)) {
+    const int64_t spec_w = (int64_t)plan->dim_in2 * ((plan->uniform_mul + 63) / 64);
+    if (spec_w > per_edge) per_edge = spec_w;
+  }
+  return num_edges * per_edge * es;
 }
 
 static int nqa_tp_scatter_bwd_edge_impl(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x,
