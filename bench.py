@@ -417,16 +417,20 @@ def train_bench(args, world, rank, device, distributed):
         elapsed = float(t.item())
     roofline = step_roofline = None
     kernels = {}
-    if rank == 0 and args.kernel_steps > 0:
-        ktimer.reset()
-        ktimer.enable(True)
+    if args.kernel_steps > 0 and (rank == 0 or distributed):
+        # (the instrumented steps contain the gradient all-reduce: with more than one rank EVERY rank has to run them,
+        # only rank 0 records -- rank 0 alone would wait for its peers forever)
+        if rank == 0:
+            ktimer.reset()
+            ktimer.enable(True)
         for _ in range(args.kernel_steps):
             step()
         torch.cuda.synchronize()
-        ktimer.enable(False)
-        kernels = ktimer.summary()
-        roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, elapsed / args.steps * 1e3,
-                                                   args.workload, live_pmc=False)
+        if rank == 0:
+            ktimer.enable(False)
+            kernels = ktimer.summary()
+            roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, elapsed / args.steps * 1e3,
+                                                       args.workload, live_pmc=False)
     if rank == 0:
         print(json.dumps({
             "metric": "atom-optimizer-steps/s (DDP force-matching training)",

@@ -99,3 +99,22 @@ def test_profile_summariser_classifies_every_generated_kernel():
     # the round-2 regression: a fifth template argument must not change the classification
     assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_kernel<float, 4, true, true, false>(x)")[0] == "tp_bwd_fused"
     assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_kernel<float, 4, true, false, true, 7>(x)")[0] == "tp_bwd_edge"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_training_line_on_a_shared_device(device):
+    """`bench.py --gpus 2 --workload train256` with both ranks on device 0 (gloo; a functional check of the N > 1 control
+    flow, not a measurement): barriers, max over ranks, the flat gradient all-reduce inside the timed AND the
+    kernel-instrumented steps (which every rank has to run: rank 0 alone used to wait for its peer forever), one JSON
+    line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["NQA_BENCH_SHARE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "train256",
+                        "--steps", "2", "--warmup", "1", "--kernel-steps", "1", "--no-pmc", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and "all-reduce" in d["config"]["collective"]
+    assert d["value"] > 0 and "node_linear" in d["kernels_ms_per_step"]
