@@ -145,6 +145,9 @@ def _full_nequip_energy_model(
     do_derivatives: bool = True,
     convnet_sc: bool = True,
     convnet_resnet: bool = False,
+    convnet_nonlinearity_type: str = "gate",
+    convnet_nonlinearity_scalars: Dict[str, str] = {"e": "silu", "o": "tanh"},
+    convnet_nonlinearity_gates: Dict[str, str] = {"e": "silu", "o": "tanh"},
 ):
     assert all(tn.isalnum() for tn in type_names)
     assert len(radial_mlp_depth) == len(radial_mlp_width) == len(feature_irreps_hidden)
@@ -189,6 +192,9 @@ def _full_nequip_energy_model(
                 "type_names": type_names,
             },
             resnet=(layer_i != 0) and convnet_resnet,
+            nonlinearity_type=convnet_nonlinearity_type,
+            nonlinearity_scalars=convnet_nonlinearity_scalars,
+            nonlinearity_gates=convnet_nonlinearity_gates,
         )
         prev_irreps_out = current_convnet.irreps_out
         modules[f"layer{layer_i}_convnet"] = current_convnet

@@ -6,7 +6,7 @@ import torch
 
 from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
-from ..o3.modules import Gate
+from ..o3.modules import Gate, NormActivation
 from ._graph_mixin import GraphModuleMixin
 from .interaction_block import InteractionBlock
 from .utils import tp_path_exists
@@ -27,7 +27,7 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
                  nonlinearity_scalars: Dict[str, str] = {"e": "silu", "o": "tanh"},
                  nonlinearity_gates: Dict[str, str] = {"e": "silu", "o": "tanh"}):
         super().__init__()
-        assert nonlinearity_type == "gate", "only the default gate nonlinearity is on the benchmarked path"
+        assert nonlinearity_type in ("gate", "norm")
         nonlinearity_scalars = {1: nonlinearity_scalars["e"], -1: nonlinearity_scalars["o"]}
         nonlinearity_gates = {1: nonlinearity_gates["e"], -1: nonlinearity_gates["o"]}
         convolution_kwargs = {} if convolution_kwargs is None else dict(convolution_kwargs)
@@ -47,16 +47,24 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
              if ir.l > 0 and tp_path_exists(irreps_layer_out_prev, edge_attr_irreps, ir)]
         )
         irreps_layer_out = (irreps_scalars + irreps_gated).simplify()
-        ir = "0e" if tp_path_exists(irreps_layer_out_prev, edge_attr_irreps, "0e") else "0o"
-        irreps_gates = Irreps([(mul, ir) for mul, _ in irreps_gated])
-        equivariant_nonlin = Gate(
-            irreps_scalars=irreps_scalars,
-            act_scalars=[acts[nonlinearity_scalars[ir.p]] for _, ir in irreps_scalars],
-            irreps_gates=irreps_gates,
-            act_gates=[acts[nonlinearity_gates[ir.p]] for _, ir in irreps_gates],
-            irreps_gated=irreps_gated,
-        )
-        conv_irreps_out = equivariant_nonlin.irreps_in.simplify()
+        if nonlinearity_type == "gate":
+            ir = "0e" if tp_path_exists(irreps_layer_out_prev, edge_attr_irreps, "0e") else "0o"
+            irreps_gates = Irreps([(mul, ir) for mul, _ in irreps_gated])
+            equivariant_nonlin = Gate(
+                irreps_scalars=irreps_scalars,
+                act_scalars=[acts[nonlinearity_scalars[ir.p]] for _, ir in irreps_scalars],
+                irreps_gates=irreps_gates,
+                act_gates=[acts[nonlinearity_gates[ir.p]] for _, ir in irreps_gates],
+                irreps_gated=irreps_gated,
+            )
+            conv_irreps_out = equivariant_nonlin.irreps_in.simplify()
+        else:
+            # nequip/nn/convnetlayer.py:113-125: the norm is an even scalar, so nonlinearity_scalars[1] applies
+            conv_irreps_out = irreps_layer_out.simplify()
+            equivariant_nonlin = NormActivation(
+                irreps_in=conv_irreps_out, scalar_nonlinearity=acts[nonlinearity_scalars[1]], normalize=True,
+                epsilon=1e-8, bias=False,
+            )
         self.equivariant_nonlin = equivariant_nonlin
         self.resnet = bool(irreps_layer_out == irreps_layer_out_prev and resnet)
 

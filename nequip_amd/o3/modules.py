@@ -357,3 +357,49 @@ class Gate(torch.nn.Module):
         for (mul, ir), g, blk in zip(self.irreps_gated, gsplit, parts[2:]):
             cols.append((blk.view(Z, mul, ir.dim) * g.unsqueeze(-1)).view(Z, mul * ir.dim))
         return torch.cat(cols, dim=-1)
+
+
+class NormActivation(torch.nn.Module):
+    """``x_u -> act(|x_u|) / |x_u| * x_u`` per irrep copy ``u`` (``|x_u|^2 = sum_m x_{u m}^2``, clamped below at
+    ``epsilon^2``): e3nn ``NormActivation(irreps, scalar_nonlinearity, normalize=True, epsilon=1e-8, bias=False)`` as
+    ``ConvNetLayer`` builds it for ``nonlinearity_type="norm"`` (``nequip/nn/convnetlayer.py:116-125``).  Semantics
+    restated from e3nn 0.5/0.6 [RECALLED: ``o3.Norm(squared=True)`` = plain sum of squares, the clamp at ``epsilon**2``
+    before the square root, ``ElementwiseTensorProduct`` of a 0e scalar with an irrep = plain product].  Plain ATen ops
+    (elementwise node-sized work off the benchmarked path; traceable as is)."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity: Callable, normalize: bool = True, epsilon: Optional[float] = None,
+                 bias: bool = False):
+        super().__init__()
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_in)
+        if epsilon is None and normalize:
+            epsilon = 1e-8
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        elif not normalize:
+            epsilon = 0.0
+        self.epsilon = float(epsilon)
+        self.scalar_nonlinearity = scalar_nonlinearity
+        self.normalize = normalize
+        self.bias = bias
+        if bias:
+            self.biases = torch.nn.Parameter(torch.zeros(self.irreps_in.num_irreps))
+        self._sizes = [(m.mul, m.ir.dim) for m in self.irreps_in]
+
+    def forward(self, features: torch.Tensor) -> torch.Tensor:
+        Z = features.shape[0]
+        blocks = torch.split(features, [mul * d for mul, d in self._sizes], dim=1) if len(self._sizes) > 1 else (features,)
+        eps2 = self.epsilon * self.epsilon
+        outs, off = [], 0
+        for (mul, d), blk in zip(self._sizes, blocks):
+            xb = blk.reshape(Z, mul, d)
+            norms = xb.square().sum(dim=-1)
+            if eps2 > 0:
+                norms = torch.clamp(norms, min=eps2).sqrt()
+            arg = norms + self.biases[off : off + mul] if self.bias else norms
+            scal = self.scalar_nonlinearity(arg)
+            if self.normalize:
+                scal = scal / norms
+            outs.append((xb * scal.unsqueeze(-1)).reshape(Z, mul * d))
+            off += mul
+        return torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]

@@ -57,7 +57,11 @@ def build_specs(cfg):
         S.irreps_scalars, S.irreps_gates, S.irreps_gated = scalars, gates, gated
         S.act_scalars = [acts_s[p] for _, _, p in scalars]
         S.act_gates = [acts_s[p] for _, _, p in gates]
-        S.conv_irreps_out = ir.simplify(ir.simplify(scalars + gates + gated))
+        S.nonlin = cfg.get("convnet_nonlinearity_type", "gate")
+        if S.nonlin == "gate":
+            S.conv_irreps_out = ir.simplify(ir.simplify(scalars + gates + gated))
+        else:  # "norm" (nequip/nn/convnetlayer.py:113-125): no gate scalars, NormActivation on the simplified output
+            S.conv_irreps_out = ir.simplify(scalars + gated)
         S.irreps_mid, S.instructions = otp.build_instructions(prev, edge_sh, S.conv_irreps_out)
         S.use_sc = (li != 0) and cfg.get("convnet_sc", True)
         S.radial_depth = cfg.get("radial_mlp_depth", 1)
@@ -66,7 +70,7 @@ def build_specs(cfg):
         S.node_attrs = node_attrs
         S.edge_sh = edge_sh
         # Gate output: activated scalars (+) gated (tanh keeps 0o odd, silu keeps 0e)
-        prev = scalars + gated
+        prev = scalars + gated if S.nonlin == "gate" else S.conv_irreps_out
         S.irreps_out = prev
         specs.append(S)
     return specs
@@ -94,6 +98,7 @@ def energy_model(data, cfg, weights, specs=None):
         vec, r_max, cfg.get("num_bessels", 8), cfg.get("polynomial_cutoff_p", 6), dt
     )
     norm = torch.tensor(1.0 / math.sqrt(cfg["avg_num_neighbors"]), dtype=dt)  # nequip/nn/norm.py:39
+    acts_norm = cfg.get("convnet_nonlinearity_scalars", {"e": "silu"})["e"]
     for li, S in enumerate(specs):
         pre = f"layer{li}_convnet.conv."
         # InteractionBlock.forward, nequip/nn/interaction_block.py:158-207
@@ -110,7 +115,10 @@ def energy_model(data, cfg, weights, specs=None):
         if S.use_sc:
             x = x + sc
         # ConvNetLayer: Gate, nequip/nn/convnetlayer.py:162-164
-        x = onn.gate(x, S.irreps_scalars, S.act_scalars, S.irreps_gates, S.act_gates, S.irreps_gated)
+        if S.nonlin == "gate":
+            x = onn.gate(x, S.irreps_scalars, S.act_scalars, S.irreps_gates, S.act_gates, S.irreps_gated)
+        else:
+            x = onn.norm_activation(x, S.conv_irreps_out, acts_norm)
     # readout: ScalarMLP(output_dim=1, depth 0) -> PerTypeScaleShift (float64) -> AtomwiseReduce
     e_atom = onn.scalar_mlp(x, [weights["per_atom_energy_readout.mlp_module.mlp.0.weight"]], "silu")
     e_atom = e_atom.to(torch.float64)

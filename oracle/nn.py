@@ -208,3 +208,24 @@ def gate(x, irreps_scalars, act_scalars, irreps_gates, act_gates, irreps_gated):
         xoff += mul * (2 * l + 1)
         cols.append((blk * g.unsqueeze(-1)).reshape(Z, mul * (2 * l + 1)))
     return torch.cat([scalars] + cols, dim=-1)
+
+
+# --------------------------------------------------------------------------------------------------
+# e3nn NormActivation (used at nequip/nn/convnetlayer.py:116-125 for nonlinearity_type="norm") [RECALLED, e3nn 0.5/0.6]:
+#   norms = o3.Norm(irreps, squared=True)(x)           # per irrep copy: sum_m x_m^2
+#   norms[norms < eps^2] = eps^2; norms = norms.sqrt()  # eps = 1e-8
+#   scalings = act(norms) / norms                       # normalize=True, bias=False; act is the RAW function (no
+#   out = ElementwiseTensorProduct(scalings, x)         #   normalize2mom here); 0e x l -> l with unit coefficient
+# --------------------------------------------------------------------------------------------------
+def norm_activation(x, irreps, act_name="silu", epsilon=1e-8):
+    Z = x.shape[0]
+    cols, off = [], 0
+    for mul, l, _ in ir.parse(irreps):
+        d = 2 * l + 1
+        blk = x[:, off : off + mul * d].reshape(Z, mul, d)
+        off += mul * d
+        norms = (blk * blk).sum(-1)
+        norms = torch.where(norms < epsilon * epsilon, torch.full_like(norms, epsilon * epsilon), norms).sqrt()
+        scalings = _ACTS[act_name](norms) / norms
+        cols.append((blk * scalings.unsqueeze(-1)).reshape(Z, mul * d))
+    return torch.cat(cols, dim=-1)
