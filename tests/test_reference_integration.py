@@ -112,3 +112,47 @@ def test_reference_discovery_and_replacement(ref, monkeypatch):
     for layer in new_model.layers:
         assert isinstance(layer.tp_scatter, HipTPS)
     assert new_model.layers[0].tp_scatter.tp is old_tp
+
+
+def test_entry_point_autoload_registers_on_import_of_the_reference_module():
+    """The `nequip.extension` / `init_always` entry point target (pyproject.toml): loaded BEFORE nequip.nn exists, it must
+    attach `enable_NequipAMD` as soon as `nequip.nn._tp_scatter_base` is imported by anybody."""
+    spec = importlib.util.spec_from_file_location(
+        "make_reference_golden", os.path.join(os.path.dirname(__file__), "golden", "make_reference_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    finder = mod._Finder()
+    for k in [k for k in sys.modules if k == "nequip" or k.startswith("nequip.")]:
+        del sys.modules[k]
+    sys.modules.pop("nequip_amd.integrations.nequip_autoload", None)
+    sys.meta_path.insert(0, finder)
+    sys.path.insert(0, REFERENCE)
+    import warnings
+
+    real = warnings.filterwarnings
+    warnings.filterwarnings = lambda action, message="", category=Warning, *a, **k: (
+        real(action, message, category, *a, **k) if isinstance(category, type) else None)
+    try:
+        import nequip_amd.integrations.nequip_autoload as auto  # what `ep.load()` does, nequip.nn not imported yet
+
+        assert "nequip.nn._tp_scatter_base" not in sys.modules
+        assert any(isinstance(f, auto._RegisterAfterImport) for f in sys.meta_path)
+        import nequip.nn._tp_scatter_base as tps
+
+        assert hasattr(tps.TensorProductScatter, "enable_NequipAMD")
+        assert not any(isinstance(f, auto._RegisterAfterImport) for f in sys.meta_path)  # one-shot
+    finally:
+        warnings.filterwarnings = real
+        sys.meta_path[:] = [f for f in sys.meta_path if f is not finder and type(f).__name__ != "_RegisterAfterImport"]
+        sys.path.remove(REFERENCE)
+        for k in [k for k in sys.modules if k == "nequip" or k.startswith("nequip.") or k.split(".")[0] in mod._Finder.TOPS]:
+            del sys.modules[k]
+
+
+def test_pyproject_declares_the_entry_point():
+    import tomli
+
+    cfg = tomli.load(open(os.path.join(os.path.dirname(__file__), "..", "pyproject.toml"), "rb"))
+    eps = cfg["project"]["entry-points"]["nequip.extension"]
+    assert eps["init_always"] == "nequip_amd.integrations.nequip_autoload"
+    importlib.import_module(eps["init_always"])  # importable without nequip installed (defers registration)
