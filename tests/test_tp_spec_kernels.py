@@ -263,3 +263,67 @@ def test_pair_backward_equals_per_edge_backward(device, system):
     _close(fx.cpu(), px, "gx")
     _close((fw[:P] + fw[P:]).cpu(), pw, "gw (summed over the pair)")
     _close(fy.cpu(), py, "gy")
+
+
+def _big_graph(n_nodes, n_pairs, seed):
+    """Pairable random graph built with tensor ops (tens of thousands of nodes): every (i <- j) has its (j <- i)."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(1, n_nodes, (n_pairs,), generator=g)
+    b = torch.randint(1, n_nodes, (n_pairs,), generator=g)
+    keep = a != b
+    lo, hi = torch.minimum(a, b)[keep], torch.maximum(a, b)[keep]
+    key = torch.unique(lo * n_nodes + hi)
+    lo, hi = key // n_nodes, key % n_nodes
+    dst, src = torch.cat([lo, hi]), torch.cat([hi, lo])
+    perm = torch.randperm(dst.numel(), generator=g)
+    return dst[perm].contiguous(), src[perm].contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,f_in_1x,lmax,f_out_1x,mul,n_nodes", [
+    ("l2n_mid", "1x0e+1x1o+1x2e", 2, "1x0e+1x1o+1x2e", 64, 50000),
+    ("l3n_mid", "1x0e+1x1o+1x2e+1x3o", 3, "1x0e+1x1o+1x2e+1x3o", 128, 25000),
+])
+def test_one_wavefront_per_node_launch_shape_vs_oracle(device, name, f_in_1x, lmax, f_out_1x, mul, n_nodes):
+    """The launch shape of the LARGE boxes -- one wavefront per (node, 64-channel chunk) instead of four, chosen when
+    nodes x chunks >= 49 152 (cfg-5 and beyond; `spec_wpn`) -- against the oracle, for the forward, the pair-centric
+    backward (one wavefront per pair for l_max 2, split by input block over four for l_max 3) and the per-edge fused
+    backward.  Sparse graph (about three neighbours per node) so that the oracle stays affordable."""
+    from nequip_amd.nn._topology import EdgeTopology
+
+    tps, f_in, e_at, mid_s, instructions = _module(f_in_1x, lmax, f_out_1x, mul, device)
+    k = tps._get_kernels()
+    assert k.has_spec(torch.float32)
+    assert n_nodes * ((mul + 63) // 64) >= 49152
+    dst, src = _big_graph(n_nodes, int(1.5 * n_nodes), seed=11 + lmax)
+    E = dst.numel()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n_nodes, k.dim_in1, generator=g)
+    y = torch.randn(E, k.dim_in2, generator=g)
+    go = torch.randn(n_nodes, k.dim_out, generator=g)
+    topo = EdgeTopology(dst.to(device), src.to(device), n_nodes)
+    pr = topo.pairing(None)
+    assert pr is not None
+    P = pr.num_pairs
+    w_rows = torch.randn(P, k.weight_numel, generator=g)
+    rows = pr.rows.long().cpu()
+    w = w_rows[rows % P].contiguous()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    xr, yr, wr = (t.clone().requires_grad_(True) for t in (x, y, w))
+    ref = otp.tp_scatter(xr, yr, wr, dst, src, f_in, e_at, mid_s, instructions, edge_chunk=8192)
+    rgx, rgy, rgw = torch.autograd.grad(ref, (xr, yr, wr), go)
+    ref = ref.detach()
+    d = lambda t: t.to(device)  # noqa: E731
+    xd, yd, wd, god = d(x), d(y), d(w_rows), d(go)
+    tag = f"{name} mul={mul} N={n_nodes} E={E} (one wavefront per node)"
+    _close(ref, k.fwd(xd, yd, wd, topo, pr), f"fwd {tag}")
+    fx, fw, fy = k.bwd_fused(xd, yd, wd, god, topo, pairing=pr)
+    _close(rgx, fx, f"bwd_fused gx {tag}")
+    _close(rgw, fw[d(rows)], f"bwd_fused gw {tag}")
+    _close(rgy, fy, f"bwd_fused gy {tag}")
+    assert k.has_pairs_kernel(torch.float32)
+    px, pw, py = k.bwd_pairs(xd, yd, wd, god, topo, pr)
+    rgw_pairs = torch.zeros(P, k.weight_numel).index_add_(0, rows % P, rgw)
+    _close(rgx, px, f"bwd_pairs gx {tag}")
+    _close(rgw_pairs, pw, f"bwd_pairs gw {tag}")
+    _close(rgy, py, f"bwd_pairs gy {tag}")
