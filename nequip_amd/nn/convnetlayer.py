@@ -28,51 +28,50 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
                  nonlinearity_gates: Dict[str, str] = {"e": "silu", "o": "tanh"}):
         super().__init__()
         assert nonlinearity_type in ("gate", "norm")
-        nonlinearity_scalars = {1: nonlinearity_scalars["e"], -1: nonlinearity_scalars["o"]}
-        nonlinearity_gates = {1: nonlinearity_gates["e"], -1: nonlinearity_gates["o"]}
         convolution_kwargs = {} if convolution_kwargs is None else dict(convolution_kwargs)
         self.feature_irreps_hidden = Irreps(feature_irreps_hidden)
         self.resnet = resnet
         self._init_irreps(irreps_in=irreps_in, required_irreps_in=[AtomicDataDict.NODE_FEATURES_KEY])
 
-        edge_attr_irreps = self.irreps_in[AtomicDataDict.EDGE_ATTRS_KEY]
-        irreps_layer_out_prev = self.irreps_in[AtomicDataDict.NODE_FEATURES_KEY]
-
-        irreps_scalars = Irreps(
-            [(mul, ir) for mul, ir in self.feature_irreps_hidden
-             if ir.l == 0 and tp_path_exists(irreps_layer_out_prev, edge_attr_irreps, ir)]
-        )
-        irreps_gated = Irreps(
-            [(mul, ir) for mul, ir in self.feature_irreps_hidden
-             if ir.l > 0 and tp_path_exists(irreps_layer_out_prev, edge_attr_irreps, ir)]
-        )
-        irreps_layer_out = (irreps_scalars + irreps_gated).simplify()
-        if nonlinearity_type == "gate":
-            ir = "0e" if tp_path_exists(irreps_layer_out_prev, edge_attr_irreps, "0e") else "0o"
-            irreps_gates = Irreps([(mul, ir) for mul, _ in irreps_gated])
-            equivariant_nonlin = Gate(
-                irreps_scalars=irreps_scalars,
-                act_scalars=[acts[nonlinearity_scalars[ir.p]] for _, ir in irreps_scalars],
-                irreps_gates=irreps_gates,
-                act_gates=[acts[nonlinearity_gates[ir.p]] for _, ir in irreps_gates],
-                irreps_gated=irreps_gated,
-            )
-            conv_irreps_out = equivariant_nonlin.irreps_in.simplify()
-        else:
-            # nequip/nn/convnetlayer.py:113-125: the norm is an even scalar, so nonlinearity_scalars[1] applies
-            conv_irreps_out = irreps_layer_out.simplify()
-            equivariant_nonlin = NormActivation(
-                irreps_in=conv_irreps_out, scalar_nonlinearity=acts[nonlinearity_scalars[1]], normalize=True,
-                epsilon=1e-8, bias=False,
-            )
-        self.equivariant_nonlin = equivariant_nonlin
-        self.resnet = bool(irreps_layer_out == irreps_layer_out_prev and resnet)
+        sh = self.irreps_in[AtomicDataDict.EDGE_ATTRS_KEY]
+        x_prev = self.irreps_in[AtomicDataDict.NODE_FEATURES_KEY]
+        # hidden irreps the convolution can actually produce from (previous features) x (spherical harmonics)
+        reachable = [(mul, ir) for mul, ir in self.feature_irreps_hidden if tp_path_exists(x_prev, sh, ir)]
+        scalars = Irreps([(mul, ir) for mul, ir in reachable if ir.l == 0])
+        vectors = Irreps([(mul, ir) for mul, ir in reachable if ir.l > 0])
+        layer_out = (scalars + vectors).simplify()
+        act_of = {"scalars": {1: nonlinearity_scalars["e"], -1: nonlinearity_scalars["o"]},
+                  "gates": {1: nonlinearity_gates["e"], -1: nonlinearity_gates["o"]}}
+        build = self._gate_nonlinearity if nonlinearity_type == "gate" else self._norm_nonlinearity
+        self.equivariant_nonlin, conv_irreps_out = build(scalars, vectors, layer_out, x_prev, sh, act_of)
+        self.resnet = bool(resnet and layer_out == x_prev)
 
         convolution_kwargs.pop("irreps_in", None)
         convolution_kwargs.pop("irreps_out", None)
         self.conv = convolution(irreps_in=self.irreps_in, irreps_out=conv_irreps_out, **convolution_kwargs)
         self.irreps_out.update(self.conv.irreps_out)
         self.irreps_out[AtomicDataDict.NODE_FEATURES_KEY] = self.equivariant_nonlin.irreps_out
+
+    @staticmethod
+    def _gate_nonlinearity(scalars, vectors, layer_out, x_prev, sh, act_of):
+        """e3nn ``Gate`` (nequip/nn/convnetlayer.py:94-112): one extra scalar per gated irrep copy, of the parity the
+        convolution can produce; the convolution then outputs scalars (+) gates (+) gated."""
+        gate_ir = "0e" if tp_path_exists(x_prev, sh, "0e") else "0o"
+        gates = Irreps([(mul, gate_ir) for mul, _ in vectors])
+        nonlin = Gate(
+            irreps_scalars=scalars, act_scalars=[acts[act_of["scalars"][ir.p]] for _, ir in scalars],
+            irreps_gates=gates, act_gates=[acts[act_of["gates"][ir.p]] for _, ir in gates],
+            irreps_gated=vectors,
+        )
+        return nonlin, nonlin.irreps_in.simplify()
+
+    @staticmethod
+    def _norm_nonlinearity(scalars, vectors, layer_out, x_prev, sh, act_of):
+        """e3nn ``NormActivation`` (nequip/nn/convnetlayer.py:113-125): the norm of every irrep copy goes through the scalar
+        activation of EVEN scalars (a norm is even); no gate scalars, the convolution outputs the hidden irreps."""
+        nonlin = NormActivation(irreps_in=layer_out, scalar_nonlinearity=acts[act_of["scalars"][1]], normalize=True,
+                                epsilon=1e-8, bias=False)
+        return nonlin, layer_out
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         old_x = data[AtomicDataDict.NODE_FEATURES_KEY]
