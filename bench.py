@@ -53,6 +53,8 @@ WORKLOADS = {
                        type_embed_num_features=32),
     "water10k_L": dict(box="water", n_side=15, l_max=3, num_features=[128, 64, 32, 32], num_layers=6,
                        type_embed_num_features=32),
+    "water10k_XL": dict(box="water", n_side=15, l_max=4, num_features=[320, 96, 64, 32, 32], num_layers=6,
+                        type_embed_num_features=32),
     # BASELINE config 5: 100k-atom fcc Cu, l_max=3, 128 features (cu20k: same model on a fifth of the box)
     "cu100k": dict(box="cu", reps=(25, 25, 40), l_max=3, num_features=128, num_layers=3),
     "cu20k": dict(box="cu", reps=(25, 25, 8), l_max=3, num_features=128, num_layers=3),

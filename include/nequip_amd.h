@@ -54,7 +54,10 @@ enum nqa_plan_field {
   NQA_PLAN_NUM_INSTR = 4,
   NQA_PLAN_OUT_NEEDS_ZERO = 5, /* 1 if output slots are shared/uncovered (caller must zero `out`) */
   NQA_PLAN_YPART_WIDTH = 6,  /* columns of the per-edge dY partial buffer (bwd_edge workspace) */
-  NQA_PLAN_HAS_SPECIALIZED = 7 /* 1 if structure-specialised (edge-outer) kernels are prebuilt for this plan */
+  NQA_PLAN_HAS_SPECIALIZED = 7, /* 1 if structure-specialised (edge-outer) kernels are prebuilt for this plan */
+  NQA_PLAN_FUSED_ROWS_OK = 8  /* 1 if nqa_tp_scatter_bwd_fused keeps its per-channel operands (grad_out row, two feature
+                                 rows, the weights and their gradient) in registers; 0: it spills (l_max = 4 middle
+                                 layer: 364 values) and nqa_tp_scatter_bwd_x + _bwd_edge are the faster route */
 };
 
 typedef struct nqa_plan nqa_plan;

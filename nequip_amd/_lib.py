@@ -31,6 +31,7 @@ NQA_PLAN_NUM_INSTR = 4
 NQA_PLAN_OUT_NEEDS_ZERO = 5
 NQA_PLAN_YPART_WIDTH = 6
 NQA_PLAN_HAS_SPECIALIZED = 7
+NQA_PLAN_FUSED_ROWS_OK = 8
 
 _P32 = POINTER(c_int32)
 

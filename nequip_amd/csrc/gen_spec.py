@@ -74,8 +74,9 @@ def baseline_irreps() -> List[Tuple[str, str, int, str]]:
     """(name, feature_irreps_in, lmax_sh, feature_irreps_out) of every prebuilt structure, with ``1x`` multiplicities
     (the kernels take ``mul`` at run time; tests substitute 32 / 64 / 128)."""
     out = []
-    for lmax in (1, 2, 3):
-        for parity in (False, True):
+    for lmax in (1, 2, 3, 4):
+        # l_max = 4 (the reference's XL preset, SO(3) irreps only): the full-parity l = 4 structures are not prebuilt
+        for parity in ((False, True) if lmax <= 3 else (False,)):
             hidden = "+".join(
                 f"1x{l}{'e' if p == 1 else 'o'}"
                 for l in range(lmax + 1)

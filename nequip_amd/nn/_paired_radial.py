@@ -100,7 +100,7 @@ class _PairedRadialTPFn(torch.autograd.Function):
             if _pair_backward_pays(g):
                 fused = k.bwd_pairs(x, y, w_half, g, topo, pairing)
                 folded = fused is not None
-            if fused is None:
+            if fused is None and k.fused_rows_ok:
                 fused = k.bwd_fused(x, y, w_half, g, topo, pairing=pairing)
         if fused is not None:
             gx, G, gy = fused

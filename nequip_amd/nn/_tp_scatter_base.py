@@ -53,6 +53,9 @@ class _Kernels:
         # The fused backward trades the per-edge gather of grad_out rows (dim_out) and a second read of the weights for
         # a per-edge row of grad_x contributions written and read once (2 * dim_in1): worth it for wide outputs only.
         self.prefer_fused_bwd = (self.weight_numel + self.dim_out) >= 3 * self.dim_in1
+        # ... and only while the kernel's per-channel operands fit the register file (the pair-centric kernel, which is
+        # split by input block for the wide structures, is not bound by this)
+        self.fused_rows_ok = bool(plan.query(_lib.NQA_PLAN_FUSED_ROWS_OK))
 
     def has_spec(self, dtype: torch.dtype) -> bool:
         """Structure-specialised kernels available (float32, uniform-mul NequIP shapes)?"""
@@ -378,7 +381,7 @@ class _TPScatterBwdFn(torch.autograd.Function):
             if k.use_pairs(x.dtype, pairing):
                 fused = k.bwd_pairs(x, y, w, g, topo, pairing)
                 folded = fused is not None
-            if fused is None:
+            if fused is None and k.fused_rows_ok:
                 fused = k.bwd_fused(x, y, w, g, topo, need_gw=need[2], need_gy=need[1], pairing=pairing)
         if fused is not None:
             gx, gw, gy = fused

@@ -93,7 +93,7 @@ def _bwd_cuda(grad_out, x, edge_attr, edge_weight, edge_dst, edge_src, plan: str
     topo = _topology(edge_dst, edge_src, x.size(0))
     g, x, y, w = grad_out.contiguous(), x.contiguous(), edge_attr.contiguous(), edge_weight.contiguous()
     fused = None
-    if need_x and need_y and need_w and k.prefer_fused_bwd:
+    if need_x and need_y and need_w and k.prefer_fused_bwd and k.fused_rows_ok:
         fused = k.bwd_fused(x, y, w, g, topo)
     if fused is not None:
         gx, gw, gy = fused

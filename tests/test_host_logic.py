@@ -91,6 +91,14 @@ def test_native_plan_matches_host_bookkeeping():
     mid2, instr2 = otp.build_instructions("4x0e + 3x1o + 2x2e", "0e + 1o", "0e + 1o + 2e")
     tps2 = TensorProductScatter(Irreps("4x0e + 3x1o + 2x2e"), Irreps("0e + 1o"), Irreps(oir.to_str(mid2)), instr2)
     assert tps2._plan.query(_lib.NQA_PLAN_HAS_SPECIALIZED) == 0
+    assert plan.query(_lib.NQA_PLAN_FUSED_ROWS_OK) == 1 and tps2._plan.query(_lib.NQA_PLAN_FUSED_ROWS_OK) == 0
+    # the full l_max = 4 middle layer (the XL preset's first channel segment) has specialised kernels, but its fused
+    # edge-row backward would hold 364 values per channel: callers take nqa_tp_scatter_bwd_x + _bwd_edge instead
+    h4 = "32x0e+32x1o+32x2e+32x3o+32x4e"
+    mid4, instr4 = otp.build_instructions(h4, str(Irreps.spherical_harmonics(4)), h4)
+    tps4 = TensorProductScatter(Irreps(h4), Irreps.spherical_harmonics(4), Irreps(oir.to_str(mid4)), instr4)
+    assert tps4._plan.query(_lib.NQA_PLAN_HAS_SPECIALIZED) == 1 and tps4._plan.query(_lib.NQA_PLAN_FUSED_ROWS_OK) == 0
+    assert tps4._get_kernels().fused_rows_ok is False
 
 
 def test_native_plan_rejects_invalid_instructions():

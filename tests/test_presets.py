@@ -1,5 +1,5 @@
 """The reference's model presets (``nequip/model/nequip_models.py:30-58``: S / M / L with non-uniform ``num_features``)
-on the structure-specialised kernels through channel segments (nn/_segmented.py)."""
+and XL with l_max = 4) on the structure-specialised kernels through channel segments (nn/_segmented.py)."""
 import os
 import sys
 
@@ -13,6 +13,7 @@ PRESETS = {
     "S": dict(num_layers=2, l_max=1, num_features=[128, 64]),
     "M": dict(num_layers=4, l_max=2, num_features=[128, 64, 32]),
     "L": dict(num_layers=6, l_max=3, num_features=[128, 64, 32, 32]),
+    "XL": dict(num_layers=6, l_max=4, num_features=[320, 96, 64, 32, 32]),
 }
 
 
@@ -64,7 +65,7 @@ def _cfg(preset, n_avg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["S", "M", "L"])
+@pytest.mark.parametrize("preset", ["S", "M", "L", "XL"])
 def test_preset_model_matches_the_oracle(device, preset, monkeypatch):
     from nequip_amd.data import AtomicDataDict
     from nequip_amd.model import PresetNequIPGNNModel
