@@ -200,12 +200,16 @@ TP_REGIONS = ("tp_fwd", "tp_bwd_edge", "tp_bwd_x", "tp_bwd_fused", "tp_fwd_mlp",
 def kernel_roofline(kname, ks, kernel_steps):
     launches = ks["calls"] / max(kernel_steps, 1)
     if ks.get("flops_per_call", 0) > 0 and kname.startswith("radial_mlp"):
-        # GEMM on the matrix cores.  The default kernels execute 6 bf16 MFMA partial products per fp32 product (split
-        # operands, fp32-accurate): `achieved` / `frac` are the EXECUTED bf16 MFMA rate against the dense bf16 peak -- the
-        # pipe the kernel runs on.  The algorithmic fp32 FLOP rate (what the reference's fp32 GEMM would be credited
-        # with) is reported next to it; with NQA_MLP_EXACT_FP32=1 the kernels run on the fp32 MFMA pipe and that is the
+        # GEMM on the matrix cores.  The split kernels execute several 16-bit MFMA partial products per fp32 product
+        # (fp32-accurate): 6 on the three-plane bf16 split (backward, and forward with NQA_MLP_FWD_F16=0), 3 on the
+        # two-plane fp16 split (forward, default).  Two roofs bound such a launch from below -- the EXECUTED 16-bit MFMA
+        # work against the dense bf16 / fp16 peak, and the rows it writes (forward) or reads (backward) against HBM;
+        # `bound` / `achieved` / `frac` are those of the roof that gives the longer lower bound (the larger fraction),
+        # the other one is reported next to it.  The algorithmic fp32 FLOP rate (what the reference's fp32 GEMM would be
+        # credited with) is there too; with NQA_MLP_EXACT_FP32=1 the kernels run on the fp32 MFMA pipe and that is the
         # roofline.
         split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
+        f16_fwd = kname == "radial_mlp_fwd" and os.environ.get("NQA_MLP_FWD_F16", "") != "0"
         r = {
             "bound": "mfma", "kernel": kname, "unit": "TFLOP/s",
             "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],
@@ -214,8 +218,16 @@ def kernel_roofline(kname, ks, kernel_steps):
             "frac_of_fp32_mfma_peak": ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
         }
         if split:
-            r.update(achieved=6.0 * ks["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, frac=6.0 * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                     pipe="bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 partial products per fp32 product")
+            products = 3.0 if f16_fwd else 6.0
+            frac_mfma = products * ks["tflops"] / MFMA_BF16_PEAK_TFLOPS
+            frac_hbm = ks["gbps"] / HBM_PEAK_GBPS
+            r.update(executed_mfma_tflops=products * ks["tflops"], frac_mfma=frac_mfma, frac_hbm=frac_hbm,
+                     pipe=("fp16 MFMA (v_mfma_f32_32x32x16_f16), 3 partial products per fp32 product" if f16_fwd else
+                           "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 partial products per fp32 product"))
+            if frac_hbm > frac_mfma:
+                r.update(bound="hbm", unit="GB/s", achieved=ks["gbps"], peak=HBM_PEAK_GBPS, frac=frac_hbm)
+            else:
+                r.update(achieved=products * ks["tflops"], peak=MFMA_BF16_PEAK_TFLOPS, frac=frac_mfma)
         else:
             r.update(achieved=ks["tflops"], peak=MFMA_F32_PEAK_TFLOPS, frac=ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
                      pipe="fp32 MFMA (v_mfma_f32_32x32x2_f32)")

@@ -250,6 +250,10 @@ int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, 
  * ------------------------------------------------------------------------------------------- */
 #define NQA_MLP_FP32 0
 #define NQA_MLP_BF16X6 1
+/* forward only (nqa_radial_mlp_fwd; the backward entry points treat it as NQA_MLP_BF16X6): operands scaled by powers of
+ * two (weights per 32-column tile, hidden activations per row) and split into two fp16 terms, three partial products on
+ * v_mfma_f32_32x32x16_f16 -- fp32-level accuracy (2^-22 per operand) at half the matrix instructions of BF16X6 */
+#define NQA_MLP_F16X3 2
 int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, int32_t out_features);
 int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features);
 int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,

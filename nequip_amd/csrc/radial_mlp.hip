@@ -8,7 +8,10 @@
 // This is the one true dense GEMM on the hot path ([E,H] x [H,W], K = H = 64/128).  Two interchangeable GEMM modes:
 //   NQA_MLP_FP32   : exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, 157 TFLOP/s peak);
 //   NQA_MLP_BF16X6 : every fp32 operand split exactly into three bf16 terms, six partial products accumulated in fp32 on
-//                    v_mfma_f32_32x32x16_bf16 (fp32-accurate, 2.7x the fp32-MFMA ceiling) -- second half of this file.
+//                    v_mfma_f32_32x32x16_bf16 (fp32-accurate, 2.7x the fp32-MFMA ceiling) -- second half of this file;
+//   NQA_MLP_F16X3  : (forward) operands scaled by powers of two and split into two fp16 terms, three partial products on
+//                    v_mfma_f32_32x32x16_f16 -- half the matrix instructions of BF16X6 at the same fp32-level accuracy
+//                    (2^-22 per operand); the backward of this mode is the bf16 split.
 // Kernel structure (both modes):
 //   forward : a workgroup owns 128 edges; each wavefront keeps the SiLU-activated hidden rows of its 32 edges in
 //             VGPRs as MFMA fragments for the whole kernel (the hidden layer never touches HBM) and streams
@@ -419,6 +422,41 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
                                                  0);
 }
 
+// ---- two-plane fp16 split ("f16x3"): x = h + l / 4096 with h = fp16(x), l = fp16((x - h) * 4096) represents x to
+// 2^-22 |x| (two 11-bit significands), so a product needs three matrix instructions (h h, h l, l h; the dropped l l term
+// is 2^-24 of the product) instead of the six of the three-plane bf16 split.  fp16 has no exponent range to spare, so
+// every operand is first multiplied by a power of two that puts the largest magnitude of its group into [2^14, 2^15):
+// weights per 32-column tile (prepass), hidden activations per row (in registers, the row's values sit in one lane
+// pair) -- exact, undone on the accumulators.  Elements below 2^-28 of their group's maximum fall into the fp16
+// subnormals (error <= 2^-29 of the maximum whether or not the matrix pipe flushes them); the low plane stays below
+// 2^15 because |x - h| <= 2^-11 |x|.  Applies where the scale of a row is known before its first k-step, i.e. to the
+// forward GEMM; the backward streams the gradient rows and keeps the bf16 split (fp32 exponent range).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float kF16LowScale = 4096.f;
+
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, uint32_t& h, uint32_t& l) {
+  const f16x2 hh = {(_Float16)x0, (_Float16)x1};
+  const f16x2 ll = {(_Float16)((x0 - (float)hh[0]) * kF16LowScale), (_Float16)((x1 - (float)hh[1]) * kF16LowScale)};
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, ll);
+}
+
+// power of two that brings a maximum magnitude m into [2^14, 2^15); 1 for m = 0 or a non-finite m (the row / tile then
+// carries its inf / NaN through the fp16 conversion as the fp32 arithmetic would)
+__device__ __forceinline__ float f16_scale_up(float m) {
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(m, &e);  // m = f 2^e, f in [0.5, 1)
+  int k = 15 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return ldexpf(1.f, k);
+}
+
 // hidden index held by lane-half `half`, element t of bf16 k-step s, when the hidden layer is produced by the
 // transposed fp32 MFMA of step 1 (accumulator register r = 8*(s&1) + t of 32-row block s>>1)
 __device__ __forceinline__ constexpr int mlp_hmap(int s, int half, int t) {
@@ -446,6 +484,45 @@ __global__ __launch_bounds__(256) void radial_mlp_split_w1_fwd_kernel(const floa
   }
   u32x4* __restrict__ o = Wf + ((int64_t)(tile * KS + s) * 3) * 64 + lane;
   o[0] = h; o[64] = m; o[128] = l;
+}
+
+// f16x3 forward weight fragments: Wf[tile][s][plane][lane] (plane 0 / 1 = h / l) of the tile scaled by a power of two,
+// tile_scale[tile] = the inverse power (multiplied back on the accumulators).  One workgroup per tile: the maximum over
+// the tile's H x 32 values comes first.
+__global__ __launch_bounds__(256) void radial_mlp_split_w1_fwd_f16_kernel(const float* __restrict__ W1, float a1, int H,
+                                                                          int W, u32x4* __restrict__ Wf,
+                                                                          float* __restrict__ tile_scale) {
+  __shared__ float red[4];
+  const int KS = H / 16;
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < H * 32; i += 256) {
+    const int k = i >> 5, n = 32 * tile + (i & 31);
+    if (n < W) m = fmaxf(m, fabsf(W1[(int64_t)k * W + n] * a1));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float su = f16_scale_up(m);
+  if (tid == 0) tile_scale[tile] = 1.f / su;
+  for (int idx = tid; idx < KS * 64; idx += 256) {
+    const int lane = idx & 63, s = idx >> 6;
+    const int n = 32 * tile + (lane & 31), half = lane >> 5;
+    u32x4 h, l;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      const float v0 = n < W ? W1[(int64_t)mlp_hmap(s, half, 2 * tp) * W + n] * a1 * su : 0.f;
+      const float v1 = n < W ? W1[(int64_t)mlp_hmap(s, half, 2 * tp + 1) * W + n] * a1 * su : 0.f;
+      uint32_t a, b;
+      split_pair_f16(v0, v1, a, b);
+      h[tp] = a; l[tp] = b;
+    }
+    u32x4* __restrict__ o = Wf + ((int64_t)(tile * KS + s) * 2) * 64 + lane;
+    o[0] = h; o[64] = l;
+  }
 }
 
 // Backward weight fragments: Wb[chunk][s][split][nt][lane] = B[k = 32*chunk + 16*half + 8*s + t][j = 32*nt + (lane&31)]
@@ -678,13 +755,17 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
 // middle recomputes that block's hidden layer (about 0.7 tile-times, at most two extra blocks per workgroup).
 // The tile pipeline (weight tiles two ahead, alternating accumulator sets, epilogue of unit i-1 behind the first
 // k-steps of unit i) runs straight across block boundaries; the next block's embedding row is requested one tile early.
-template <int H>
-__global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const float* __restrict__ emb,
-                                                                        const float* __restrict__ W0,
-                                                                        const u32x4* __restrict__ Wf, float a0, int nb,
-                                                                        int W, int64_t E, float* __restrict__ out) {
+// F16: the second GEMM on the two-plane fp16 split (three products per k-step, weight tiles of 16 KiB, tile_scale from
+// the prepass) instead of the three-plane bf16 split (six products, 24 KiB tiles).
+template <int H, bool F16>
+__global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const float* __restrict__ emb,
+                                                                       const float* __restrict__ W0,
+                                                                       const u32x4* __restrict__ Wf, float a0, int nb,
+                                                                       int W, int64_t E, float* __restrict__ out,
+                                                                       const float* __restrict__ tile_scale) {
   constexpr int KS = H / 16;
-  constexpr int TILE = KS * 3 * 64;
+  constexpr int NPL = F16 ? 2 : 3;      // operand planes
+  constexpr int TILE = KS * NPL * 64;
   constexpr int NTH = 256;
   constexpr int NV = TILE / NTH;
   static_assert(TILE % NTH == 0, "tile must divide evenly over the workgroup");
@@ -744,8 +825,10 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const
   if (u0 + 1 < u1) stage_load(tile_after(t, 1));
   __syncthreads();
 
-  u32x4 bh[KS], bm[KS], bl[KS];
+  u32x4 bh[KS], bm[F16 ? 1 : KS], bl[KS];
+  float row_scale = 1.f;  // F16: inverse of the power of two this lane's row was multiplied by
   auto hidden = [&](const float (&e)[kMaxNb], bool row_ok) __attribute__((always_inline)) {
+    float hv[F16 ? (H / 32) * 16 : 1];
 #pragma unroll
     for (int kb = 0; kb < H / 32; ++kb) {
       f32x16 hacc = {0};
@@ -759,22 +842,61 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const
       for (int r = 0; r < 16; r += 2) {
         const float h0 = row_ok ? silu_f(hacc[r]) : 0.f;
         const float h1 = row_ok ? silu_f(hacc[r + 1]) : 0.f;
-        uint32_t a, b, c;
-        split_pair(h0, h1, a, b, c);
-        const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
-        bh[s][tp] = a; bm[s][tp] = b; bl[s][tp] = c;
+        if constexpr (F16) {
+          hv[kb * 16 + r] = h0;
+          hv[kb * 16 + r + 1] = h1;
+        } else {
+          uint32_t a, b, c;
+          split_pair(h0, h1, a, b, c);
+          const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
+          bh[s][tp] = a; bm[s][tp] = b; bl[s][tp] = c;
+        }
+      }
+    }
+    if constexpr (F16) {
+      // the row's H values sit in this lane and in lane ^ 32
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < (H / 32) * 16; ++i) m = fmaxf(m, fabsf(hv[i]));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const float su = f16_scale_up(m);
+      row_scale = 1.f / su;
+#pragma unroll
+      for (int kb = 0; kb < H / 32; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          uint32_t a, b;
+          split_pair_f16(hv[kb * 16 + r] * su, hv[kb * 16 + r + 1] * su, a, b);
+          const int s = 2 * kb + (r >> 3), tp = (r & 7) >> 1;
+          bh[s][tp] = a; bl[s][tp] = b;
+        }
       }
     }
   };
   hidden(ev, blk * kMlpRows + wv * 32 + l31 < E);
 
   float* __restrict__ tb = tbuf + wv * (32 * kTS);
-  auto emit = [&](const f32x16& pa, const f32x16& pb, int tile, int64_t wrow0) __attribute__((always_inline)) {
+  // bf16: pa + pb (large + small partial products).  F16: (pa + (pb + pc) / 4096) * rs * tile_scale with pa = h h,
+  // pb = h l, pc = l h and rs the row scale of the unit the accumulators belong to.
+  auto emit = [&](const f32x16& pa, const f32x16& pb, const f32x16& pc, int tile, int64_t wrow0, float rs)
+      __attribute__((always_inline)) {
+    if constexpr (F16) {
+      const float f = rs * tile_scale[tile];
+      const float fl = f * (1.f / kF16LowScale);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(tb + l31 * kTS + 8 * g + 4 * half) =
-          make_float4(pa[4 * g] + pb[4 * g], pa[4 * g + 1] + pb[4 * g + 1], pa[4 * g + 2] + pb[4 * g + 2],
-                      pa[4 * g + 3] + pb[4 * g + 3]);
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(tb + l31 * kTS + 8 * g + 4 * half) =
+            make_float4(fmaf(pb[4 * g] + pc[4 * g], fl, pa[4 * g] * f),
+                        fmaf(pb[4 * g + 1] + pc[4 * g + 1], fl, pa[4 * g + 1] * f),
+                        fmaf(pb[4 * g + 2] + pc[4 * g + 2], fl, pa[4 * g + 2] * f),
+                        fmaf(pb[4 * g + 3] + pc[4 * g + 3], fl, pa[4 * g + 3] * f));
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(tb + l31 * kTS + 8 * g + 4 * half) =
+            make_float4(pa[4 * g] + pb[4 * g], pa[4 * g + 1] + pb[4 * g + 1], pa[4 * g + 2] + pb[4 * g + 2],
+                        pa[4 * g + 3] + pb[4 * g + 3]);
+    }
     const int n0 = tile * 32;
     const int c4 = lane & 7, rsub = lane >> 3;
     if (wrow0 + 32 <= E && n0 + 32 <= W) {
@@ -794,7 +916,9 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const
   // one work unit; `i` = index of the unit in this workgroup's range (selects the LDS weight buffer)
   int prev_tile = 0;
   int64_t prev_row0 = 0;
-  auto unit = [&](int64_t i, f32x16& accA, f32x16& accB, const f32x16& prevA, const f32x16& prevB) __attribute__((always_inline)) {
+  float prev_rs = 1.f;
+  auto unit = [&](int64_t i, f32x16& accA, f32x16& accB, f32x16& accC, const f32x16& prevA, const f32x16& prevB,
+                  const f32x16& prevC) __attribute__((always_inline)) {
     const int64_t left = (u1 - u0) - i;  // units left including this one
     if (t == 0 && i > 0) {  // entering the next block: its embedding row was requested during the previous tile
       ++blk;
@@ -809,44 +933,53 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_bf16x6_bal_kernel(const
     const u32x4* __restrict__ a = as[buf] + lane;
     accA = (f32x16){0};
     accB = (f32x16){0};
-    u32x4 fa[2][3];
+    if constexpr (F16) accC = (f32x16){0};
+    u32x4 fa[2][NPL];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) fa[0][q] = a[q * 64];
+    for (int q = 0; q < NPL; ++q) fa[0][q] = a[q * 64];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s + 1 < KS) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fa[(s + 1) & 1][q] = a[((s + 1) * 3 + q) * 64];
+        for (int q = 0; q < NPL; ++q) fa[(s + 1) & 1][q] = a[((s + 1) * NPL + q) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
-      accA = mfma_bf16(ah, bh[s], accA);
-      accB = mfma_bf16(am, bm[s], accB);
-      accA = mfma_bf16(ah, bm[s], accA);
-      accB = mfma_bf16(ah, bl[s], accB);
-      accA = mfma_bf16(am, bh[s], accA);
-      accB = mfma_bf16(al, bh[s], accB);
+      if constexpr (F16) {
+        const u32x4 &ah = fa[s & 1][0], &al = fa[s & 1][1];
+        accA = mfma_f16(ah, bh[s], accA);
+        accB = mfma_f16(ah, bl[s], accB);
+        accC = mfma_f16(al, bh[s], accC);
+      } else {
+        const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
+        accA = mfma_bf16(ah, bh[s], accA);
+        accB = mfma_bf16(am, bm[s], accB);
+        accA = mfma_bf16(ah, bm[s], accA);
+        accB = mfma_bf16(ah, bl[s], accB);
+        accA = mfma_bf16(am, bh[s], accA);
+        accB = mfma_bf16(al, bh[s], accB);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (s == 1 && i > 0) {
-        emit(prevA, prevB, prev_tile, prev_row0);
+        emit(prevA, prevB, prevC, prev_tile, prev_row0, prev_rs);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     lds_barrier();
     prev_tile = t;
     prev_row0 = blk * kMlpRows + wv * 32;
+    prev_rs = row_scale;
     if (++t == ntiles) t = 0;
   };
-  f32x16 a0A, a0B, a1A, a1B;
+  f32x16 a0A, a0B, a0C, a1A, a1B, a1C;
   const int64_t n = u1 - u0;
   for (int64_t i = 0; i < n; i += 2) {
-    unit(i, a0A, a0B, a1A, a1B);
-    if (i + 1 < n) unit(i + 1, a1A, a1B, a0A, a0B);
+    unit(i, a0A, a0B, a0C, a1A, a1B, a1C);
+    if (i + 1 < n) unit(i + 1, a1A, a1B, a1C, a0A, a0B, a0C);
   }
   if (n & 1)
-    emit(a0A, a0B, prev_tile, prev_row0);
+    emit(a0A, a0B, a0C, prev_tile, prev_row0, prev_rs);
   else
-    emit(a1A, a1B, prev_tile, prev_row0);
+    emit(a1A, a1B, a1C, prev_tile, prev_row0, prev_rs);
 }
 
 // TM (training mode, see nqa_radial_mlp_bwd_train): 0 = inference (g_emb only); 1 = additionally hid_out = silu(P)
@@ -1172,7 +1305,13 @@ int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, i
 
 int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features) {
   if (hidden <= 0 || out_features <= 0) return -1;
-  if (mode == NQA_MLP_BF16X6) {
+  if (mode == NQA_MLP_F16X3 && !backward) {
+    // forward fragments on the two-plane fp16 split: ceil(W/32) tiles x (H/16) k-steps x 2 planes x 1 KiB, then one
+    // float per tile (the inverse of the tile's power-of-two scale)
+    const int64_t ntiles = (out_features + 31) / 32;
+    return ntiles * (hidden / 16) * 2 * 1024 + ((ntiles * 4 + 255) & ~(int64_t)255);
+  }
+  if (mode == NQA_MLP_BF16X6 || mode == NQA_MLP_F16X3) {
     // weight fragments: ceil(W/32) tiles x (H/16) k-steps x 3 splits x 1 KiB (same size for both directions)
     return (int64_t)((out_features + 31) / 32) * (hidden / 16) * 3 * 1024;
   }
@@ -1186,7 +1325,7 @@ static int check_mode(int32_t dtype, int32_t mode, const char* fn) {
     set_error(std::string(fn) + ": only float32 is implemented on MFMA");
     return NQA_ERR_UNSUPPORTED;
   }
-  if (mode != NQA_MLP_FP32 && mode != NQA_MLP_BF16X6) {
+  if (mode != NQA_MLP_FP32 && mode != NQA_MLP_BF16X6 && mode != NQA_MLP_F16X3) {
     set_error(std::string(fn) + ": unknown mode");
     return NQA_ERR_INVALID;
   }
@@ -1230,6 +1369,32 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
     const char* v = std::getenv("NQA_MLP_DBG");
     return v ? std::atoi(v) : 0;
   }();
+  static const int num_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  if (mode == NQA_MLP_F16X3) {
+    if (cotangent != nullptr) {
+      set_error("nqa_radial_mlp_fwd_tangent: NQA_MLP_F16X3 is a mode of the plain forward (use NQA_MLP_BF16X6)");
+      return NQA_ERR_UNSUPPORTED;
+    }
+    const int ntiles = (out_features + 31) / 32;
+    u32x4* wf = static_cast<u32x4*>(workspace);
+    float* ts = reinterpret_cast<float*>(static_cast<char*>(workspace) + (int64_t)ntiles * (hidden / 16) * 2 * 1024);
+    if (!workspace_ready)
+      hipLaunchKernelGGL(radial_mlp_split_w1_fwd_f16_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, b, (float)alpha1,
+                         hidden, out_features, wf, ts);
+    const int64_t units = (int64_t)grid * ntiles;
+    const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
+    if (hidden == 128)
+      hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<128, true>), dim3(gb), dim3(256), 0, s, e, a, wf,
+                         (float)alpha0, num_basis, out_features, num_edges, o, ts);
+    else
+      hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<64, true>), dim3(gb), dim3(256), 0, s, e, a, wf,
+                         (float)alpha0, num_basis, out_features, num_edges, o, ts);
+    return launch_status("nqa_radial_mlp_fwd");
+  }
   if (mode == NQA_MLP_BF16X6) {
     u32x4* wf = static_cast<u32x4*>(workspace);
     const int nfrag = ((out_features + 31) / 32) * (hidden / 16) * 64;
@@ -1254,20 +1419,15 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
       const char* v = std::getenv("NQA_MLP_FWD_BALANCED");
       return v == nullptr || v[0] != '0';
     }();
-    static const int num_cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      return n;
-    }();
     if (balanced && dbg == 0) {
       const int64_t units = (int64_t)grid * ((out_features + 31) / 32);
       const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
       if (hidden == 128)
-        hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_bal_kernel<128>), dim3(gb), dim3(256), 0, s, e, a, wf, (float)alpha0,
-                           num_basis, out_features, num_edges, o);
+        hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<128, false>), dim3(gb), dim3(256), 0, s, e, a, wf,
+                           (float)alpha0, num_basis, out_features, num_edges, o, nullptr);
       else
-        hipLaunchKernelGGL((radial_mlp_fwd_bf16x6_bal_kernel<64>), dim3(gb), dim3(256), 0, s, e, a, wf, (float)alpha0,
-                           num_basis, out_features, num_edges, o);
+        hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<64, false>), dim3(gb), dim3(256), 0, s, e, a, wf,
+                           (float)alpha0, num_basis, out_features, num_edges, o, nullptr);
       return launch_status("nqa_radial_mlp_fwd");
     }
     if (hidden == 128 && wide)
@@ -1322,6 +1482,7 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
                         int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
+  if (mode == NQA_MLP_F16X3) mode = NQA_MLP_BF16X6;  // the gradient rows have no known scale: bf16 split (see f16_scale_up)
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   if (num_edges == 0) return NQA_OK;

@@ -24,6 +24,15 @@ def radial_mlp_mode() -> int:
     return _lib.NQA_MLP_FP32 if os.environ.get("NQA_MLP_EXACT_FP32", "") not in ("", "0") else _lib.NQA_MLP_BF16X6
 
 
+def forward_mode(mode: int) -> int:
+    """Mode of the plain forward launch: the split-bf16 default runs its forward GEMM on the two-plane fp16 split
+    (``NQA_MLP_F16X3``: three matrix instructions per k-step instead of six, operands scaled by powers of two;
+    ``NQA_MLP_FWD_F16=0`` keeps the bf16 split)."""
+    if mode == _lib.NQA_MLP_BF16X6 and os.environ.get("NQA_MLP_FWD_F16", "") not in ("0",):
+        return _lib.NQA_MLP_F16X3
+    return mode
+
+
 from ..utils.tracing import traceable
 
 class _WeightImages:
@@ -56,6 +65,7 @@ def _launch_fwd(emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _We
     H, W = w1.shape
     out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
     flops = 2.0 * E * (nb * H + H * W)
+    mode = forward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
     ws, ready = cache.get(w1, mode, 0, ws_bytes)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):

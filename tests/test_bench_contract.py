@@ -62,8 +62,12 @@ def test_bench_line_traffic_is_measured_for_the_dominant_kernel(device):
         if name.startswith(("tp_", "radial_mlp", "node_linear", "gate")):
             assert k["traffic"] is not None and k["traffic"] > 0, (name, k)
     for name, k in regions.items():
-        if name.startswith("radial_mlp"):  # the MLP is priced on the pipe it executes on
-            assert k["peak"] == 2500.0 and abs(k["frac"] - 6.0 * k["algorithmic_fp32_tflops"] / 2500.0) < 1e-9
+        if name.startswith("radial_mlp"):  # the MLP is priced on what it executes: 3 (fp16 forward) / 6 (bf16) products
+            products = 3.0 if name == "radial_mlp_fwd" else 6.0
+            assert abs(k["frac_mfma"] - products * k["algorithmic_fp32_tflops"] / 2500.0) < 1e-9
+            assert abs(k["frac_hbm"] - k["hbm_gbps"] / 8000.0) < 1e-9
+            assert k["frac"] == max(k["frac_mfma"], k["frac_hbm"]) and k["bound"] in ("mfma", "hbm")
+            assert k["peak"] == (2500.0 if k["bound"] == "mfma" else 8000.0)
 
 
 def test_profile_summariser_classifies_every_generated_kernel():
@@ -76,6 +80,9 @@ def test_profile_summariser_classifies_every_generated_kernel():
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import summarize_profile as sp
 
+    assert sp.region_of("void nqa::radial_mlp_fwd_split_bal_kernel<128, true>(float const*, float const*)") == ("radial_mlp_fwd", "main")
+    assert sp.region_of("void nqa::radial_mlp_bwd_bf16x6_kernel<128, 0, false>(float const*)") == ("radial_mlp_bwd", "main")
+    assert sp.region_of("nqa::radial_mlp_split_w1_fwd_f16_kernel(float const*)") == ("radial_mlp_fwd", "helper")
     spec_dir = os.path.join(ROOT, "nequip_amd", "csrc", "generated_spec")
     files = glob.glob(os.path.join(spec_dir, "*.hip"))
     if not files:

@@ -1,7 +1,8 @@
 """Fused MFMA radial MLP (nqa_radial_mlp_fwd/bwd) against the oracle's ScalarMLPFunction restatement
 (oracle/nn.py::scalar_mlp following nequip/nn/mlp.py:141-156,262-268).  float32, tolerance 1e-5 relative to
-the output scale, for both GEMM modes: exact-fp32 MFMA (only the summation order differs from the CPU mm) and the
-default split-bf16 mode (three exact bf16 terms per operand, six partial products, fp32 accumulation)."""
+the output scale, for the GEMM modes: exact-fp32 MFMA (only the summation order differs from the CPU mm), the split-bf16
+mode (three exact bf16 terms per operand, six partial products, fp32 accumulation) and the default: forward on the
+two-plane fp16 split of power-of-two scaled operands (three partial products), backward on the bf16 split."""
 
 import math
 
@@ -11,9 +12,14 @@ import torch
 from oracle import nn as onn
 
 
-@pytest.fixture(params=["bf16x6", "fp32"])
+def _set_mode(monkeypatch, mode):
+    monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if mode == "fp32" else "0")
+    monkeypatch.setenv("NQA_MLP_FWD_F16", "0" if mode == "bf16x6" else "1")
+
+
+@pytest.fixture(params=["f16x3", "bf16x6", "fp32"])
 def mlp_mode(request, monkeypatch):
-    monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if request.param == "fp32" else "0")
+    _set_mode(monkeypatch, request.param)
     return request.param
 
 
@@ -65,8 +71,8 @@ def test_radial_mlp_split_bf16_has_fp32_accuracy(device, monkeypatch):
 
     mlp = mlp.to(device)
     errs = {}
-    for mode in ("fp32", "bf16x6"):
-        monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if mode == "fp32" else "0")
+    for mode in ("fp32", "bf16x6", "f16x3"):
+        _set_mode(monkeypatch, mode)
         e_dev = emb.to(device).requires_grad_(True)
         out = mlp(e_dev)
         (ge,) = torch.autograd.grad(out, e_dev, g.to(device))
@@ -77,9 +83,54 @@ def test_radial_mlp_split_bf16_has_fp32_accuracy(device, monkeypatch):
     print("max error / max|ref| vs float64: cpu fp32", (err_cpu, gerr_cpu), errs)
     for mode, (ef, eb) in errs.items():
         assert ef < 2e-6 and eb < 4e-6, (mode, ef, eb)
-    # split-bf16 within 3x of the exact-fp32 kernels' own rounding error
-    assert errs["bf16x6"][0] < 3 * max(errs["fp32"][0], err_cpu)
-    assert errs["bf16x6"][1] < 3 * max(errs["fp32"][1], gerr_cpu)
+    # the split modes within 3x of the exact-fp32 kernels' own rounding error
+    for mode in ("bf16x6", "f16x3"):
+        assert errs[mode][0] < 3 * max(errs["fp32"][0], err_cpu), mode
+        assert errs[mode][1] < 3 * max(errs["fp32"][1], gerr_cpu), mode
+
+
+@pytest.mark.gpu
+def test_radial_mlp_f16x3_forward_is_scale_robust(device, monkeypatch):
+    """fp16 has five exponent bits: the forward scales every hidden row and every 32-column weight tile by a power of
+    two before splitting it.  Rows and column tiles whose magnitudes differ by many orders (embedding rows down to 1e-12
+    of the largest -- edges at the cutoff --, a zero row, weight columns from 1e-6 to 1e+5) must come out at the fp32
+    level RELATIVE TO THEIR OWN row x tile scale, like the bf16 split (fp32 exponent range) and the exact mode."""
+    from nequip_amd.nn.mlp import ScalarMLPFunction
+
+    torch.manual_seed(11)
+    E, H, W = 640, 128, 256
+    mlp = ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=1, hidden_layers_width=H).eval()
+    with torch.no_grad():
+        col = torch.ones(W)
+        col[32:64] = 1e-6
+        col[64:96] = 1e5
+        col[96:128] = 3e-3
+        col[130] = 1e-4  # one small column inside an O(1) tile: precision relative to the tile, not to itself
+        mlp.mlp[2].weight.mul_(col)
+    emb = torch.randn(E, 8) * 0.7
+    row = torch.ones(E)
+    row[100:200] = 1e-4
+    row[200:300] = 1e-8
+    row[300:400] = 1e-12
+    row[400:420] = 30.0
+    emb = emb * row[:, None]
+    emb[7] = 0.0
+    w0, w1 = mlp.mlp[0].weight.detach(), mlp.mlp[2].weight.detach()
+    ref = onn.scalar_mlp(emb.double(), [w0.double(), w1.double()], "silu")
+    # scale of (row, tile): largest |ref| of the row within the 32-column tile
+    scale = ref.abs().reshape(E, W // 32, 32).amax(dim=2, keepdim=True).expand(E, W // 32, 32).reshape(E, W)
+    scale = scale.clamp_min(1e-300)
+    mlp = mlp.to(device)
+    errs = {}
+    for mode in ("fp32", "bf16x6", "f16x3"):
+        _set_mode(monkeypatch, mode)
+        out = mlp(emb.to(device)).cpu().double()
+        assert torch.isfinite(out).all(), mode
+        assert torch.equal(out[7], torch.zeros(W, dtype=torch.float64)), mode
+        errs[mode] = float(((out - ref).abs() / scale).max())
+    print("max error relative to the (row, tile) scale:", errs)
+    assert errs["f16x3"] < 3e-6 and errs["bf16x6"] < 3e-6 and errs["fp32"] < 3e-6, errs
+    assert errs["f16x3"] < 3 * max(errs["fp32"], errs["bf16x6"]) + 5e-7, errs
 
 
 def _force_matching_loss(mlp_fn, emb, v, f_t):
