@@ -1,0 +1,60 @@
+/*
+ * nequip_amd_torch.h -- what libnequip_amd_torch.so provides (nequip_amd/csrc/torch_ops/nequip_amd_torch.cpp).
+ *
+ * The library registers the inference subset of the `nequip_amd::` dispatcher ops from C++ (TORCH_LIBRARY), so that an
+ * AOTInductor package of the HIP-backed model (`nequip_amd.utils.aot.aot_export_model`, the reference's
+ * `nequip-compile --mode aotinductor`, nequip/scripts/compile.py:248-344) runs in a process without a Python
+ * interpreter.  It replaces, for such hosts, the reference's `import_custom_ops_libs` step
+ * (nequip/utils/aoti_metadata.py:40-54: importing the Python modules named by the package's `nequip_custom_ops_libs`
+ * entry): dlopen / link this library before constructing torch::inductor::AOTIModelPackageLoader.
+ *
+ * Ops (schemas identical to the Python registrations; CUDA dispatch key = HIP on ROCm builds; no CPU kernels):
+ *   tp_scatter_fwd(Tensor x, Tensor edge_attr, Tensor edge_weight, Tensor edge_dst, Tensor edge_src, str plan) -> Tensor
+ *   tp_scatter_bwd(Tensor grad_out, Tensor x, Tensor edge_attr, Tensor edge_weight, Tensor edge_dst, Tensor edge_src,
+ *                  str plan, bool need_x, bool need_y, bool need_w) -> (Tensor, Tensor, Tensor)
+ *   edge_vectors(Tensor pos, Tensor? cell, Tensor edge_index, Tensor? shift, Tensor? batch) -> Tensor
+ *   edge_vectors_adj(Tensor g_vec, Tensor edge_index, Tensor? shift, Tensor? batch, SymInt num_nodes, SymInt num_frames,
+ *                    bool need_cell) -> (Tensor, Tensor)
+ *   edge_embed_fwd(Tensor edge_vec, Tensor bessel_weights, int lmax, bool want_sh, bool want_emb, int nb,
+ *                  float rmax_recip, float p, float factor, bool f32) -> (Tensor, Tensor)
+ *   edge_embed_bwd(Tensor edge_vec, Tensor bessel_weights, Tensor g_sh, Tensor g_emb, <same configuration>) -> Tensor
+ *   radial_mlp_fwd(Tensor emb, Tensor w0, Tensor w1, float alpha0, float alpha1) -> Tensor
+ *   radial_mlp_bwd(Tensor emb, Tensor w0, Tensor w1, Tensor g, float alpha0, float alpha1) -> Tensor
+ *   node_linear(Tensor x, Tensor wp, Tensor? addend, Tensor? types, str key, float scale, bool transposed) -> Tensor
+ *   gate(Tensor x, str key) -> Tensor
+ *   gate_bwd(Tensor x, Tensor g, str key) -> Tensor
+ * `plan` / `key` are the canonical texts of the module constructor arguments (nequip_amd/nn/_tp_scatter_ops.py::plan_key,
+ * nequip_amd/o3/_node_ops.py::linear_key / gate_key) that an exported graph carries as string constants.
+ *
+ * The C functions below expose the host tables derived from those texts (tests compare them byte for byte with the Python
+ * host's; no GPU involved).
+ */
+#ifndef NEQUIP_AMD_TORCH_H
+#define NEQUIP_AMD_TORCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1: the ops of this process are (or would be) the ones defined by this library's TORCH_LIBRARY block */
+int nqa_torch_ops_registered_here(void);
+
+/* node_linear tables of `key` (transposed != 0: the adjoint map): chunk records of 8 int32, instruction records of 4
+ * int32 (include/nequip_amd.h, nqa_node_linear).  Returns (n_chunk_int32 << 16) | n_instr_int32, or -1; copies when the
+ * capacities (in int32) suffice.  dims = {dim_in, dim_out, weight_stride}. */
+int nqa_torch_linear_tables(const char* key, int transposed, int32_t* chunks, int32_t chunks_cap, int32_t* instr,
+                            int32_t instr_cap, int64_t* dims);
+/* gather indices that turn packed forward weights into the packed weights of the adjoint map; returns their number */
+int64_t nqa_torch_linear_transpose_perm(const char* key, int64_t* out, int64_t cap);
+/* gate column table (32-byte records; which = 0 forward, 1 backward); returns its size in bytes; dims = {dim_in, dim_out} */
+int64_t nqa_torch_gate_table(const char* key, int which, uint8_t* out, int64_t cap, int64_t* dims);
+/* out7 = {dim_in1, dim_in2, dim_out, weight_numel, out_needs_zero, prefer_fused_bwd, fused_rows_ok} of a plan text */
+int nqa_torch_plan_dims(const char* plan, int64_t* out7);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NEQUIP_AMD_TORCH_H */

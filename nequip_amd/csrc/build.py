@@ -4,7 +4,10 @@
 Cross-compiles without a GPU.  The shared object is written next to this file (in-tree, git-ignored)
 so it travels to the GPU box with the repository snapshot.
 
-    python -m nequip_amd.csrc.build [--force] [--jobs N]
+    python -m nequip_amd.csrc.build [--force] [--jobs N] [--no-torch-ops]
+
+Second target (host C++ only): ``libnequip_amd_torch.so`` + ``nequip_amd_aoti_run`` -- the dispatcher ops registered
+from C++ and a package runner for deployments without a Python interpreter (``build_torch_ops``).
 """
 
 from __future__ import annotations
@@ -142,9 +145,60 @@ def build(force: bool = False, jobs: int = 0, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+TORCH_LIB_NAME = "libnequip_amd_torch.so"
+TORCH_LIB_PATH = os.path.join(HERE, TORCH_LIB_NAME)
+RUNNER_PATH = os.path.join(HERE, "nequip_amd_aoti_run")
+
+
+def _cxx() -> str:
+    for cand in (os.environ.get("CXX"), shutil.which("g++"), shutil.which("c++")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("no C++ compiler found for libnequip_amd_torch.so (set CXX)")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = True):
+    """``libnequip_amd_torch.so`` (the dispatcher ops registered from C++, ``torch_ops/nequip_amd_torch.cpp``) and the
+    stand-alone package runner ``nequip_amd_aoti_run``: host C++ only (g++ against this interpreter's libtorch), linked to
+    ``libnequip_amd.so`` next to them.  Returns (library path, runner path)."""
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    tdir = os.path.join(HERE, "torch_ops")
+    lib_src, run_src = os.path.join(tdir, "nequip_amd_torch.cpp"), os.path.join(tdir, "aoti_run.cpp")
+    tlib = ce.library_paths()[0]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    common = ["-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+              f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{os.path.join(REPO, 'include')}"]
+    common += [f"-I{p}" for p in ce.include_paths()] + [f"-I{os.path.join(rocm, 'include')}"]
+    link = [f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", f"-L{HERE}"]
+    rpath = ["-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    steps = [
+        (TORCH_LIB_PATH, [lib_src], ["-fPIC", "-shared"], ["-lnequip_amd"]),
+        (RUNNER_PATH, [run_src], [], ["-lnequip_amd_torch", "-lnequip_amd"]),
+    ]
+    for out, srcs, extra, libs in steps:
+        stamp = out + ".stamp"
+        want = _digest(srcs + [os.path.join(REPO, "include", h) for h in ("nequip_amd.h", "nequip_amd_torch.h")]) + "|" + torch.__version__ + "|" + " ".join(common)
+        if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            continue
+        cmd = [_cxx()] + common + extra + srcs + ["-o", out] + link + libs + rpath
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"building {os.path.basename(out)} failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        with open(stamp, "w") as f:
+            f.write(want)
+    if verbose:
+        print(f"[nequip_amd] built {TORCH_LIB_PATH} and {RUNNER_PATH}")
+    return TORCH_LIB_PATH, RUNNER_PATH
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=0)
+    ap.add_argument("--no-torch-ops", action="store_true", help="skip libnequip_amd_torch.so / nequip_amd_aoti_run")
     a = ap.parse_args()
     build(force=a.force, jobs=a.jobs)
+    if not a.no_torch_ops:
+        build_torch_ops(force=a.force)
