@@ -422,18 +422,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
                                                  0);
 }
 
-// ---- two-plane fp16 split ("f16x3"): x = h + l / 4096 with h = fp16(x), l = fp16((x - h) * 4096) represents x to
-// 2^-22 |x| (two 11-bit significands), so a product needs three matrix instructions (h h, h l, l h; the dropped l l term
-// is 2^-24 of the product) instead of the six of the three-plane bf16 split.  fp16 has no exponent range to spare, so
-// every operand is first multiplied by a power of two that puts the largest magnitude of its group into [2^14, 2^15):
-// weights per 32-column tile (prepass), hidden activations per row (in registers, the row's values sit in one lane
-// pair) -- exact, undone on the accumulators.  Elements below 2^-28 of their group's maximum fall into the fp16
-// subnormals (error <= 2^-29 of the maximum whether or not the matrix pipe flushes them); the low plane stays below
-// 2^15 because |x - h| <= 2^-11 |x|.  Applies where the scale of a row is known before its first k-step, i.e. to the
-// forward GEMM; the backward streams the gradient rows and keeps the bf16 split (fp32 exponent range).
+// ---- two-plane fp16 split ("f16x3"): x = h + l with h = fp16(x), l = fp16(x - h) represents x to 2^-22 |x| (two
+// 11-bit significands), so a product needs three matrix instructions (h h, h l, l h; the dropped l l term is 2^-24 of
+// the product) accumulated into ONE fp32 accumulator, instead of the six of the three-plane bf16 split.  fp16 has no
+// exponent range to spare, so every operand is first multiplied by a power of two that puts the largest magnitude of its
+// group into [2^14, 2^15): weights per 32-column tile (prepass), hidden activations per row (in registers, the row's
+// values sit in one lane pair) -- exact, undone on the accumulators.  With the group's maximum up there, whatever falls
+// below fp16's smallest normal number 2^-14 -- an element under 2^-28 of the maximum, or the low part of an element
+// under 2^-17 of it -- is lost to at most 2^-14 absolute = 2^-28 of the maximum, whether or not the matrix pipe flushes
+// subnormal inputs.  Applies where the scale of a row is known before its first k-step, i.e. to the forward GEMM; the
+// backward streams the gradient rows and keeps the bf16 split (fp32 exponent range).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float kF16LowScale = 4096.f;
 
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -441,7 +441,7 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const
 
 __device__ __forceinline__ void split_pair_f16(float x0, float x1, uint32_t& h, uint32_t& l) {
   const f16x2 hh = {(_Float16)x0, (_Float16)x1};
-  const f16x2 ll = {(_Float16)((x0 - (float)hh[0]) * kF16LowScale), (_Float16)((x1 - (float)hh[1]) * kF16LowScale)};
+  const f16x2 ll = {(_Float16)(x0 - (float)hh[0]), (_Float16)(x1 - (float)hh[1])};
   h = __builtin_bit_cast(uint32_t, hh);
   l = __builtin_bit_cast(uint32_t, ll);
 }
@@ -770,7 +770,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
   constexpr int NV = TILE / NTH;
   static_assert(TILE % NTH == 0, "tile must divide evenly over the workgroup");
   constexpr int kTS = 36;
-  __shared__ float w0s[H * kMaxNb];
+  // (the first-layer weights come straight from global memory -- L2 -- once per block, in the A-fragment order of the
+  // hidden-layer MFMA: 2 KiB per wavefront, and 4 KiB of LDS less: three workgroups per CU fit in F16 mode)
   __shared__ u32x4 as[2][TILE];
   __shared__ __align__(16) float tbuf[4 * 32 * kTS];
   const int tid = threadIdx.x;
@@ -806,10 +807,6 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
   load_ev(blk, ev);
 #pragma unroll
   for (int c = 0; c < kMaxNb; ++c) evn[c] = 0.f;
-  for (int i = tid; i < H * kMaxNb; i += NTH) {
-    const int k = i / kMaxNb, c = i - k * kMaxNb;
-    w0s[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
-  }
   u32x4 pre[NV];
   auto stage_load = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
@@ -829,12 +826,20 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
   float row_scale = 1.f;  // F16: inverse of the power of two this lane's row was multiplied by
   auto hidden = [&](const float (&e)[kMaxNb], bool row_ok) __attribute__((always_inline)) {
     float hv[F16 ? (H / 32) * 16 : 1];
+    float w0v[H / 32][kMaxNb / 2];  // all requests first: one L2 latency per block, not sixteen
+#pragma unroll
+    for (int kb = 0; kb < H / 32; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const int c = 2 * s2 + half;
+        w0v[kb][s2] = W0[(c < nb ? c : 0) * H + kb * 32 + l31];
+      }
 #pragma unroll
     for (int kb = 0; kb < H / 32; ++kb) {
       f32x16 hacc = {0};
 #pragma unroll
       for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
-        const float av = w0s[(kb * 32 + l31) * kMaxNb + 2 * s2 + half];
+        const float av = (2 * s2 + half) < nb ? w0v[kb][s2] * a0 : 0.f;
         const float bv = half ? e[2 * s2 + 1] : e[2 * s2];
         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
       }
@@ -876,20 +881,16 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
   hidden(ev, blk * kMlpRows + wv * 32 + l31 < E);
 
   float* __restrict__ tb = tbuf + wv * (32 * kTS);
-  // bf16: pa + pb (large + small partial products).  F16: (pa + (pb + pc) / 4096) * rs * tile_scale with pa = h h,
-  // pb = h l, pc = l h and rs the row scale of the unit the accumulators belong to.
-  auto emit = [&](const f32x16& pa, const f32x16& pb, const f32x16& pc, int tile, int64_t wrow0, float rs)
-      __attribute__((always_inline)) {
+  // bf16: pa + pb (large + small partial products).  F16: (pa + pb) * rs * tile_scale with rs the row scale of the unit
+  // the accumulators belong to.
+  auto emit = [&](const f32x16& pa, const f32x16& pb, int tile, int64_t wrow0, float rs) __attribute__((always_inline)) {
     if constexpr (F16) {
       const float f = rs * tile_scale[tile];
-      const float fl = f * (1.f / kF16LowScale);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(tb + l31 * kTS + 8 * g + 4 * half) =
-            make_float4(fmaf(pb[4 * g] + pc[4 * g], fl, pa[4 * g] * f),
-                        fmaf(pb[4 * g + 1] + pc[4 * g + 1], fl, pa[4 * g + 1] * f),
-                        fmaf(pb[4 * g + 2] + pc[4 * g + 2], fl, pa[4 * g + 2] * f),
-                        fmaf(pb[4 * g + 3] + pc[4 * g + 3], fl, pa[4 * g + 3] * f));
+            make_float4((pa[4 * g] + pb[4 * g]) * f, (pa[4 * g + 1] + pb[4 * g + 1]) * f,
+                        (pa[4 * g + 2] + pb[4 * g + 2]) * f, (pa[4 * g + 3] + pb[4 * g + 3]) * f);
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -917,8 +918,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
   int prev_tile = 0;
   int64_t prev_row0 = 0;
   float prev_rs = 1.f;
-  auto unit = [&](int64_t i, f32x16& accA, f32x16& accB, f32x16& accC, const f32x16& prevA, const f32x16& prevB,
-                  const f32x16& prevC) __attribute__((always_inline)) {
+  auto unit = [&](int64_t i, f32x16& accA, f32x16& accB, const f32x16& prevA, const f32x16& prevB)
+      __attribute__((always_inline)) {
     const int64_t left = (u1 - u0) - i;  // units left including this one
     if (t == 0 && i > 0) {  // entering the next block: its embedding row was requested during the previous tile
       ++blk;
@@ -933,7 +934,6 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
     const u32x4* __restrict__ a = as[buf] + lane;
     accA = (f32x16){0};
     accB = (f32x16){0};
-    if constexpr (F16) accC = (f32x16){0};
     u32x4 fa[2][NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) fa[0][q] = a[q * 64];
@@ -946,9 +946,17 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (F16) {
         const u32x4 &ah = fa[s & 1][0], &al = fa[s & 1][1];
-        accA = mfma_f16(ah, bh[s], accA);
-        accB = mfma_f16(ah, bl[s], accB);
-        accC = mfma_f16(al, bh[s], accC);
+        // the three products rotate over the two accumulators so that no instruction waits for its predecessor
+        // (one accumulator = one dependent chain was measured: 168 registers, three workgroups per CU, 4 % slower)
+        if (s & 1) {
+          accB = mfma_f16(ah, bl[s], accB);
+          accA = mfma_f16(al, bh[s], accA);
+          accB = mfma_f16(ah, bh[s], accB);
+        } else {
+          accA = mfma_f16(ah, bl[s], accA);
+          accB = mfma_f16(al, bh[s], accB);
+          accA = mfma_f16(ah, bh[s], accA);
+        }
       } else {
         const u32x4 &ah = fa[s & 1][0], &am = fa[s & 1][1], &al = fa[s & 1][2];
         accA = mfma_bf16(ah, bh[s], accA);
@@ -960,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s == 1 && i > 0) {
-        emit(prevA, prevB, prevC, prev_tile, prev_row0, prev_rs);
+        emit(prevA, prevB, prev_tile, prev_row0, prev_rs);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -970,16 +978,16 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
     prev_rs = row_scale;
     if (++t == ntiles) t = 0;
   };
-  f32x16 a0A, a0B, a0C, a1A, a1B, a1C;
+  f32x16 a0A, a0B, a1A, a1B;
   const int64_t n = u1 - u0;
   for (int64_t i = 0; i < n; i += 2) {
-    unit(i, a0A, a0B, a0C, a1A, a1B, a1C);
-    if (i + 1 < n) unit(i + 1, a1A, a1B, a1C, a0A, a0B, a0C);
+    unit(i, a0A, a0B, a1A, a1B);
+    if (i + 1 < n) unit(i + 1, a1A, a1B, a0A, a0B);
   }
   if (n & 1)
-    emit(a0A, a0B, a0C, prev_tile, prev_row0, prev_rs);
+    emit(a0A, a0B, prev_tile, prev_row0, prev_rs);
   else
-    emit(a1A, a1B, a1C, prev_tile, prev_row0, prev_rs);
+    emit(a1A, a1B, prev_tile, prev_row0, prev_rs);
 }
 
 // TM (training mode, see nqa_radial_mlp_bwd_train): 0 = inference (g_emb only); 1 = additionally hid_out = silu(P)
