@@ -201,15 +201,16 @@ def kernel_roofline(kname, ks, kernel_steps):
     launches = ks["calls"] / max(kernel_steps, 1)
     if ks.get("flops_per_call", 0) > 0 and kname.startswith("radial_mlp"):
         # GEMM on the matrix cores.  The split kernels execute several 16-bit MFMA partial products per fp32 product
-        # (fp32-accurate): 6 on the three-plane bf16 split (backward, and forward with NQA_MLP_FWD_F16=0), 3 on the
-        # two-plane fp16 split (forward, default).  Two roofs bound such a launch from below -- the EXECUTED 16-bit MFMA
+        # (fp32-accurate): 3 on the two-plane fp16 split (default: forward with per-row / per-tile scales, backward with
+        # a running per-row scale), 6 on the three-plane bf16 split (NQA_MLP_FWD_F16=0 / NQA_MLP_BWD_F16=0; training).  Two roofs bound such a launch from below -- the EXECUTED 16-bit MFMA
         # work against the dense bf16 / fp16 peak, and the rows it writes (forward) or reads (backward) against HBM;
         # `bound` / `achieved` / `frac` are those of the roof that gives the longer lower bound (the larger fraction),
         # the other one is reported next to it.  The algorithmic fp32 FLOP rate (what the reference's fp32 GEMM would be
         # credited with) is there too; with NQA_MLP_EXACT_FP32=1 the kernels run on the fp32 MFMA pipe and that is the
         # roofline.
         split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
-        f16_fwd = kname == "radial_mlp_fwd" and os.environ.get("NQA_MLP_FWD_F16", "") != "0"
+        f16_fwd = ((kname == "radial_mlp_fwd" and os.environ.get("NQA_MLP_FWD_F16", "") != "0")
+                   or (kname == "radial_mlp_bwd" and os.environ.get("NQA_MLP_BWD_F16", "") != "0"))
         r = {
             "bound": "mfma", "kernel": kname, "unit": "TFLOP/s",
             "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],

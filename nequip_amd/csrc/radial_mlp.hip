@@ -550,6 +550,53 @@ __global__ __launch_bounds__(256) void radial_mlp_split_w1_bwd_kernel(const floa
   o[0] = h; o[(int64_t)NT * 64] = m; o[(int64_t)2 * NT * 64] = l;
 }
 
+// f16x3 backward weight fragments: Wb[chunk][s][plane][nt][lane] (plane 0 / 1 = h / l) of the 32-row K chunk scaled by
+// 2^chunk_exp[chunk] (largest magnitude into [2^14, 2^15); exponent clamped to +-100).  One workgroup per chunk.
+__global__ __launch_bounds__(256) void radial_mlp_split_w1_bwd_f16_kernel(const float* __restrict__ W1, float a1, int H,
+                                                                          int W, u32x4* __restrict__ Wb,
+                                                                          int* __restrict__ chunk_exp) {
+  __shared__ float red[4];
+  const int NT = H / 32;
+  const int chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < H * 32; i += 256) {
+    const int j = i >> 5, k = 32 * chunk + (i & 31);
+    if (k < W) m = fmaxf(m, fabsf(W1[(int64_t)j * W + k] * a1));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int ex = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    (void)frexpf(m, &e);
+    ex = 15 - e;
+    ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+  }
+  const float su = ldexpf(1.f, ex);
+  if (tid == 0) chunk_exp[chunk] = ex;
+  for (int idx = tid; idx < 2 * NT * 64; idx += 256) {  // (s, nt, lane)
+    const int lane = idx & 63, nt = (idx >> 6) % NT, sk = idx / (64 * NT);
+    const int j = 32 * nt + (lane & 31), half = lane >> 5;
+    const int k0 = 32 * chunk + 16 * half + 8 * sk;
+    u32x4 h, l;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      const int k = k0 + 2 * tp;
+      const float v0 = k < W ? W1[(int64_t)j * W + k] * a1 * su : 0.f;
+      const float v1 = k + 1 < W ? W1[(int64_t)j * W + k + 1] * a1 * su : 0.f;
+      uint32_t a, b;
+      split_pair_f16(v0, v1, a, b);
+      h[tp] = a; l[tp] = b;
+    }
+    u32x4* __restrict__ o = Wb + ((int64_t)((chunk * 2 + sk) * 2) * NT + nt) * 64 + lane;
+    o[0] = h; o[(int64_t)NT * 64] = l;
+  }
+}
+
 // NW wavefronts (32 edges each) share every staged weight tile: 8 instead of 4 halves the L2 -> LDS weight traffic
 // (1.7 GB per middle-layer launch at NW = 4, i.e. the whole L2 bandwidth for ~100 us).
 // TAN (nqa_radial_mlp_fwd_tangent): the hidden layer fed to the second GEMM is (cemb W0) silu'(emb W0) instead of
@@ -996,7 +1043,14 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
 // Everything happens in the epilogue on the tile that is already on chip; the main loop is the same code.
 // PAIR (nqa_radial_mlp_bwd_paired): the incoming gradient is the sum of two row streams gw[row] + gw2[row] (the two
 // directed edges of a pair wrote their halves separately), added in registers when a chunk is consumed.
-template <int H, int TM, bool PAIR = false>
+// F16 (inference backward, TM = 0): the two-plane fp16 split with a RUNNING per-row scale.  The gradient rows stream in
+// with no scale known in advance, so every row carries an exponent S: its accumulators hold 2^S x the true sums, a chunk
+// is multiplied by 2^(S - chunk_exp[chunk]) (the weights of the chunk were multiplied by 2^chunk_exp[chunk]) before it
+// is split, and S is lowered -- the row's accumulators are multiplied by the power of two that bridges the old and the
+// new scale -- whenever a chunk's largest magnitude would leave fp16's range.  S is set three bits below the limit, so
+// later chunks up to 8x larger pass without a rescale.  Both factors are powers of two: exact.  The error of a product
+// is 2^-22 of the row's (running) maximum x the chunk's weight maximum, the rounding level of the fp32 sum itself.
+template <int H, int TM, bool PAIR = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wb,
@@ -1005,11 +1059,14 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
                                                                     int dbg, const float* __restrict__ cemb,
                                                                     float* __restrict__ hid_out,
                                                                     float* __restrict__ w0_part,
-                                                                    const float* __restrict__ gw2 = nullptr) {
+                                                                    const float* __restrict__ gw2 = nullptr,
+                                                                    const int* __restrict__ chunk_exp = nullptr) {
+  static_assert(!F16 || TM == 0, "the fp16 split is an inference-backward mode");
   // K (= W) is consumed in chunks of 32 columns = two bf16 k-steps; lane (row, half) owns the 16 contiguous floats
   // 32*chunk + 16*half + [0, 16) of its g_w row per chunk: HBM -> registers directly, split in registers.
   constexpr int NT = H / 32;
-  constexpr int CH = 2 * 3 * NT * 64;   // uint4 per chunk of B fragments (24 KiB for H = 128)
+  constexpr int NPL = F16 ? 2 : 3;        // operand planes
+  constexpr int CH = 2 * NPL * NT * 64;   // uint4 per chunk of B fragments (24 KiB for H = 128; 16 KiB in F16 mode)
   constexpr int NV = CH / 256;
   constexpr int GS = H + 1;
   constexpr int kMainBytes = 2 * CH * 16;
@@ -1019,6 +1076,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   __shared__ float w0s[H * kMaxNb];        // [k][c]
   __shared__ float w0t[kMaxNb * H];        // [c][k]
   __shared__ float es[kMlpRows * kMaxNb];  // embedding tile [row][c]
+  __shared__ int rowexp[F16 ? kMlpRows : 1];  // F16: per-row exponents on their way from the row's lane to its registers
   // cotangent tile [row][c] of the second-order mode: only needed after the GEMV pass, so for H = 128 (where LDS caps
   // the occupancy) it reuses w0s' storage; each lane keeps its own cotangent row in registers until then
   __shared__ float cs_own[(TM == 2 && H * kMaxNb < kMlpRows * kMaxNb) ? kMlpRows * kMaxNb : 1];
@@ -1099,6 +1157,21 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+  constexpr int kUnset = 1 << 20;
+  int S = kUnset;                              // F16: exponent of this lane's row (unset while the row is all zero)
+  int we_next = F16 ? chunk_exp[0] : 0;        // F16: weight exponent of the chunk about to be consumed
+  // rows (r, half) of the accumulator registers <- values held by the rows' own lanes (same wavefront: LDS in order)
+  auto rows_from_lanes = [&](int value, int (&out)[16]) __attribute__((always_inline)) {
+    int* __restrict__ rb = rowexp + wv * 32;
+    if (half == 0) rb[l31] = value;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = rb[(r & 3) + 8 * (r >> 2) + 4 * half];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
 
   auto body = [&](int ch, float4 (&pa)[4], float4 (&pc)[4]) {
     const int buf = ch & 1;
@@ -1109,7 +1182,51 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
       }
     }
     // split this chunk's 16 floats into the A fragments of its two k-steps
-    u32x4 ah[2], am[2], al[2];
+    u32x4 ah[2], am[F16 ? 1 : 2], al[2];
+    if constexpr (F16) {
+      const int we = we_next;
+      if (ch + 1 < nchunks) we_next = chunk_exp[ch + 1];
+      float m = 0.f;  // the row's largest magnitude in this chunk (its other 16 values sit in lane ^ 32)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(pa[v].x), fabsf(pa[v].y)), fmaxf(fabsf(pa[v].z), fabsf(pa[v].w))));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      int shift = 0;
+      if (m > 0.f && m < 3.0e38f) {
+        int em;
+        (void)frexpf(m, &em);          // m < 2^em
+        const int cap = 15 - em + we;  // largest S that keeps m 2^(S - we) below 2^15
+        if (cap < S) {
+          int ns = cap - 3;
+          ns = ns > we + 100 ? we + 100 : (ns < we - 100 ? we - 100 : ns);
+          shift = S == kUnset ? 0 : S - ns;
+          S = ns;
+        }
+      }
+      if (ch > 0 && __any(shift > 0)) {  // (rare after the first chunks: a new maximum 8x above every earlier one)
+        int kr[16];
+        rows_from_lanes(shift, kr);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = ldexpf(acc[t][r], -kr[r]);
+      }
+      int q = S == kUnset ? 0 : S - we;
+      q = q > 120 ? 120 : (q < -120 ? -120 : q);
+      const float qs = ldexpf(1.f, q);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t a, b;
+        split_pair_f16(pa[2 * s].x * qs, pa[2 * s].y * qs, a, b);
+        ah[s][0] = a; al[s][0] = b;
+        split_pair_f16(pa[2 * s].z * qs, pa[2 * s].w * qs, a, b);
+        ah[s][1] = a; al[s][1] = b;
+        split_pair_f16(pa[2 * s + 1].x * qs, pa[2 * s + 1].y * qs, a, b);
+        ah[s][2] = a; al[s][2] = b;
+        split_pair_f16(pa[2 * s + 1].z * qs, pa[2 * s + 1].w * qs, a, b);
+        ah[s][3] = a; al[s][3] = b;
+      }
+    } else
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint32_t a, b, c;
@@ -1127,7 +1244,22 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
     const u32x4* __restrict__ bs = bsm + buf * CH + lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      u32x4 fb[3][NT];
+      u32x4 fb[NPL][NT];
+      if constexpr (F16) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) fb[q][t] = bs[((s * 2 + q) * NT + t) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(al[s], fb[0][t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(ah[s], fb[1][t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(ah[s], fb[0][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if (!(dbg & 16) || ch == 0) {  // (ablation bit 16: weight fragments read from LDS for the first chunk only)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -1162,6 +1294,14 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const flo
     if (ch + 1 < nchunks) body(ch + 1, paB, reinterpret_cast<float4(&)[4]>(pcB));
   }
 
+  if constexpr (F16) {  // accumulators back to the true scale: 2^-S of their row
+    int sr[16];
+    rows_from_lanes(S == kUnset ? 0 : S, sr);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = ldexpf(acc[t][r], -sr[r]);
+  }
   // epilogue (exact fp32): pre-activations recomputed on MFMA in the accumulator layout, g_pre = g_h * silu'(pre),
   // one pass through LDS for the NB-wide GEMV -- identical to the fp32 kernel
   float* __restrict__ gp = reinterpret_cast<float*>(smem_raw);
@@ -1313,6 +1453,12 @@ int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, i
 
 int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features) {
   if (hidden <= 0 || out_features <= 0) return -1;
+  if (mode == NQA_MLP_F16X3 && backward) {
+    // backward fragments on the two-plane fp16 split: ceil(W/32) chunks x 2 k-steps x 2 planes x (H/32) x 1 KiB, then
+    // one int per chunk (the exponent the chunk was scaled by)
+    const int64_t nchunks = (out_features + 31) / 32;
+    return nchunks * 2 * 2 * (hidden / 32) * 1024 + ((nchunks * 4 + 255) & ~(int64_t)255);
+  }
   if (mode == NQA_MLP_F16X3 && !backward) {
     // forward fragments on the two-plane fp16 split: ceil(W/32) tiles x (H/16) k-steps x 2 planes x 1 KiB, then one
     // float per tile (the inverse of the tile's power-of-two scale)
@@ -1490,7 +1636,10 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
                         int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
-  if (mode == NQA_MLP_F16X3) mode = NQA_MLP_BF16X6;  // the gradient rows have no known scale: bf16 split (see f16_scale_up)
+  if (mode == NQA_MLP_F16X3 && tm != 0) {
+    set_error("nqa_radial_mlp_bwd_train: NQA_MLP_F16X3 is an inference mode (use NQA_MLP_BF16X6)");
+    return NQA_ERR_UNSUPPORTED;
+  }
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   if (num_edges == 0) return NQA_OK;
@@ -1513,6 +1662,27 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
     const char* v = std::getenv("NQA_MLP_DBG_BWD");
     return v ? std::atoi(v) : 0;
   }();
+  if (mode == NQA_MLP_F16X3) {
+    const int nchunks = (out_features + 31) / 32;
+    u32x4* wb = static_cast<u32x4*>(workspace);
+    int* ce = reinterpret_cast<int*>(static_cast<char*>(workspace) + (int64_t)nchunks * 2 * 2 * (hidden / 32) * 1024);
+    if (!workspace_ready)
+      hipLaunchKernelGGL(radial_mlp_split_w1_bwd_f16_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, b, (float)alpha1,
+                         hidden, out_features, wb, ce);
+    const float* g2 = static_cast<const float*>(grad_edge_weight2);
+#define NQA_MLP_BWD_F16_LAUNCH(HH, PP)                                                                               \
+  hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<HH, 0, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,       \
+                     (float)alpha0, num_basis, out_features, num_edges, o, 0, nullptr, nullptr, nullptr, g2, ce)
+    if (hidden == 128) {
+      if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(128, true);
+      else NQA_MLP_BWD_F16_LAUNCH(128, false);
+    } else {
+      if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(64, true);
+      else NQA_MLP_BWD_F16_LAUNCH(64, false);
+    }
+#undef NQA_MLP_BWD_F16_LAUNCH
+    return launch_status(g2 != nullptr ? "nqa_radial_mlp_bwd_paired" : "nqa_radial_mlp_bwd");
+  }
   if (mode == NQA_MLP_BF16X6) {
     u32x4* wb = static_cast<u32x4*>(workspace);
     const int nfrag = ((out_features + 31) / 32) * 2 * (hidden / 32) * 64;

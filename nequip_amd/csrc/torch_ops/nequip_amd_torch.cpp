@@ -539,7 +539,9 @@ Tensor radial_mlp_bwd(const Tensor& emb_, const Tensor& w0_, const Tensor& w1_, 
   const int32_t nb = (int32_t)emb.size(1), H = (int32_t)w1.size(0), W = (int32_t)w1.size(1);
   TORCH_CHECK(g.scalar_type() == at::kFloat && g.dim() == 2 && g.size(0) == E && g.size(1) == W,
               "nequip_amd::radial_mlp_bwd: g must be float32 [E, W]");
-  const int32_t mode = mlp_mode();
+  int32_t mode = mlp_mode();
+  if (mode == NQA_MLP_BF16X6 && !(std::getenv("NQA_MLP_BWD_F16") && std::getenv("NQA_MLP_BWD_F16")[0] == '0'))
+    mode = NQA_MLP_F16X3;  // (nequip_amd/nn/mlp.py::backward_mode)
   Tensor g_emb = at::empty_like(emb);
   const int64_t ws_bytes = nqa_radial_mlp_workspace_bytes(mode, 1, H, W);
   TORCH_CHECK(ws_bytes >= 0, "nequip_amd::radial_mlp_bwd: workspace query failed");

@@ -33,6 +33,15 @@ def forward_mode(mode: int) -> int:
     return mode
 
 
+def backward_mode(mode: int) -> int:
+    """Mode of the inference backward launches (``nqa_radial_mlp_bwd`` / ``_bwd_paired``): the split-bf16 default runs
+    them on the two-plane fp16 split with a running per-row scale (``NQA_MLP_BWD_F16=0`` keeps the bf16 split).  The
+    training entry points (``_bwd_train``, ``_fwd_tangent``) stay on the bf16 split."""
+    if mode == _lib.NQA_MLP_BF16X6 and os.environ.get("NQA_MLP_BWD_F16", "") not in ("0",):
+        return _lib.NQA_MLP_F16X3
+    return mode
+
+
 from ..utils.tracing import traceable
 
 class _WeightImages:
@@ -84,6 +93,7 @@ def _launch_bwd(emb, w0, w1, alpha0: float, alpha1: float, g_w, mode: int, cache
     H, W = w1.shape
     g_emb = torch.empty_like(emb)
     flops = 2.0 * E * (nb * H * 2 + H * W)
+    mode = backward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
     ws, ready = cache.get(w1, mode, 1, ws_bytes)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
@@ -145,6 +155,7 @@ def _launch_bwd_paired(emb, w0, w1, alpha0: float, alpha1: float, g_a, g_b, mode
     assert g_a.shape == (E, W) and g_b.shape == (E, W) and g_a.is_contiguous() and g_b.is_contiguous()
     g_emb = torch.empty_like(emb)
     flops = 2.0 * E * (nb * H * 2 + H * W)
+    mode = backward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
     ws, ready = cache.get(w1, mode, 1, ws_bytes)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + 2 * W), flops):

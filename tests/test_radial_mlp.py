@@ -15,6 +15,7 @@ from oracle import nn as onn
 def _set_mode(monkeypatch, mode):
     monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if mode == "fp32" else "0")
     monkeypatch.setenv("NQA_MLP_FWD_F16", "0" if mode == "bf16x6" else "1")
+    monkeypatch.setenv("NQA_MLP_BWD_F16", "0" if mode == "bf16x6" else "1")
 
 
 @pytest.fixture(params=["f16x3", "bf16x6", "fp32"])
@@ -131,6 +132,69 @@ def test_radial_mlp_f16x3_forward_is_scale_robust(device, monkeypatch):
     print("max error relative to the (row, tile) scale:", errs)
     assert errs["f16x3"] < 3e-6 and errs["bf16x6"] < 3e-6 and errs["fp32"] < 3e-6, errs
     assert errs["f16x3"] < 3 * max(errs["fp32"], errs["bf16x6"]) + 5e-7, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [False, True])
+def test_radial_mlp_f16x3_backward_running_scale(device, monkeypatch, paired):
+    """The backward streams the gradient rows chunk by chunk with no scale known in advance: the fp16 split carries a
+    running per-row exponent and rescales a row's accumulators when a later chunk outgrows it.  Rows whose chunks
+    differ by 20 orders of magnitude in either direction (small first / large first), rows of 1e-25 and 1e+12, a zero
+    row, and weight column groups from 1e-6 to 1e+5: the error of every row stays at the fp32 level relative to the
+    magnitude sum  |g| |W1| |silu'| |W0|  of that row (what an fp32 evaluation is accurate to), like the bf16 split."""
+    from nequip_amd.nn import mlp as m
+
+    torch.manual_seed(5)
+    E, H, W = 384, 128, 320
+    mod = m.ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=1, hidden_layers_width=H).eval()
+    with torch.no_grad():
+        col = torch.ones(W)
+        col[32:64] = 1e-6
+        col[96:128] = 1e5
+        col[200] = 1e-3
+        mod.mlp[2].weight.mul_(col)
+    emb = torch.randn(E, 8) * 0.7
+    g = torch.randn(E, W)
+    g[10:40, :64] *= 1e-20          # small chunks first, then O(1): rescale on the third chunk
+    g[40:70, 64:] *= 1e-20          # large chunks first: the tail must not be lost relative to the head's scale
+    g[70:100] *= 1e-25
+    g[100:130] *= 1e12
+    for r in range(130, 160):       # staircase: every chunk 30x the previous one
+        for c in range(W // 32):
+            g[r, 32 * c:32 * c + 32] *= 30.0 ** c * 1e-8
+    g[7] = 0.0
+    w0, w1 = mod.mlp[0].weight.detach(), mod.mlp[2].weight.detach()
+    a0, a1 = 1.0 / math.sqrt(8), math.sqrt(2.0) / math.sqrt(H)
+    e64 = emb.double().requires_grad_(True)
+    ref = onn.scalar_mlp(e64, [w0.double(), w1.double()], "silu")
+    (ge64,) = torch.autograd.grad(ref, e64, g.double())
+    pre = emb.double() @ (w0.double() * a0)
+    sig = torch.sigmoid(pre)
+    dsilu = sig * (1 + pre * (1 - sig))
+    denom = ((g.double().abs() @ (w1.double() * a1).abs().T) * dsilu.abs()) @ (w0.double() * a0).abs().T
+    denom = denom.amax(dim=1, keepdim=True).clamp_min(1e-300)
+    mod = mod.to(device)
+    cache = m._WeightImages()
+    cache.validate(mod.mlp[2].weight)
+    errs = {}
+    for mode in ("fp32", "bf16x6", "f16x3"):
+        _set_mode(monkeypatch, mode)
+        args = (emb.to(device), mod.mlp[0].weight.detach(), mod.mlp[2].weight.detach(), a0, a1)
+        if paired:  # the same gradient as two row streams that the kernel adds while loading
+            if mode == "fp32":
+                continue
+            g_a = (g * 0.25).to(device)
+            ge = m._launch_bwd_paired(*args, g_a, (g - g * 0.25).to(device), m.radial_mlp_mode(), cache)
+        else:
+            ge = m._launch_bwd(*args, g.to(device), m.radial_mlp_mode(), cache)
+        ge = ge.cpu().double()
+        assert torch.isfinite(ge).all(), mode
+        assert torch.equal(ge[7], torch.zeros(8, dtype=torch.float64)), mode
+        errs[mode] = float(((ge - ge64).abs() / denom).max())
+    print("max row error / row magnitude sum:", errs)
+    for mode, e in errs.items():
+        assert e < 1e-6, errs
+    assert errs["f16x3"] < 3 * errs["bf16x6"] + 2e-7, errs
 
 
 def _force_matching_loss(mlp_fn, emb, v, f_t):
