@@ -9,7 +9,7 @@ echo "{\"commit\": \"${NQA_COMMIT:-n/a}\"}" > $O/commit.json
 timeout 600 python bench.py > $O/r3_bench_default.json 2> $O/bench_default.err
 timeout 600 bash scripts/profile.sh r3 > $O/profile.log 2>&1
 timeout 300 bash scripts/profile_train.sh r3_train > $O/profile_train.log 2>&1
-for w in si1k aspirin5 cu20k cu100k train256 water10k_S water10k_M water10k_L; do
+for w in si1k aspirin5 cu20k cu100k train256 water10k_S water10k_M water10k_L water10k_XL; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-pmc 2>/dev/null >> $O/r3_other_workloads.jsonl
 done
 cp $R/gpurun_out/prof_r3/r3_*  $R/gpurun_out/prof_r3/bench_trace.json $O/ 2>/dev/null
