@@ -469,14 +469,90 @@ __device__ __forceinline__ f32x16n nl_mfma_bf16(const nl_u32x4& a, const nl_u32x
                                                  0, 0, 0);
 }
 
+// ---- two-plane fp16 split with a running per-column scale (default; NQA_NODE_F16=0 keeps the bf16 split) ----------------
+// As in the radial MLP's backward (radial_mlp.hip): x = h + l with h = fp16(x), l = fp16(x - h) carries 22 significand
+// bits, three products h.h + h.l + l.h per fp32 product instead of six.  fp16's range is bridged by exact powers of two:
+// every 16-row K block of a weight matrix is stored multiplied by 2^e (largest magnitude into [2^14, 2^15); e per (atom
+// type, instruction, K block), kept behind the fragments), and every output COLUMN (atom, component) -- a lane of the
+// accumulator layout, so all of this is lane-local -- carries a running exponent S: its accumulators hold 2^S x the true
+// sums, the 16 x-values of a K block are multiplied by 2^(S - e) before they are split, and when a block's largest
+// magnitude would leave the range S drops (three bits below the limit) and the lane's accumulators are multiplied by the
+// bridging power of two.  The epilogue multiplies by 2^-S.
+using nl_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using nl_f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ f32x16n nl_mfma_f16(const nl_u32x4& a, const nl_u32x4& b, const f32x16n& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(nl_f16x8, a), __builtin_bit_cast(nl_f16x8, b), c, 0,
+                                                0, 0);
+}
+__device__ __forceinline__ void nl_split_pair_f16(float x0, float x1, uint32_t& h, uint32_t& l) {
+  const nl_f16x2 hh = {(_Float16)x0, (_Float16)x1};
+  const nl_f16x2 ll = {(_Float16)(x0 - (float)hh[0]), (_Float16)(x1 - (float)hh[1])};
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, ll);
+}
+
 struct NodePackArgs {
   const float* __restrict__ w;  // [n_types][wstride]
   nl_u32x4* __restrict__ out;   // [n_types][frag_stride]
+  int32_t* __restrict__ wexp;   // F16: [n_types][exp_stride] exponent of every (instruction, 16-row K block)
   int64_t wstride, frag_stride;
-  int32_t n_instr, n_types;
+  int32_t n_instr, n_types, exp_stride;
+  int32_t exp_off[kMaxNodeInstr];
   int32_t mul_in[kMaxNodeInstr], mul_out[kMaxNodeInstr], w_off[kMaxNodeInstr];
   int32_t frag_off[kMaxNodeInstr + 1];  // first fragment-lane (uint4 index) of every instruction, within one type
 };
+
+// F16: exponent of every (type, instruction, K block): one thread each, over the block's 16 x mul_out values
+__global__ __launch_bounds__(256) void node_weights_exp_kernel(const NodePackArgs a) {
+  const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (idx >= a.exp_stride * a.n_types) return;
+  const int t = idx / a.exp_stride, r = idx - t * a.exp_stride;
+  int q = 0;
+  while (q + 1 < a.n_instr && r >= a.exp_off[q + 1]) ++q;
+  const int k16 = r - a.exp_off[q];
+  const float* __restrict__ wq = a.w + (int64_t)t * a.wstride + a.w_off[q];
+  float m = 0.f;
+  for (int u = 16 * k16; u < min(16 * k16 + 16, a.mul_in[q]); ++u)
+    for (int c = 0; c < a.mul_out[q]; ++c) m = fmaxf(m, fabsf(wq[(int64_t)u * a.mul_out[q] + c]));
+  int ex = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    (void)frexpf(m, &e);
+    ex = 15 - e;
+    ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+  }
+  a.wexp[idx] = ex;
+}
+
+__global__ __launch_bounds__(256) void node_weights_pack_f16_kernel(const NodePackArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (type, fragment (q, k16, tile), lane)
+  const int64_t per_type = a.frag_stride / 2;                    // one thread writes the two planes
+  if (idx >= per_type * a.n_types) return;
+  const int t = (int)(idx / per_type);
+  const int64_t r = idx - (int64_t)t * per_type;
+  int q = 0;
+  while (q + 1 < a.n_instr && r * 2 >= a.frag_off[q + 1]) ++q;
+  const int64_t f = r - a.frag_off[q] / 2;  // (k16 * nct + tile) * 64 + lane
+  const int lane = (int)(f & 63);
+  const int nct = (a.mul_out[q] + 31) / 32;
+  const int tile = (int)((f >> 6) % nct), k16 = (int)((f >> 6) / nct);
+  const int c = 32 * tile + (lane & 31);
+  const int u0 = 16 * k16 + 8 * (lane >> 5);
+  const float* __restrict__ wq = a.w + (int64_t)t * a.wstride + a.w_off[q];
+  const float su = ldexpf(1.f, a.wexp[t * a.exp_stride + a.exp_off[q] + k16]);
+  nl_u32x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int u = u0 + 2 * e;
+    const float v0 = (c < a.mul_out[q] && u < a.mul_in[q]) ? wq[(int64_t)u * a.mul_out[q] + c] * su : 0.f;
+    const float v1 = (c < a.mul_out[q] && u + 1 < a.mul_in[q]) ? wq[(int64_t)(u + 1) * a.mul_out[q] + c] * su : 0.f;
+    uint32_t x, y;
+    nl_split_pair_f16(v0, v1, x, y);
+    h[e] = x; l[e] = y;
+  }
+  nl_u32x4* __restrict__ o = a.out + (int64_t)t * a.frag_stride + a.frag_off[q] + ((f >> 6) * 2) * 64 + lane;
+  o[0] = h; o[64] = l;
+}
 
 __global__ __launch_bounds__(256) void node_weights_pack_kernel(const NodePackArgs a) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (type, fragment (q, k16, tile), lane)
@@ -510,6 +586,8 @@ __global__ __launch_bounds__(256) void node_weights_pack_kernel(const NodePackAr
 struct NodeLinearPackedArgs {
   NodeLinearArgs<float> base;            // base.w is unused
   const nl_u32x4* __restrict__ wf;       // packed weights
+  const int32_t* __restrict__ wexp;      // F16: [n_types][exp_stride], index base.instr[q].pad + K block
+  int32_t exp_stride;
   int64_t frag_stride;                   // uint4 per atom type
   int32_t frag_off[kMaxNodeInstr];       // uint4 offset of every instruction's fragments
   // unit enumeration: a group = the 64-channel chunks of ONE output block (same instructions, same x columns); unit u of a
@@ -528,9 +606,10 @@ struct NodeStage {  // one (instruction, atom type, 32-channel K slab) step of a
   bool valid;
 };
 
-template <int D>
+template <int D, bool F16>
 __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPackedArgs& pa, const NodeChunk& ch, int64_t g,
                                                            float* __restrict__ xs, int unit) {
+  constexpr int NPL = F16 ? 2 : 3;  // operand planes
   const NodeLinearArgs<float>& a = pa.base;
   constexpr int NZT = 32 / D;
   constexpr int P = D == 1 ? 1 : ((D + 3) / 4) * 4;
@@ -642,20 +721,80 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
   // (a stage whose slab holds 16 channels or fewer -- multiplicities that are not multiples of 32 -- repeats its block
   // with B = 0: branch-free, wasted work only for such shapes).  They come out of the L2 (all wavefronts of a chunk read
   // the same 12 KiB per stage) and land behind the LDS write / B split; double-buffering them (measured) buys nothing.
-  nl_u32x4 Af[1][2][3];
+  nl_u32x4 Af[1][2][NPL];
+  int we_blk = 0;  // F16: exponent of the K block whose fragments are in Af
   auto load_a = [&](int buf, const NodeStage& st, int k16) {
     const nl_u32x4* __restrict__ p = pa.wf + (int64_t)st.t * pa.frag_stride + pa.frag_off[st.q] + lane +
-                                     ((int64_t)(k16 * nct + ct0) * 3) * 64;
-    Af[buf][0][0] = p[0]; Af[buf][0][1] = p[64]; Af[buf][0][2] = p[128];
-    if (two_tiles) { Af[buf][1][0] = p[192]; Af[buf][1][1] = p[256]; Af[buf][1][2] = p[320]; }
+                                     ((int64_t)(k16 * nct + ct0) * NPL) * 64;
+    if constexpr (F16) {
+      Af[buf][0][0] = p[0]; Af[buf][0][1] = p[64];
+      if (two_tiles) { Af[buf][1][0] = p[128]; Af[buf][1][1] = p[192]; }
+      we_blk = pa.wexp[st.t * pa.exp_stride + a.instr[st.q].pad + k16];
+    } else {
+      Af[buf][0][0] = p[0]; Af[buf][0][1] = p[64]; Af[buf][0][2] = p[128];
+      if (two_tiles) { Af[buf][1][0] = p[192]; Af[buf][1][1] = p[256]; Af[buf][1][2] = p[320]; }
+    }
   };
   f32x16n acc0 = {0}, acc1 = {0};
+  constexpr int kUnset = 1 << 20;
+  int Scol = kUnset;  // F16: running exponent of this lane's column
   auto block = [&](int buf, int s, bool on) {
     // B fragment: the 8 k-values 16 s + 8 half + e of this lane's column, split in registers
     const float* __restrict__ xb = xs + zl * S + m;
     float bq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bq[e] = xb[(16 * s + 8 * half + e) * D];
+    if constexpr (F16) {
+      const int we = we_blk;
+      float mx = 0.f;  // the column's largest magnitude in this K block (its other 8 values sit in lane ^ 32)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(on ? bq[e] : 0.f));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      int shift = 0;
+      if (mx > 0.f && mx < 3.0e38f) {
+        int em;
+        (void)frexpf(mx, &em);
+        const int cap = 15 - em + we;
+        if (cap < Scol) {
+          int ns = cap - 3;
+          ns = ns > we + 100 ? we + 100 : (ns < we - 100 ? we - 100 : ns);
+          shift = Scol == kUnset ? 0 : Scol - ns;
+          Scol = ns;
+        }
+      }
+      if (__any(shift > 0)) {  // (rare: a block 8x above everything the column has seen)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc0[r] = ldexpf(acc0[r], -shift);
+          acc1[r] = ldexpf(acc1[r], -shift);
+        }
+      }
+      int q = Scol == kUnset ? 0 : Scol - we;
+      q = q > 120 ? 120 : (q < -120 ? -120 : q);
+      const float qs = ldexpf(1.f, q);
+      nl_u32x4 Bh, Bl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = on ? bq[2 * e] * qs : 0.f, v1 = on ? bq[2 * e + 1] * qs : 0.f;
+        uint32_t x, y;
+        nl_split_pair_f16(v0, v1, x, y);
+        Bh[e] = x; Bl[e] = y;
+      }
+      // three partial products per tile, small ones first; the two tiles alternate
+      if (two_tiles) {
+        acc0 = nl_mfma_f16(Af[buf][0][1], Bh, acc0);
+        acc1 = nl_mfma_f16(Af[buf][1][1], Bh, acc1);
+        acc0 = nl_mfma_f16(Af[buf][0][0], Bl, acc0);
+        acc1 = nl_mfma_f16(Af[buf][1][0], Bl, acc1);
+        acc0 = nl_mfma_f16(Af[buf][0][0], Bh, acc0);
+        acc1 = nl_mfma_f16(Af[buf][1][0], Bh, acc1);
+      } else {
+        acc0 = nl_mfma_f16(Af[buf][0][1], Bh, acc0);
+        acc0 = nl_mfma_f16(Af[buf][0][0], Bl, acc0);
+        acc0 = nl_mfma_f16(Af[buf][0][0], Bh, acc0);
+      }
+      return;
+    }
     nl_u32x4 Bh, Bm, Bl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -741,6 +880,14 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
   constexpr int RUN4E = kNLW * D / 4;
   constexpr int XV4E = (NZT * RUN4E + 63) / 64;
   static_assert(NZT * SE <= kNLXS, "result slab too small");
+  if constexpr (F16) {  // back to the true scale: 2^-S of this lane's column
+    const int sb = Scol == kUnset ? 0 : Scol;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = ldexpf(acc0[r], -sb);
+      acc1[r] = ldexpf(acc1[r], -sb);
+    }
+  }
   if (zlr < NZT) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -794,6 +941,7 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
 
 constexpr int kNLWavesPerWG = 4;  // independent wavefronts (units) per workgroup: no barrier, only fewer dispatches
 
+template <bool F16>
 __global__ __launch_bounds__(64 * kNLWavesPerWG, 3) void node_linear_wave_bf16_kernel(const NodeLinearPackedArgs pa) {
   __shared__ __align__(16) float xs_all[kNLWavesPerWG * kNLXS];
   const NodeLinearArgs<float>& a = pa.base;
@@ -808,11 +956,11 @@ __global__ __launch_bounds__(64 * kNLWavesPerWG, 3) void node_linear_wave_bf16_k
   const NodeChunk ch = a.chunks[pa.grp_chunk0[gi] + local % n];
   const int64_t g = (int64_t)(local / n);
   switch (ch.d) {
-    case 1: node_linear_wave_bf16_unit<1>(pa, ch, g, xs, unit); break;
-    case 3: node_linear_wave_bf16_unit<3>(pa, ch, g, xs, unit); break;
-    case 5: node_linear_wave_bf16_unit<5>(pa, ch, g, xs, unit); break;
-    case 7: node_linear_wave_bf16_unit<7>(pa, ch, g, xs, unit); break;
-    case 9: node_linear_wave_bf16_unit<9>(pa, ch, g, xs, unit); break;
+    case 1: node_linear_wave_bf16_unit<1, F16>(pa, ch, g, xs, unit); break;
+    case 3: node_linear_wave_bf16_unit<3, F16>(pa, ch, g, xs, unit); break;
+    case 5: node_linear_wave_bf16_unit<5, F16>(pa, ch, g, xs, unit); break;
+    case 7: node_linear_wave_bf16_unit<7, F16>(pa, ch, g, xs, unit); break;
+    case 9: node_linear_wave_bf16_unit<9, F16>(pa, ch, g, xs, unit); break;
     default: break;
   }
 }
@@ -1147,8 +1295,26 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
 namespace {
 // fragment layout of one atom type: per instruction ceil(mul_in / 16) x ceil(mul_out / 32) fragments of 3 planes x 64 lanes
 // (uint4 each); mul_out is that of the output block the instruction feeds.  Returns the uint4 count per type, -1 on error.
+// two-plane fp16 split with running column scales (default) or the three-plane bf16 split (NQA_NODE_F16=0).  Read at every
+// call: a packed buffer must be used in the mode it was packed in (the Python host keys its cache on the variable).
+bool node_f16() {
+  const char* e = std::getenv("NQA_NODE_F16");
+  return e == nullptr || e[0] != '0';
+}
+
+// exponent table of the F16 layout: one int per (instruction, 16-row K block); returns the count per type
+int32_t node_exp_layout(const nqa::NodeInstr* instr, int32_t n_instr, int32_t* exp_off) {
+  int32_t off = 0;
+  for (int q = 0; q < n_instr; ++q) {
+    exp_off[q] = off;
+    off += (instr[q].mul_in + 15) / 16;
+  }
+  exp_off[n_instr] = off;
+  return off;
+}
+
 int64_t node_frag_layout(const nqa::NodeChunk* chunks, int32_t n_chunks, const nqa::NodeInstr* instr, int32_t n_instr,
-                         int32_t* frag_off, int32_t* mul_out) {
+                         int32_t* frag_off, int32_t* mul_out, int planes = node_f16() ? 2 : 3) {
   for (int q = 0; q < n_instr; ++q) mul_out[q] = 0;
   for (int c = 0; c < n_chunks; ++c)
     for (int q = chunks[c].instr_begin; q < chunks[c].instr_end; ++q) {
@@ -1158,7 +1324,7 @@ int64_t node_frag_layout(const nqa::NodeChunk* chunks, int32_t n_chunks, const n
   int64_t off = 0;
   for (int q = 0; q < n_instr; ++q) {
     frag_off[q] = (int32_t)off;
-    off += (int64_t)((instr[q].mul_in + 15) / 16) * ((mul_out[q] + 31) / 32) * 3 * 64;
+    off += (int64_t)((instr[q].mul_in + 15) / 16) * ((mul_out[q] + 31) / 32) * planes * 64;
     if (off > 2147483647LL) return -1;
   }
   frag_off[n_instr] = (int32_t)off;
@@ -1174,7 +1340,10 @@ int64_t nqa_node_weights_pack_bytes(const void* chunk_table, int32_t n_chunks, c
   int32_t frag_off[nqa::kMaxNodeInstr + 1], mul_out[nqa::kMaxNodeInstr];
   const int64_t per_type = node_frag_layout(static_cast<const nqa::NodeChunk*>(chunk_table), n_chunks,
                                             static_cast<const nqa::NodeInstr*>(instr_table), n_instr, frag_off, mul_out);
-  return per_type < 0 ? -1 : per_type * 16 * n_types;
+  if (per_type < 0) return -1;
+  int32_t exp_off[nqa::kMaxNodeInstr + 1];
+  const int64_t nexp = node_f16() ? node_exp_layout(static_cast<const nqa::NodeInstr*>(instr_table), n_instr, exp_off) : 0;
+  return per_type * 16 * n_types + ((nexp * n_types * 4 + 255) & ~(int64_t)255);
 }
 
 int nqa_node_weights_pack(const void* weights, const void* chunk_table, int32_t n_chunks, const void* instr_table,
@@ -1204,9 +1373,20 @@ int nqa_node_weights_pack(const void* weights, const void* chunk_table, int32_t 
   a.frag_stride = per_type;
   a.n_instr = n_instr;
   a.n_types = n_types;
-  const int64_t threads = per_type / 3 * n_types;
-  hipLaunchKernelGGL(node_weights_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (node_f16()) {
+    a.exp_stride = node_exp_layout(instr, n_instr, a.exp_off);
+    a.wexp = reinterpret_cast<int32_t*>(static_cast<char*>(packed) + per_type * 16 * n_types);
+    const int64_t nexp = (int64_t)a.exp_stride * n_types;
+    hipLaunchKernelGGL(node_weights_exp_kernel, dim3((unsigned)((nexp + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    const int64_t threads = per_type / 2 * n_types;
+    hipLaunchKernelGGL(node_weights_pack_f16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+  } else {
+    const int64_t threads = per_type / 3 * n_types;
+    hipLaunchKernelGGL(node_weights_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+  }
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_node_weights_pack: ") + hipGetErrorString(err));
@@ -1239,12 +1419,16 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
   for (int q = 0; q < n_instr; ++q) pa.frag_off[q] = frag_off[q];
   pa.frag_stride = per_type;
   pa.wf = static_cast<const nl_u32x4*>(packed);
+  int32_t exp_off[kMaxNodeInstr + 1];
+  pa.exp_stride = node_exp_layout(instr, n_instr, exp_off);
+  pa.wexp = reinterpret_cast<const int32_t*>(static_cast<const char*>(packed) + per_type * 16 * n_types);
   NodeLinearArgs<float>& a = pa.base;
   a.x = static_cast<const float*>(x);
   a.addend = static_cast<const float*>(addend);
   a.out = static_cast<float*>(out);
   a.types = n_types > 1 ? atom_types : nullptr;
   if (n_instr > 0) std::memcpy(a.instr, instr, sizeof(NodeInstr) * (size_t)n_instr);
+  for (int q = 0; q < n_instr; ++q) a.instr[q].pad = exp_off[q];  // (F16: first exponent of the instruction)
   a.n_types = n_types;
   a.din = dim_in;
   a.dout = dim_out;
@@ -1303,8 +1487,12 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
       set_error("nqa_node_linear_packed: too many work units for one launch");
       return NQA_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(node_linear_wave_bf16_kernel, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
-                       dim3(64 * kNLWavesPerWG), 0, s, pa);
+    if (node_f16())
+      hipLaunchKernelGGL(node_linear_wave_bf16_kernel<true>, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
+                         dim3(64 * kNLWavesPerWG), 0, s, pa);
+    else
+      hipLaunchKernelGGL(node_linear_wave_bf16_kernel<false>, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
+                         dim3(64 * kNLWavesPerWG), 0, s, pa);
   }
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {

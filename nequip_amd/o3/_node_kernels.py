@@ -119,12 +119,13 @@ def exact_fp32() -> bool:
 
 
 def packed_weights(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.Tensor:
-    """``wp [T, wstride]`` split into three bf16 planes in MFMA-fragment order (``nqa_node_weights_pack``).  Constant
+    """``wp [T, wstride]`` split into 16-bit planes in MFMA-fragment order (``nqa_node_weights_pack``: two fp16 planes of
+    power-of-two scaled K blocks by default, three bf16 planes with ``NQA_NODE_F16=0``).  Constant
     weights (eval mode: the modules keep ``wp`` alive across steps) are packed once per version of the tensor; a ``wp``
     that is part of an autograd graph (training: rebuilt from the parameter every step) is packed per call."""
     lib = _lib.load()
     ct, nchunks, it, ninstr = meta.host_tables(which)
-    key = (id(meta), which)
+    key = (id(meta), which, os.environ.get("NQA_NODE_F16", ""))  # (the layout depends on the split the library uses)
     cache = None
     if not wp.requires_grad:
         cache = wp.__dict__.setdefault("_nqa_packed", {}) if hasattr(wp, "__dict__") else None

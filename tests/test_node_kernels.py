@@ -145,3 +145,78 @@ def test_gate_kernel_double_backward(device, dtype):
         out = second_order(gate_d, x.to(device), go.to(device), cot.to(device))
         for r, o in zip(ref, out):
             torch.testing.assert_close(r, o.cpu(), atol=tol * max(1.0, float(r.abs().max())), rtol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typed", [False, True])
+def test_node_linear_constant_weight_modes_over_a_wide_dynamic_range(device, monkeypatch, typed):
+    """Constant weights (eval mode) run on 16-bit MFMA operands: two fp16 planes with exact power-of-two scales -- per K
+    block of the weights, and a RUNNING one per output column that is lowered, with the column's accumulators, when a
+    later block outgrows it -- (default), three bf16 planes (NQA_NODE_F16=0), or exact fp32 (NQA_NODE_EXACT_FP32=1).
+    Atoms from 1e-12 to 1e+8, irrep blocks six orders apart, channel groups inside a block twenty orders apart in
+    either order, weight matrices of 1e-5 and 1e+4, non-multiple-of-16 multiplicities: every output element within the
+    fp32 level of its magnitude sum  sum |x| |W|, forward and transposed."""
+    from nequip_amd.o3._node_kernels import NodeLinearMeta, _launch_linear, _transposed, meta_transposed_weights
+    from nequip_amd.o3.irreps import Irreps
+
+    torch.manual_seed(2)
+    s_in = "64x0e+64x0e+40x1o+64x1o+70x2e+64x3o"
+    s_out = "128x0e+96x1o+64x2e+16x3o"
+    ins = [(0, 0), (1, 0), (2, 1), (3, 1), (4, 2), (5, 3)]
+    i_in, i_out = Irreps(s_in), Irreps(s_out)
+    meta = NodeLinearMeta(i_in, i_out, ins)
+    N, T = 203, (3 if typed else 1)
+    x = torch.randn(N, i_in.dim)
+    atom = torch.ones(N)
+    atom[20:60] = 1e-12
+    atom[60:90] = 1e8
+    x *= atom[:, None]
+    off = i_in.offsets()
+    x[:, off[1]:off[2]] *= 1e6                      # a whole block far above its neighbour feeding the same output
+    x[100:140, off[3]:off[3] + 16 * 3] *= 1e-20     # small channels first, then O(1): rescale inside the block
+    x[140:180, off[3] + 16 * 3:off[4]] *= 1e-20     # large channels first
+    x[7] = 0.0
+    wp = torch.randn(T, meta.wstride)
+    for k, (i, o) in enumerate(ins):
+        n = i_in[i].mul * i_out[o].mul
+        if k == 2:
+            wp[:, meta.w_off[k]:meta.w_off[k] + n] *= 1e-5
+        if k == 4:
+            wp[:, meta.w_off[k]:meta.w_off[k] + n] *= 1e4
+    types = torch.randint(0, T, (N,)) if typed else None
+
+    def reference(xx, w, m):
+        out = torch.zeros(xx.shape[0], m.dout, dtype=torch.float64)
+        mag = torch.zeros_like(out)
+        io, oo = m.irreps_in.offsets(), m.irreps_out.offsets()
+        for k, (i, o) in enumerate(m.instructions):
+            mi, ir = m.irreps_in[i]
+            mo = m.irreps_out[o].mul
+            d = ir.dim
+            W = w[:, m.w_off[k]:m.w_off[k] + mi * mo].view(-1, mi, mo).double()
+            Wz = W[types] if typed else W[0].expand(xx.shape[0], mi, mo)
+            xb = xx[:, io[i]:io[i] + mi * d].view(-1, mi, d).double()
+            out[:, oo[o]:oo[o] + mo * d] += torch.einsum("zum,zuw->zwm", xb, Wz).reshape(-1, mo * d)
+            mag[:, oo[o]:oo[o] + mo * d] += torch.einsum("zum,zuw->zwm", xb.abs(), Wz.abs()).reshape(-1, mo * d)
+        return out, mag.clamp_min(1e-300)
+
+    cases = [("fwd", x, wp, meta)]
+    xt = torch.randn(N, i_out.dim) * atom[:, None]
+    xt[7] = 0.0
+    cases.append(("transposed", xt, meta_transposed_weights(meta, wp), _transposed(meta)))
+    for label, xx, w, m in cases:
+        ref, mag = reference(xx, w, m)
+        errs = {}
+        for mode, env in (("f16", {"NQA_NODE_F16": "1", "NQA_NODE_EXACT_FP32": "0"}),
+                          ("bf16", {"NQA_NODE_F16": "0", "NQA_NODE_EXACT_FP32": "0"}),
+                          ("fp32", {"NQA_NODE_F16": "1", "NQA_NODE_EXACT_FP32": "1"})):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            out = _launch_linear(xx.to(device), w.to(device).contiguous(), None, None if types is None else types.to(device),
+                                 m, "fwd", 1.0).cpu().double()
+            assert torch.isfinite(out).all(), (label, mode)
+            assert torch.equal(out[7], torch.zeros(m.dout, dtype=torch.float64)), (label, mode)
+            errs[mode] = float(((out - ref).abs() / mag).max())
+        print(label, "max error / magnitude sum:", errs)
+        assert all(e < 1e-6 for e in errs.values()), (label, errs)
+        assert errs["f16"] < 3 * max(errs["bf16"], errs["fp32"]) + 2e-7, (label, errs)
