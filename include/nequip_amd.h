@@ -250,9 +250,12 @@ int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, 
  * ------------------------------------------------------------------------------------------- */
 #define NQA_MLP_FP32 0
 #define NQA_MLP_BF16X6 1
-/* forward only (nqa_radial_mlp_fwd; the backward entry points treat it as NQA_MLP_BF16X6): operands scaled by powers of
- * two (weights per 32-column tile, hidden activations per row) and split into two fp16 terms, three partial products on
- * v_mfma_f32_32x32x16_f16 -- fp32-level accuracy (2^-22 per operand) at half the matrix instructions of BF16X6 */
+/* inference entry points (nqa_radial_mlp_fwd, nqa_radial_mlp_bwd, nqa_radial_mlp_bwd_paired; the training entry points
+ * reject it): operands multiplied by exact powers of two and split into two fp16 terms, three partial products on
+ * v_mfma_f32_32x32x16_f16 -- fp32-level accuracy (2^-22 per operand) at half the matrix instructions of BF16X6.  Forward:
+ * weights scaled per 32-column tile, hidden activations per row.  Backward: weights per 32-row K chunk, the streamed
+ * gradient rows by a running per-row exponent that is lowered, together with the row's accumulators, when a chunk
+ * outgrows it.  The workspace of this mode differs from BF16X6's (nqa_radial_mlp_workspace_bytes). */
 #define NQA_MLP_F16X3 2
 int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, int32_t out_features);
 int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features);
@@ -282,7 +285,7 @@ int nqa_radial_mlp_bwd(int32_t dtype, int32_t mode, const void* edge_embedding, 
  *   the MLP along `cotangent`; same workspace as nqa_radial_mlp_fwd. */
 /* nqa_radial_mlp_bwd_paired: nqa_radial_mlp_bwd for an incoming gradient given as two row streams that are added on
  *   the fly (grad_edge_weight[row] + grad_edge_weight2[row]): the halves written by the two directed edges of a pair in
- *   nqa_tp_scatter_bwd_*_paired.  num_edges counts rows (pairs).  NQA_MLP_BF16X6 only. */
+ *   nqa_tp_scatter_bwd_*_paired.  num_edges counts rows (pairs).  NQA_MLP_BF16X6 or NQA_MLP_F16X3. */
 int nqa_radial_mlp_bwd_paired(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,
                               const void* w1, double alpha1, const void* grad_edge_weight,
                               const void* grad_edge_weight2, int32_t num_basis, int32_t hidden, int32_t out_features,
@@ -332,13 +335,17 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
              void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Split-bf16 form of nqa_node_linear (float32 tensors, default): the same maps -- e3nn `o3.Linear` / the type-contracted
- *   `FullyConnectedTensorProduct` of nequip/nn/interaction_block.py:82-87,129-146,175-177,201 -- with every fp32 operand
- *   written as the sum of three bf16 numbers and each product accumulated in fp32 from its six leading partial products on
- *   v_mfma_f32_32x32x16_bf16 (fp32 accuracy at 2.7x the fp32-MFMA rate).
+ * Split 16-bit form of nqa_node_linear (float32 tensors, default for constant weights): the same maps -- e3nn `o3.Linear`
+ *   / the type-contracted `FullyConnectedTensorProduct` of nequip/nn/interaction_block.py:82-87,129-146,175-177,201 --
+ *   with fp32-level accuracy on the 16-bit matrix pipe.  Default: every operand multiplied by an exact power of two and
+ *   written as the sum of two fp16 numbers, three partial products on v_mfma_f32_32x32x16_f16 (weights scaled per atom
+ *   type, instruction and 16-row K block; every output column carries a running exponent).  NQA_NODE_F16=0 (environment,
+ *   read at every call): three bf16 numbers per operand, six partial products on v_mfma_f32_32x32x16_bf16.
  * nqa_node_weights_pack: weights [n_types][weight_stride] (the layout nqa_node_linear reads) -> `packed`
- *   (nqa_node_weights_pack_bytes bytes): [type][instruction][16-row K block][32-column tile][plane hi/mid/lo][lane] of
- *   16 bytes = 8 bf16 W[16 kb + 8 (lane >> 5) + e][32 tile + (lane & 31)], zero beyond the matrix.  Once per weight version.
+ *   (nqa_node_weights_pack_bytes bytes): [type][instruction][16-row K block][32-column tile][plane][lane] of 16 bytes = 8
+ *   16-bit values W[16 kb + 8 (lane >> 5) + e][32 tile + (lane & 31)], zero beyond the matrix; fp16 mode: 2 planes, then
+ *   int32 exponents [type][instruction][K block]; bf16 mode: 3 planes.  Once per weight version, and the buffer must be
+ *   consumed in the mode it was packed in.
  * nqa_node_linear_packed: out = scale * sum_instr x_block @ W (+ addend), tables as for nqa_node_linear (chunks must
  *   start at multiples of 64 channels); one 64-lane workgroup per (64-channel chunk, floor(32 / d) atoms) unit.
  * ------------------------------------------------------------------------------------------- */

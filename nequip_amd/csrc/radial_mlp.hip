@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
 // later chunks up to 8x larger pass without a rescale.  Both factors are powers of two: exact.  The error of a product
 // is 2^-22 of the row's (running) maximum x the chunk's weight maximum, the rounding level of the fp32 sum itself.
 template <int H, int TM, bool PAIR = false, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void radial_mlp_bwd_bf16x6_kernel(const float* __restrict__ emb,
+__global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wb,
                                                                     const float* __restrict__ gw, float a0, int nb,
@@ -1671,7 +1671,7 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
                          hidden, out_features, wb, ce);
     const float* g2 = static_cast<const float*>(grad_edge_weight2);
 #define NQA_MLP_BWD_F16_LAUNCH(HH, PP)                                                                               \
-  hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<HH, 0, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,       \
+  hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, 0, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,       \
                      (float)alpha0, num_basis, out_features, num_edges, o, 0, nullptr, nullptr, nullptr, g2, ce)
     if (hidden == 128) {
       if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(128, true);
@@ -1693,7 +1693,7 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
     float* ho = static_cast<float*>(hidden_out);
     float* wp = static_cast<float*>(w0_partials);
 #define NQA_MLP_BWD_LAUNCH(HH, TT)                                                                              \
-  hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<HH, TT>), dim3(grid), dim3(256), 0, s, e, a, wb, g,          \
+  hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, TT>), dim3(grid), dim3(256), 0, s, e, a, wb, g,          \
                      (float)alpha0, num_basis, out_features, num_edges, o, (TT) == 0 ? dbg : 0, c, ho, wp)
     if (grad_edge_weight2 != nullptr) {
       const float* g2 = static_cast<const float*>(grad_edge_weight2);
@@ -1702,10 +1702,10 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
         return NQA_ERR_UNSUPPORTED;
       }
       if (hidden == 128)
-        hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<128, 0, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,
+        hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<128, 0, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,
                            (float)alpha0, num_basis, out_features, num_edges, o, 0, c, ho, wp, g2);
       else
-        hipLaunchKernelGGL((radial_mlp_bwd_bf16x6_kernel<64, 0, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,
+        hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<64, 0, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,
                            (float)alpha0, num_basis, out_features, num_edges, o, 0, c, ho, wp, g2);
       return launch_status("nqa_radial_mlp_bwd_paired");
     }

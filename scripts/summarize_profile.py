@@ -52,7 +52,7 @@ REGIONS = {
                      [plain("gx_rows_sum_kernel")]),
     "radial_mlp_fwd": ([lambda k: re.search(r"radial_mlp_fwd\w*_kernel", k) is not None],
                        [plain("radial_mlp_split_w1_fwd_kernel", "radial_mlp_split_w1_fwd_f16_kernel")]),
-    "radial_mlp_bwd": ([lambda k: re.search(r"radial_mlp_bwd(_bf16x6)?_kernel", k) is not None],
+    "radial_mlp_bwd": ([lambda k: re.search(r"radial_mlp_bwd\w*_kernel", k) is not None],
                        [plain("radial_mlp_transpose_w1_kernel", "radial_mlp_split_w1_bwd_kernel")]),
     "node_linear": ([plain("node_linear_kernel", "node_linear_mfma_kernel", "node_linear_")], []),
     "gate": ([plain("gate_fwd_kernel", "gate_bwd_kernel")], []),

@@ -81,7 +81,7 @@ def test_profile_summariser_classifies_every_generated_kernel():
     import summarize_profile as sp
 
     assert sp.region_of("void nqa::radial_mlp_fwd_split_bal_kernel<128, true>(float const*, float const*)") == ("radial_mlp_fwd", "main")
-    assert sp.region_of("void nqa::radial_mlp_bwd_bf16x6_kernel<128, 0, false>(float const*)") == ("radial_mlp_bwd", "main")
+    assert sp.region_of("void nqa::radial_mlp_bwd_split_kernel<128, 0, false>(float const*)") == ("radial_mlp_bwd", "main")
     assert sp.region_of("nqa::radial_mlp_split_w1_fwd_f16_kernel(float const*)") == ("radial_mlp_fwd", "helper")
     spec_dir = os.path.join(ROOT, "nequip_amd", "csrc", "generated_spec")
     files = glob.glob(os.path.join(spec_dir, "*.hip"))
