@@ -250,8 +250,7 @@ int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, 
  * ------------------------------------------------------------------------------------------- */
 #define NQA_MLP_FP32 0
 #define NQA_MLP_BF16X6 1
-/* inference entry points (nqa_radial_mlp_fwd, nqa_radial_mlp_bwd, nqa_radial_mlp_bwd_paired; the training entry points
- * reject it): operands multiplied by exact powers of two and split into two fp16 terms, three partial products on
+/* every entry point except nqa_radial_mlp_fwd_tangent (which rejects it): operands multiplied by exact powers of two and split into two fp16 terms, three partial products on
  * v_mfma_f32_32x32x16_f16 -- fp32-level accuracy (2^-22 per operand) at half the matrix instructions of BF16X6.  Forward:
  * weights scaled per 32-column tile, hidden activations per row.  Backward: weights per 32-row K chunk, the streamed
  * gradient rows by a running per-row exponent that is lowered, together with the row's accumulators, when a chunk

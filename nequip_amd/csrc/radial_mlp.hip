@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
 // Everything happens in the epilogue on the tile that is already on chip; the main loop is the same code.
 // PAIR (nqa_radial_mlp_bwd_paired): the incoming gradient is the sum of two row streams gw[row] + gw2[row] (the two
 // directed edges of a pair wrote their halves separately), added in registers when a chunk is consumed.
-// F16 (inference backward, TM = 0): the two-plane fp16 split with a RUNNING per-row scale.  The gradient rows stream in
+// F16: the two-plane fp16 split with a RUNNING per-row scale (main loop only: the training epilogues work on the
+// accumulators after they have been brought back to the true scale).  The gradient rows stream in
 // with no scale known in advance, so every row carries an exponent S: its accumulators hold 2^S x the true sums, a chunk
 // is multiplied by 2^(S - chunk_exp[chunk]) (the weights of the chunk were multiplied by 2^chunk_exp[chunk]) before it
 // is split, and S is lowered -- the row's accumulators are multiplied by the power of two that bridges the old and the
@@ -1061,7 +1062,6 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(const floa
                                                                     float* __restrict__ w0_part,
                                                                     const float* __restrict__ gw2 = nullptr,
                                                                     const int* __restrict__ chunk_exp = nullptr) {
-  static_assert(!F16 || TM == 0, "the fp16 split is an inference-backward mode");
   // K (= W) is consumed in chunks of 32 columns = two bf16 k-steps; lane (row, half) owns the 16 contiguous floats
   // 32*chunk + 16*half + [0, 16) of its g_w row per chunk: HBM -> registers directly, split in registers.
   constexpr int NT = H / 32;
@@ -1636,10 +1636,6 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
                         int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
-  if (mode == NQA_MLP_F16X3 && tm != 0) {
-    set_error("nqa_radial_mlp_bwd_train: NQA_MLP_F16X3 is an inference mode (use NQA_MLP_BF16X6)");
-    return NQA_ERR_UNSUPPORTED;
-  }
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   if (num_edges == 0) return NQA_OK;
@@ -1670,15 +1666,24 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
       hipLaunchKernelGGL(radial_mlp_split_w1_bwd_f16_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, b, (float)alpha1,
                          hidden, out_features, wb, ce);
     const float* g2 = static_cast<const float*>(grad_edge_weight2);
-#define NQA_MLP_BWD_F16_LAUNCH(HH, PP)                                                                               \
-  hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, 0, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,       \
-                     (float)alpha0, num_basis, out_features, num_edges, o, 0, nullptr, nullptr, nullptr, g2, ce)
+    if (g2 != nullptr && tm != 0) {
+      set_error("nqa_radial_mlp_bwd_paired: inference backward only");
+      return NQA_ERR_UNSUPPORTED;
+    }
+#define NQA_MLP_BWD_F16_LAUNCH(HH, TT, PP)                                                                           \
+  hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, TT, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,      \
+                     (float)alpha0, num_basis, out_features, num_edges, o, 0, static_cast<const float*>(cotangent),  \
+                     static_cast<float*>(hidden_out), static_cast<float*>(w0_partials), g2, ce)
     if (hidden == 128) {
-      if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(128, true);
-      else NQA_MLP_BWD_F16_LAUNCH(128, false);
+      if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(128, 0, true);
+      else if (tm == 0) NQA_MLP_BWD_F16_LAUNCH(128, 0, false);
+      else if (tm == 1) NQA_MLP_BWD_F16_LAUNCH(128, 1, false);
+      else NQA_MLP_BWD_F16_LAUNCH(128, 2, false);
     } else {
-      if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(64, true);
-      else NQA_MLP_BWD_F16_LAUNCH(64, false);
+      if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(64, 0, true);
+      else if (tm == 0) NQA_MLP_BWD_F16_LAUNCH(64, 0, false);
+      else if (tm == 1) NQA_MLP_BWD_F16_LAUNCH(64, 1, false);
+      else NQA_MLP_BWD_F16_LAUNCH(64, 2, false);
     }
 #undef NQA_MLP_BWD_F16_LAUNCH
     return launch_status(g2 != nullptr ? "nqa_radial_mlp_bwd_paired" : "nqa_radial_mlp_bwd");

@@ -34,9 +34,9 @@ def forward_mode(mode: int) -> int:
 
 
 def backward_mode(mode: int) -> int:
-    """Mode of the inference backward launches (``nqa_radial_mlp_bwd`` / ``_bwd_paired``): the split-bf16 default runs
-    them on the two-plane fp16 split with a running per-row scale (``NQA_MLP_BWD_F16=0`` keeps the bf16 split).  The
-    training entry points (``_bwd_train``, ``_fwd_tangent``) stay on the bf16 split."""
+    """Mode of the backward launches (``nqa_radial_mlp_bwd`` / ``_bwd_paired`` / ``_bwd_train``): the split-bf16 default
+    runs them on the two-plane fp16 split with a running per-row scale (``NQA_MLP_BWD_F16=0`` keeps the bf16 split).
+    ``_fwd_tangent`` stays on the bf16 split (its kernel keeps the three-plane weight image)."""
     if mode == _lib.NQA_MLP_BF16X6 and os.environ.get("NQA_MLP_BWD_F16", "") not in ("0",):
         return _lib.NQA_MLP_F16X3
     return mode
@@ -117,6 +117,7 @@ def _launch_bwd_train(emb, w0, w1, alpha0: float, alpha1: float, g_w, cot, mode:
     tiles = lib.nqa_radial_mlp_train_tiles(E)
     parts = torch.empty((tiles, nb, H), dtype=emb.dtype, device=emb.device)
     flops = 2.0 * E * (nb * H * (3 if cot is None else 5) + H * W)
+    mode = backward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
     ws, ready = cache.get(w1, mode, 1, ws_bytes)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd_train", 4.0 * E * (3 * nb + W + H), flops):
