@@ -502,18 +502,23 @@ struct NodePackArgs {
   int32_t frag_off[kMaxNodeInstr + 1];  // first fragment-lane (uint4 index) of every instruction, within one type
 };
 
-// F16: exponent of every (type, instruction, K block): one thread each, over the block's 16 x mul_out values
-__global__ __launch_bounds__(256) void node_weights_exp_kernel(const NodePackArgs a) {
-  const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (idx >= a.exp_stride * a.n_types) return;
+// F16: exponent of every (type, instruction, K block): one wavefront each, over the block's 16 x mul_out values (rows of
+// mul_out contiguous floats: coalesced)
+__global__ __launch_bounds__(64) void node_weights_exp_kernel(const NodePackArgs a) {
+  const int idx = (int)blockIdx.x;  // (type, exponent slot)
+  const int lane = (int)threadIdx.x;
   const int t = idx / a.exp_stride, r = idx - t * a.exp_stride;
   int q = 0;
   while (q + 1 < a.n_instr && r >= a.exp_off[q + 1]) ++q;
   const int k16 = r - a.exp_off[q];
   const float* __restrict__ wq = a.w + (int64_t)t * a.wstride + a.w_off[q];
+  const int u1 = min(16 * k16 + 16, a.mul_in[q]);
   float m = 0.f;
-  for (int u = 16 * k16; u < min(16 * k16 + 16, a.mul_in[q]); ++u)
-    for (int c = 0; c < a.mul_out[q]; ++c) m = fmaxf(m, fabsf(wq[(int64_t)u * a.mul_out[q] + c]));
+  for (int u = 16 * k16; u < u1; ++u)
+    for (int c = lane; c < a.mul_out[q]; c += 64) m = fmaxf(m, fabsf(wq[(int64_t)u * a.mul_out[q] + c]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane != 0) return;
   int ex = 0;
   if (m > 0.f && m < 3.0e38f) {
     int e;
@@ -1377,8 +1382,7 @@ int nqa_node_weights_pack(const void* weights, const void* chunk_table, int32_t 
     a.exp_stride = node_exp_layout(instr, n_instr, a.exp_off);
     a.wexp = reinterpret_cast<int32_t*>(static_cast<char*>(packed) + per_type * 16 * n_types);
     const int64_t nexp = (int64_t)a.exp_stride * n_types;
-    hipLaunchKernelGGL(node_weights_exp_kernel, dim3((unsigned)((nexp + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(node_weights_exp_kernel, dim3((unsigned)nexp), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     const int64_t threads = per_type / 2 * n_types;
     hipLaunchKernelGGL(node_weights_pack_f16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a);

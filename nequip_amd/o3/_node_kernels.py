@@ -160,7 +160,8 @@ def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale
     flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
     # (weights that are part of an autograd graph -- training -- change every step: the exact-fp32 kernel reads them as
     # they are, packing them per call would cost a launch per module and direction)
-    if x.dtype == torch.float32 and not exact_fp32() and ninstr > 0 and not wp.requires_grad:
+    if (x.dtype == torch.float32 and not exact_fp32() and ninstr > 0 and not wp.requires_grad
+            and not getattr(wp, "_nqa_volatile", False)):
         wf = packed_weights(wp, meta, which)
         with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
             rc = lib.nqa_node_linear_packed(
@@ -222,7 +223,11 @@ def _transposed(meta: NodeLinearMeta) -> NodeLinearMeta:
 
 def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Tensor:
     if wp.requires_grad:
-        return meta.transpose_weights(wp)
+        wt = meta.transpose_weights(wp)
+        # inside a backward pass that builds no graph this copy does not require grad although it changes every step:
+        # tell _launch_linear not to pack it (one prepass launch per module and step otherwise)
+        wt._nqa_volatile = True
+        return wt
     # constant weights (eval mode): the modules keep `wp` alive across steps, so the transposed copy rides on it
     cached = getattr(wp, "_nqa_transposed", None)
     if cached is None or cached[0] != wp._version:
