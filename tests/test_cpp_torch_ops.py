@@ -27,8 +27,11 @@ OPS = ["tp_scatter_fwd", "tp_scatter_bwd", "edge_vectors", "edge_vectors_adj", "
 
 @pytest.fixture(scope="module")
 def cpp():
-    if not os.path.exists(LIB):
-        pytest.fail(f"{LIB} is missing: run python -m nequip_amd.csrc.build")
+    if not os.path.exists(LIB) or not os.path.exists(RUNNER):
+        from nequip_amd.csrc import build as _build  # host C++ only (g++ against this interpreter's libtorch)
+
+        _build.build(force=False, verbose=False)
+        _build.build_torch_ops(force=False, verbose=False)
     import nequip_amd  # noqa: F401  (the Python registrations come first in this process: the C++ library must yield)
 
     lib = ctypes.CDLL(LIB)
@@ -178,7 +181,7 @@ sys.exit(1 if bad else 0)
 
 
 @pytest.mark.gpu
-def test_cpp_ops_reproduce_the_python_ops_bitwise(device, tmp_path):
+def test_cpp_ops_reproduce_the_python_ops_bitwise(device, tmp_path, cpp):
     import nequip_amd  # noqa: F401
     from nequip_amd.nn._tp_scatter_ops import plan_key
     from nequip_amd.o3._node_ops import gate_key, linear_key
@@ -301,7 +304,7 @@ def _export(device, tmp_path):
 
 
 @pytest.mark.gpu
-def test_aoti_package_runs_on_the_cpp_ops_alone(device, tmp_path, exported):
+def test_aoti_package_runs_on_the_cpp_ops_alone(device, tmp_path, exported, cpp):
     path, io, out_keys = exported
     assert {"total_energy", "forces", "virial"} <= set(out_keys), out_keys
     torch.save(io, tmp_path / "io.pt")
@@ -311,13 +314,12 @@ def test_aoti_package_runs_on_the_cpp_ops_alone(device, tmp_path, exported):
 
 
 @pytest.mark.gpu
-def test_standalone_cpp_runner(device, tmp_path, exported):
+def test_standalone_cpp_runner(device, tmp_path, exported, cpp):
     """No interpreter: nequip_amd_aoti_run loads the package with AOTIModelPackageLoader, the ops come from the C++ library
     it links, tensors travel as raw files (manifest: `name dtype ndim dims...`)."""
     import numpy as np
 
-    if not os.path.exists(RUNNER):
-        pytest.fail(f"{RUNNER} is missing: run python -m nequip_amd.csrc.build")
+    assert os.path.exists(RUNNER), f"{RUNNER} is missing: run python -m nequip_amd.csrc.build"
     path, io, out_keys = exported
     names = {torch.float32: "f32", torch.float64: "f64", torch.int64: "i64"}
     for case, (inputs, ref) in enumerate(io):

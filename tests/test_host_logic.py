@@ -298,3 +298,39 @@ def test_owner_lists_of_the_pair_centric_backward():
     owned = (orow[1:] - orow[:-1]).float()
     assert float((owned - degree / 2).abs().max()) <= 0.3 * float(degree.max()) + 2
     assert abs(float(owned.sum()) - P) < 1e-6
+
+
+def test_split_mode_workspace_sizes():
+    """Workspace sizes of the radial MLP's GEMM modes and of the packed node weights (host arithmetic of the C ABI, no
+    GPU): the fp16 images hold two planes plus their power-of-two exponents, the bf16 images three planes."""
+    import ctypes
+    import struct
+
+    from nequip_amd import _lib
+    from nequip_amd.o3._node_kernels import NodeLinearMeta
+
+    lib = _lib.load()
+    H, W = 128, 704
+    ntiles = (W + 31) // 32
+    assert lib.nqa_radial_mlp_workspace_bytes(_lib.NQA_MLP_BF16X6, 0, H, W) == ntiles * (H // 16) * 3 * 1024
+    assert lib.nqa_radial_mlp_workspace_bytes(_lib.NQA_MLP_BF16X6, 1, H, W) == ntiles * (H // 16) * 3 * 1024
+    assert lib.nqa_radial_mlp_workspace_bytes(_lib.NQA_MLP_F16X3, 0, H, W) == ntiles * (H // 16) * 2 * 1024 + 256
+    assert lib.nqa_radial_mlp_workspace_bytes(_lib.NQA_MLP_F16X3, 1, H, W) == ntiles * 2 * 2 * (H // 32) * 1024 + 256
+    assert lib.nqa_radial_mlp_workspace_bytes(_lib.NQA_MLP_FP32, 0, H, W) == 0
+    assert lib.nqa_radial_mlp_workspace_bytes(7, 0, H, W) == -1
+    meta = NodeLinearMeta(Irreps("64x0e+40x1o"), Irreps("128x0e+96x1o"), [(0, 0), (1, 1)])
+    chunks, instr = meta.fwd
+    cb = ctypes.create_string_buffer(b"".join(struct.pack("<8i", *c) for c in chunks))
+    ib = ctypes.create_string_buffer(b"".join(struct.pack("<4i", *i) for i in instr))
+    frags = (64 // 16) * (128 // 32) + ((40 + 15) // 16) * (96 // 32)  # (K blocks) x (column tiles) per instruction
+    nexp = 64 // 16 + (40 + 15) // 16
+    sizes = {}
+    for mode in ("1", "0"):
+        os.environ["NQA_NODE_F16"] = mode
+        try:
+            sizes[mode] = lib.nqa_node_weights_pack_bytes(ctypes.cast(cb, ctypes.c_void_p), len(chunks),
+                                                          ctypes.cast(ib, ctypes.c_void_p), len(instr), 2)
+        finally:
+            os.environ.pop("NQA_NODE_F16", None)
+    assert sizes["0"] == frags * 3 * 1024 * 2
+    assert sizes["1"] == frags * 2 * 1024 * 2 + ((nexp * 2 * 4 + 255) // 256) * 256
