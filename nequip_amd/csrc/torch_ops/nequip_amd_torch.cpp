@@ -207,24 +207,28 @@ Tensor plan_image(Plan& P, const at::Device& device) {
 }
 
 // ---- edge topology: CSR by destination and by source, shared by the ops of one evaluation ------------------------------
-// An entry is keyed on the identity of the two index tensors (TensorImpl, kept alive through weak references so that an
-// address cannot be recycled under an entry), their version counters, data pointers and sizes -- the rule of
-// nequip_amd/nn/_topology.py.  A compiled graph hands the same two views to every op of one evaluation and fresh ones on
-// the next, so in practice the CSRs are built once per evaluation.  NQA_TOPOLOGY_CACHE=0: never reuse.
+// An entry is keyed on the identity of the STORAGE behind the two index tensors (held through weak references, so an
+// address cannot be recycled under an entry), the version counter that views share with their base, data pointers,
+// strides and sizes -- the rule of nequip_amd/nn/_topology.py.  Every `edge_index[0]` / `edge_index[1]` view of one input
+// tensor maps to the same entry, whether the graph or one of these ops made the view; a caller that hands in the same
+// (unmodified) edge_index again reuses the CSRs across evaluations, a new tensor builds them once.
+// NQA_TOPOLOGY_CACHE=0: never reuse.
 struct Csr {
   Tensor rowptr, edge_id, other;
 };
 
 struct Topology {
-  c10::weak_intrusive_ptr<c10::TensorImpl> dst_ref, src_ref;
+  c10::weak_intrusive_ptr<c10::StorageImpl> dst_ref, src_ref;
   const void *dst_ptr, *src_ptr;
   uint32_t dst_version, src_version;
-  int64_t num_nodes, num_edges;
+  int64_t num_nodes, num_edges, dst_stride, src_stride;
   Tensor dst, src;  // contiguous int64
   Csr by_dst, by_src;
   bool has_dst = false, has_src = false;
+  std::mutex build;  // the CSRs are built on first use, outside the registry lock
   Topology(const Tensor& d, const Tensor& s)
-      : dst_ref(d.getIntrusivePtr()), src_ref(s.getIntrusivePtr()) {}
+      : dst_ref(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(d.storage().unsafeGetStorageImpl())),
+        src_ref(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(s.storage().unsafeGetStorageImpl())) {}
 };
 
 Csr build_csr(const Tensor& key, const Tensor& other, int64_t N, int64_t E) {
@@ -257,10 +261,11 @@ std::shared_ptr<Topology> topology_of(const Tensor& edge_dst, const Tensor& edge
       Topology& t = *cache[i];
       auto d = t.dst_ref.lock();
       auto s = t.src_ref.lock();
-      if (d && s && d.get() == edge_dst.unsafeGetTensorImpl() && s.get() == edge_src.unsafeGetTensorImpl() &&
-          t.dst_version == edge_dst._version() && t.src_version == edge_src._version() &&
-          t.dst_ptr == edge_dst.data_ptr() && t.src_ptr == edge_src.data_ptr() && t.num_edges == edge_dst.numel() &&
-          t.num_nodes == num_nodes) {
+      if (d && s && d.get() == edge_dst.storage().unsafeGetStorageImpl() &&
+          s.get() == edge_src.storage().unsafeGetStorageImpl() && t.dst_version == edge_dst._version() &&
+          t.src_version == edge_src._version() && t.dst_ptr == edge_dst.data_ptr() && t.src_ptr == edge_src.data_ptr() &&
+          t.num_edges == edge_dst.numel() && t.num_nodes == num_nodes &&
+          (t.num_edges == 0 || (t.dst_stride == edge_dst.stride(0) && t.src_stride == edge_src.stride(0)))) {
         auto hit = cache[i];
         cache.erase(cache.begin() + (long)i);
         cache.push_back(hit);
@@ -275,6 +280,8 @@ std::shared_ptr<Topology> topology_of(const Tensor& edge_dst, const Tensor& edge
   t->src_version = edge_src._version();
   t->num_nodes = num_nodes;
   t->num_edges = edge_dst.numel();
+  t->dst_stride = edge_dst.stride(0);
+  t->src_stride = edge_src.stride(0);
   t->dst = edge_dst.contiguous();
   t->src = edge_src.contiguous();
   if (reuse) {
@@ -290,6 +297,7 @@ std::shared_ptr<Topology> topology_of(const Tensor& edge_dst, const Tensor& edge
 }
 
 const Csr& by_dst(Topology& t) {
+  std::lock_guard<std::mutex> lock(t.build);
   if (!t.has_dst) {
     t.by_dst = build_csr(t.dst, t.src, t.num_nodes, t.num_edges);
     t.has_dst = true;
@@ -298,6 +306,7 @@ const Csr& by_dst(Topology& t) {
 }
 
 const Csr& by_src(Topology& t) {
+  std::lock_guard<std::mutex> lock(t.build);
   if (!t.has_src) {
     t.by_src = build_csr(t.src, t.dst, t.num_nodes, t.num_edges);
     t.has_src = true;
