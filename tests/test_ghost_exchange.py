@@ -95,6 +95,84 @@ def test_lammps_style_local_ghost_evaluation_matches_periodic(device, num_layers
     torch.testing.assert_close(f_b, f_a, atol=2e-5 * max(1.0, float(f_a.abs().max())), rtol=1e-5)
 
 
+class FakeMLIAPData(FakeLammpsData):
+    """The fields ``compute_forces`` reads and writes (``lmp_mliap_wrapper.py:196-257``), on device tensors as a Kokkos
+    build hands them over."""
+
+    def __init__(self, nlocal, owner, rij, pair_i, pair_j, elems):
+        super().__init__(nlocal, owner)
+        self.rij, self.pair_i, self.pair_j, self.elems = rij, pair_i, pair_j, elems
+        self.npairs = int(pair_i.numel())
+        self.eatoms = torch.zeros(nlocal, dtype=torch.float64, device=rij.device)
+        self.energy = None
+        self.pair_forces = None
+
+    def update_pair_forces_gpu(self, f):
+        self.pair_forces = f.clone()
+
+
+@pytest.mark.gpu
+def test_mliap_wrapper_drives_the_model_like_lammps(device, tmp_path):
+    """``NequIPLAMMPSMLIAPWrapper.compute_forces`` on a rank's local + ghost data = the single-domain evaluation: per-atom
+    energies written to ``eatoms``, the rank's energy, pair forces dE/d(r_ij) handed to ``update_pair_forces_gpu``; the
+    wrapper survives the ``torch.save`` / ``torch.load`` round trip LAMMPS puts it through."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.integrations.lammps_mliap import NequIPLAMMPSMLIAPWrapper, create_lmp_mliap_file
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn import with_edge_vectors_
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=8)
+    data = syn.make_data(pos, types, 4.5, cell)
+    n = len(pos)
+    model = NequIPGNNModel(seed=3, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=32,
+                           avg_num_neighbors=38.0, per_type_energy_scales={"H": 1.2, "O": 0.8},
+                           per_type_energy_shifts={"H": -0.5, "O": 1.5}).eval()
+    edge_vec = with_edge_vectors_(dict(data))[K.EDGE_VECTORS_KEY]
+    ref = copy.deepcopy(model).to(device)({K.EDGE_VECTORS_KEY: edge_vec.to(device).requires_grad_(True),
+                                           K.EDGE_INDEX_KEY: data["edge_index"].to(device),
+                                           K.ATOM_TYPE_KEY: data["atom_types"].to(device)})
+    path = create_lmp_mliap_file(model, str(tmp_path / "water.nequip.lmp.pt"), device="cuda")
+    wrapper = torch.load(path, weights_only=False)
+    assert isinstance(wrapper, NequIPLAMMPSMLIAPWrapper)
+    assert wrapper.element_types == names and wrapper.rcutfac == 2.25 and wrapper.nparams == 1
+    ei_l, types_l, owner = _ghost_representation(data)
+    lmp = FakeMLIAPData(n, owner.to(device), edge_vec.to(device), ei_l[0].to(device), ei_l[1].to(device), types_l.to(device))
+    wrapper.compute_forces(lmp)
+    assert lmp.calls == {"forward": 2, "reverse": 2}
+    torch.testing.assert_close(lmp.eatoms.double(), ref[K.PER_ATOM_ENERGY_KEY].detach().view(-1).double(), atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(lmp.energy.double().view(()), ref[K.TOTAL_ENERGY_KEY].detach().sum().double(), atol=2e-5 * n, rtol=1e-6)
+    f_ref = ref[K.EDGE_FORCE_KEY].detach()
+    torch.testing.assert_close(lmp.pair_forces.double(), f_ref.double(), atol=2e-5 * max(1.0, float(f_ref.abs().max())), rtol=1e-5)
+    # a rank without work returns before touching anything
+    empty = FakeMLIAPData(0, owner[:0].to(device), edge_vec[:0].to(device), ei_l[0, :0].to(device), ei_l[1, :0].to(device),
+                          types_l[:0].to(device))
+    wrapper.compute_forces(empty)
+    assert empty.energy is None and empty.pair_forces is None
+
+
+def test_mliap_wrapper_attributes_and_cpu_refusal(tmp_path):
+    from nequip_amd.integrations.lammps_mliap import NequIPLAMMPSMLIAPWrapper, create_lmp_mliap_file
+    from nequip_amd.model import NequIPGNNModel
+
+    model = NequIPGNNModel(seed=0, r_max=5.0, type_names=["H", "C", "O"], num_layers=2, l_max=1, parity=True,
+                           num_features=8, avg_num_neighbors=10.0)
+    with pytest.raises(ValueError, match="nequip.lmp.pt"):
+        create_lmp_mliap_file(model, str(tmp_path / "model.pt"))
+    wrapper = torch.load(create_lmp_mliap_file(model, str(tmp_path / "m.nequip.lmp.pt")), weights_only=False)
+    assert isinstance(wrapper, NequIPLAMMPSMLIAPWrapper)
+    assert wrapper.element_types == ["H", "C", "O"] and wrapper.rcutfac == 2.5
+    assert wrapper.nparams == 1 and wrapper.ndescriptors == 1
+    assert wrapper.compute_descriptors(None) is None and wrapper.compute_gradients(None) is None
+
+    class CpuData:  # what a LAMMPS build without Kokkos passes (module name has no "kokkos")
+        nlocal, ntotal, npairs = 4, 4, 6
+
+    with pytest.raises(RuntimeError, match="GPU only"):
+        wrapper.compute_forces(CpuData())
+
+
 def test_noop_ghost_exchange_is_default_and_modifier_is_private():
     from nequip_amd.model import NequIPGNNModel
     from nequip_amd.nn import InteractionBlock, NoOpGhostExchangeModule
