@@ -334,3 +334,29 @@ def test_split_mode_workspace_sizes():
             os.environ.pop("NQA_NODE_F16", None)
     assert sizes["0"] == frags * 3 * 1024 * 2
     assert sizes["1"] == frags * 2 * 1024 * 2 + ((nexp * 2 * 4 + 255) // 256) * 256
+
+
+def test_mode_switches_and_volatile_weight_copies(monkeypatch):
+    """Host-side choices that the GPU tests only exercise in their default setting: the environment switches of the split
+    modes, and the mark that keeps per-step copies of trainable weights out of the packed (prepass) path."""
+    from nequip_amd import _lib
+    from nequip_amd.nn import mlp
+    from nequip_amd.o3._node_kernels import NodeLinearMeta, meta_transposed_weights
+
+    monkeypatch.delenv("NQA_MLP_FWD_F16", raising=False)
+    monkeypatch.delenv("NQA_MLP_BWD_F16", raising=False)
+    assert mlp.forward_mode(_lib.NQA_MLP_BF16X6) == _lib.NQA_MLP_F16X3 == mlp.backward_mode(_lib.NQA_MLP_BF16X6)
+    assert mlp.forward_mode(_lib.NQA_MLP_FP32) == _lib.NQA_MLP_FP32 == mlp.backward_mode(_lib.NQA_MLP_FP32)
+    monkeypatch.setenv("NQA_MLP_FWD_F16", "0")
+    monkeypatch.setenv("NQA_MLP_BWD_F16", "0")
+    assert mlp.forward_mode(_lib.NQA_MLP_BF16X6) == _lib.NQA_MLP_BF16X6 == mlp.backward_mode(_lib.NQA_MLP_BF16X6)
+
+    meta = NodeLinearMeta(Irreps("8x0e+4x1o"), Irreps("6x0e+4x1o"), [(0, 0), (1, 1)])
+    wp = torch.randn(2, meta.wstride)
+    wt = meta_transposed_weights(meta, wp)            # constant weights: cached on the tensor, packable
+    assert meta_transposed_weights(meta, wp) is wt and not getattr(wt, "_nqa_volatile", False)
+    wg = wp.clone().requires_grad_(True)
+    with torch.no_grad():                              # what a backward pass without create_graph looks like
+        vt = meta_transposed_weights(meta, wg)
+    assert vt.requires_grad is False and vt._nqa_volatile is True
+    assert torch.equal(vt, wt)
