@@ -455,6 +455,10 @@ std::tuple<Tensor, Tensor> edge_vectors_adj(const Tensor& g_vec, const Tensor& e
     const OptTensor batch_c = as_i64(batch);
     if (!batch_c.has_value() || num_frames == 1) {
       g_cell = part.sum(0).view({num_frames, 3, 3});
+    } else if (num_frames * num_nodes > (int64_t(1) << 24)) {
+      // (nqa_frame_sum scans `batch` once per frame: beyond this product the ATen scatter is the better tool -- the limit
+      // of nequip_amd/nn/utils.py::_frame_kernel_ok)
+      g_cell = at::zeros({num_frames, 9}, f64).index_add_(0, *batch_c, part).view({num_frames, 3, 3});
     } else {
       g_cell = at::empty({num_frames, 9}, f64);
       NQA_CALL(nqa_frame_sum(static_cast<const double*>(part.data_ptr()), static_cast<const int64_t*>(batch_c->data_ptr()),
