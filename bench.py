@@ -209,8 +209,9 @@ def kernel_roofline(kname, ks, kernel_steps):
         # credited with) is there too; with NQA_MLP_EXACT_FP32=1 the kernels run on the fp32 MFMA pipe and that is the
         # roofline.
         split = os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0")
+        # (radial_mlp_bwd_train goes through nn/mlp.py::backward_mode like the inference backward: fp16 split by default)
         f16_fwd = ((kname == "radial_mlp_fwd" and os.environ.get("NQA_MLP_FWD_F16", "") != "0")
-                   or (kname == "radial_mlp_bwd" and os.environ.get("NQA_MLP_BWD_F16", "") != "0"))
+                   or (kname in ("radial_mlp_bwd", "radial_mlp_bwd_train") and os.environ.get("NQA_MLP_BWD_F16", "") != "0"))
         r = {
             "bound": "mfma", "kernel": kname, "unit": "TFLOP/s",
             "avg_launch_ms": ks["avg_ms"], "algorithmic_flops_per_launch": ks["flops_per_call"],

@@ -41,6 +41,27 @@ extern "C" {
 /* 1: the ops of this process are (or would be) the ones defined by this library's TORCH_LIBRARY block */
 int nqa_torch_ops_registered_here(void);
 
+/* Edge-topology (CSR) cache of the tp_scatter / edge_vectors_adj ops -- the reuse contract.
+ *
+ * The ops derive two CSRs (by destination, by source) from the int64 edge_index they are handed and share them between the
+ * ops of an evaluation.  An entry is keyed on the identity of the index tensors' storage, torch's version counter, data
+ * pointers, strides and sizes.  A host that refills ONE persistent device buffer outside torch (raw hipMemcpy, Kokkos
+ * kernels: the usual LAMMPS-style set-up) changes none of these, so by DEFAULT (mode 1) an entry is reused only within the
+ * evaluation that built it: `edge_embed_fwd`, which every exported energy graph runs once before any op that needs a CSR,
+ * starts a new evaluation, as does nqa_torch_begin_evaluation().  Cost: two radix sorts per evaluation (0.24 ms at 400 k
+ * edges).
+ *   mode 0  never reuse (also NQA_TOPOLOGY_CACHE=0)
+ *   mode 1  reuse within one evaluation (default)
+ *   mode 2  reuse across evaluations (NQA_TOPOLOGY_CACHE=2): ONLY for hosts whose index tensors change solely through
+ *           torch operations (new tensors or in-place torch ops, which bump the version counter); call
+ *           nqa_torch_topology_invalidate() after any out-of-band rewrite.
+ * NQA_TOPOLOGY_VERIFY=1 (environment, read once): every hit is checked against a device checksum of the index tensors and
+ * rebuilt on a mismatch -- one host synchronisation per hit, for diagnosis.
+ * nqa_torch_topology_cache_mode(m) sets the mode and returns the previous one (m outside 0..2: query only). */
+int nqa_torch_topology_cache_mode(int mode);
+void nqa_torch_topology_invalidate(void);
+void nqa_torch_begin_evaluation(void);
+
 /* node_linear tables of `key` (transposed != 0: the adjoint map): chunk records of 8 int32, instruction records of 4
  * int32 (include/nequip_amd.h, nqa_node_linear).  Returns (n_chunk_int32 << 16) | n_instr_int32, or -1; copies when the
  * capacities (in int32) suffice.  dims = {dim_in, dim_out, weight_stride}. */

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -210,9 +211,39 @@ Tensor plan_image(Plan& P, const at::Device& device) {
 // An entry is keyed on the identity of the STORAGE behind the two index tensors (held through weak references, so an
 // address cannot be recycled under an entry), the version counter that views share with their base, data pointers,
 // strides and sizes -- the rule of nequip_amd/nn/_topology.py.  Every `edge_index[0]` / `edge_index[1]` view of one input
-// tensor maps to the same entry, whether the graph or one of these ops made the view; a caller that hands in the same
-// (unmodified) edge_index again reuses the CSRs across evaluations, a new tensor builds them once.
-// NQA_TOPOLOGY_CACHE=0: never reuse.
+// tensor maps to the same entry, whether the graph or one of these ops made the view.
+//
+// Reuse contract (include/nequip_amd_torch.h).  This library serves hosts without an interpreter, and those commonly
+// refill ONE persistent device buffer with raw hipMemcpy / Kokkos kernels -- which bumps no version counter.  So the
+// DEFAULT (mode 1) reuses an entry only within one evaluation: `edge_embed_fwd` -- run exactly once, at the top of every
+// exported energy graph, before any op that needs a CSR -- starts a new evaluation (so does nqa_torch_begin_evaluation()),
+// and entries of earlier evaluations are never hit.  Mode 2 (NQA_TOPOLOGY_CACHE=2 / nqa_torch_topology_cache_mode(2)) is
+// the opt-in for hosts whose index tensors only ever change through torch: entries live across evaluations as in the
+// Python host.  Mode 0 (NQA_TOPOLOGY_CACHE=0): never reuse.  NQA_TOPOLOGY_VERIFY=1 compares a device checksum of the two
+// index tensors on every hit (one host synchronisation per hit: diagnosis, not production) and rebuilds on a mismatch.
+std::atomic<int>& cache_mode() {
+  static std::atomic<int> mode([] {
+    const char* v = std::getenv("NQA_TOPOLOGY_CACHE");
+    if (v == nullptr || v[0] == '\0') return 1;
+    return v[0] == '0' ? 0 : (v[0] == '2' ? 2 : 1);
+  }());
+  return mode;
+}
+std::atomic<uint64_t>& evaluation_generation() {
+  static std::atomic<uint64_t> g(1);
+  return g;
+}
+bool verify_hits() {
+  static const bool v = [] {
+    const char* e = std::getenv("NQA_TOPOLOGY_VERIFY");
+    return e != nullptr && e[0] != '\0' && e[0] != '0';
+  }();
+  return v;
+}
+int64_t index_checksum(const Tensor& dst, const Tensor& src) {
+  if (dst.numel() == 0) return 0;
+  return (dst * 1000003 + src).sum().item<int64_t>();  // (int64 wrap-around is fine for a checksum)
+}
 struct Csr {
   Tensor rowptr, edge_id, other;
 };
@@ -222,6 +253,8 @@ struct Topology {
   const void *dst_ptr, *src_ptr;
   uint32_t dst_version, src_version;
   int64_t num_nodes, num_edges, dst_stride, src_stride;
+  uint64_t generation = 0;  // the evaluation that built the entry
+  int64_t checksum = 0;     // NQA_TOPOLOGY_VERIFY
   Tensor dst, src;  // contiguous int64
   Csr by_dst, by_src;
   bool has_dst = false, has_src = false;
@@ -247,20 +280,25 @@ Csr build_csr(const Tensor& key, const Tensor& other, int64_t N, int64_t E) {
   return c;
 }
 
+std::vector<std::shared_ptr<Topology>>& topology_cache_entries() {  // most recent last; guarded by registry_mutex()
+  static std::vector<std::shared_ptr<Topology>> cache;
+  return cache;
+}
+
 std::shared_ptr<Topology> topology_of(const Tensor& edge_dst, const Tensor& edge_src, int64_t num_nodes) {
   TORCH_CHECK(edge_dst.scalar_type() == at::kLong && edge_src.scalar_type() == at::kLong, "nequip_amd: edge indices must be int64");
   TORCH_CHECK(edge_dst.dim() == 1 && edge_dst.sizes() == edge_src.sizes(), "nequip_amd: edge_dst / edge_src must be 1-D of one length");
-  static std::vector<std::shared_ptr<Topology>> cache;  // most recent last
-  static const bool reuse = [] {
-    const char* v = std::getenv("NQA_TOPOLOGY_CACHE");
-    return v == nullptr || v[0] != '0';
-  }();
+  const int mode = cache_mode().load();
+  const bool reuse = mode != 0;
+  const uint64_t gen = evaluation_generation().load();
   std::lock_guard<std::mutex> lock(registry_mutex());
+  std::vector<std::shared_ptr<Topology>>& cache = topology_cache_entries();
   if (reuse) {
     for (size_t i = 0; i < cache.size(); ++i) {
       Topology& t = *cache[i];
       auto d = t.dst_ref.lock();
       auto s = t.src_ref.lock();
+      if (mode == 1 && t.generation != gen) continue;  // built by an earlier evaluation: its buffers may have been refilled
       if (d && s && d.get() == edge_dst.storage().unsafeGetStorageImpl() &&
           s.get() == edge_src.storage().unsafeGetStorageImpl() && t.dst_version == edge_dst._version() &&
           t.src_version == edge_src._version() && t.dst_ptr == edge_dst.data_ptr() && t.src_ptr == edge_src.data_ptr() &&
@@ -268,6 +306,7 @@ std::shared_ptr<Topology> topology_of(const Tensor& edge_dst, const Tensor& edge
           (t.num_edges == 0 || (t.dst_stride == edge_dst.stride(0) && t.src_stride == edge_src.stride(0)))) {
         auto hit = cache[i];
         cache.erase(cache.begin() + (long)i);
+        if (verify_hits() && index_checksum(edge_dst, edge_src) != hit->checksum) break;  // rewritten behind torch's back
         cache.push_back(hit);
         return hit;
       }
@@ -284,6 +323,8 @@ std::shared_ptr<Topology> topology_of(const Tensor& edge_dst, const Tensor& edge
   t->src_stride = edge_src.stride(0);
   t->dst = edge_dst.contiguous();
   t->src = edge_src.contiguous();
+  t->generation = gen;
+  if (verify_hits()) t->checksum = index_checksum(edge_dst, edge_src);
   if (reuse) {
     // drop entries whose tensors are gone, keep at most four
     std::vector<std::shared_ptr<Topology>> alive;
@@ -474,6 +515,7 @@ std::tuple<Tensor, Tensor> edge_vectors_adj(const Tensor& g_vec, const Tensor& e
 std::tuple<Tensor, Tensor> edge_embed_fwd(const Tensor& edge_vec, const Tensor& bessel_weights, int64_t lmax, bool want_sh,
                                           bool want_emb, int64_t nb, double rmax_recip, double p, double factor, bool f32) {
   require_gpu(edge_vec, "edge_embed_fwd");
+  evaluation_generation().fetch_add(1);  // top of an exported energy graph: CSRs of earlier evaluations are not reused (mode 1)
   c10::DeviceGuard guard(edge_vec.device());
   TORCH_CHECK(edge_vec.scalar_type() == at::kDouble, "nequip_amd::edge_embed_fwd: edge vectors must be float64");
   TORCH_CHECK(!want_emb || bessel_weights.scalar_type() == at::kDouble, "nequip_amd::edge_embed_fwd: bessel weights must be float64");
@@ -878,6 +920,18 @@ TORCH_LIBRARY_FRAGMENT(nequip_amd, m) {
 
 // ---- host-side introspection (tests: the tables built here against the Python host's, no GPU needed) -------------------
 extern "C" {
+
+int nqa_torch_topology_cache_mode(int mode) {
+  if (mode < 0 || mode > 2) return cache_mode().load();
+  return cache_mode().exchange(mode);
+}
+
+void nqa_torch_topology_invalidate(void) {
+  std::lock_guard<std::mutex> lock(registry_mutex());
+  topology_cache_entries().clear();
+}
+
+void nqa_torch_begin_evaluation(void) { evaluation_generation().fetch_add(1); }
 
 // int32 tables of node_linear for `key`: returns the number of int32 written to each (or the required counts if too small)
 int nqa_torch_linear_tables(const char* key, int transposed, int32_t* chunks, int32_t chunks_cap, int32_t* instr,

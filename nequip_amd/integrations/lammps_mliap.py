@@ -44,7 +44,11 @@ class NequIPLAMMPSMLIAPWrapper(_Base):
         super().__init__()
         r_max = getattr(model, "r_max", None)
         if r_max is None:
-            r_max = float(model.metadata["r_max"])
+            md = getattr(model, "metadata", None) or {}
+            if "r_max" not in md:
+                raise ValueError("NequIPLAMMPSMLIAPWrapper needs the model's cutoff: the GraphModel was built without "
+                                 "`r_max` (pass it to the model builder so that it lands in `model.metadata`)")
+            r_max = float(md["r_max"])
         self.rcutfac = 0.5 * float(r_max)  # LAMMPS multiplies by 2 (`lmp_mliap_wrapper.py:72`)
         self.element_types = list(model.type_names)
         self.nparams = 1
@@ -119,5 +123,9 @@ def create_lmp_mliap_file(model: torch.nn.Module, output_path: str, **kwargs) ->
     wrapper object)."""
     if not str(output_path).endswith(".nequip.lmp.pt"):
         raise ValueError("the LAMMPS ML-IAP file must be named *.nequip.lmp.pt (the reference's convention)")
-    torch.save(NequIPLAMMPSMLIAPWrapper(model.to("cpu"), **kwargs), output_path)
+    # a CPU COPY is pickled: the caller's (possibly GPU-resident, possibly still in use) model is left untouched, and the
+    # copy carries no device-side derived state (`Module.to` does not move cached weight images)
+    import copy
+
+    torch.save(NequIPLAMMPSMLIAPWrapper(copy.deepcopy(model).to("cpu"), **kwargs), output_path)
     return str(output_path)

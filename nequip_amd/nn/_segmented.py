@@ -61,6 +61,27 @@ class _SegmentMLP(ScalarMLPFunction):
                 layer.weight = self._cached[1]
         return self
 
+    def release(self) -> None:
+        """Drop the derived last-layer weight once the segment's forward has been recorded.  In training it is a non-leaf
+        ``index_select`` of the parent's parameter: left on the module it would keep the previous step's autograd graph
+        alive and make ``copy.deepcopy(model)`` raise ("Only Tensors created explicitly by the user ... support the deepcopy
+        protocol") -- best-model snapshots, lazily created EMA copies.  ``sync()`` derives it again on the next forward;
+        autograd keeps what the backward needs."""
+        layer = self.mlp[self._last]
+        w = getattr(layer, "weight", None)
+        if w is not None and (w.grad_fn is not None or w.requires_grad):
+            layer.weight = None
+
+    def __getstate__(self):
+        # deepcopy / pickle: never carry derived tensors (the gathered columns, the eval-mode cache)
+        for layer in self.mlp:
+            w = getattr(layer, "weight", None)
+            if w is not None and not isinstance(w, torch.nn.Parameter):
+                layer.weight = None
+        state = dict(self.__dict__)
+        state["_cached"] = None
+        return state
+
 
 class Segment:
     def __init__(self, c0: int, c1: int, x_cols, w_cols, out_cols, tp):

@@ -210,9 +210,15 @@ class _TopologyCache:
     * ``NQA_TOPOLOGY_VERIFY=1``: every cache hit is checked against a checksum of the index values taken when the
       entry was built (one reduction + a host synchronisation per hit: a debugging mode) and raises on a mismatch.
 
-    A few entries are kept (least recently used first out), so alternating graphs do not rebuild on every call."""
+    A few entries are kept (least recently used first out), so alternating graphs do not rebuild on every call.
 
-    MAX_ENTRIES = 4
+    Memory: an entry holds views of the caller's int64 index tensors (which keeps their storage alive: the weak references
+    above guard against recycled ``id`` values, they do not free an entry early), both int32 CSRs and the pairing / owner
+    lists -- about 100 bytes per directed edge, i.e. ~0.4 GB per cached graph at the 100 000-atom Cu box.  A driver that
+    builds a new neighbour list every step (MD) therefore keeps the last ``MAX_ENTRIES`` graphs resident;
+    ``NQA_TOPOLOGY_CACHE_ENTRIES=1`` (or ``topology_cache.MAX_ENTRIES = 1``) bounds that to the current graph."""
+
+    MAX_ENTRIES = max(1, int(os.environ.get("NQA_TOPOLOGY_CACHE_ENTRIES", "4") or 4))
 
     def __init__(self):
         self._entries = []  # [(key, (ref_dst, ref_src), topo, checksum)] most recent last
@@ -287,7 +293,7 @@ class _TopologyCache:
         self._entries = [e for e in self._entries if e[1][0]() is not None and e[1][1]() is not None]
         self._entries.append((key, (weakref.ref(bd), weakref.ref(bs)), topo,
                               self._checksum(edge_dst, edge_src) if verify else None))
-        if len(self._entries) > self.MAX_ENTRIES:
+        while len(self._entries) > self.MAX_ENTRIES:
             self._entries.pop(0)
         return topo
 

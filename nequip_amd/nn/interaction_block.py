@@ -150,6 +150,8 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
                     continue
             outs.append(sg.tp(x=x_s, edge_attr=attrs, edge_weight=mlp(emb), edge_dst=edge_index[0],
                               edge_src=edge_index[1]))
+        for sg in self._segments:
+            sg.mlp.release()  # no graph-attached tensors stay on the module (deepcopy of a model in training)
         return torch.cat(outs, dim=1).index_select(1, self._segment_out_perm)
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:

@@ -51,6 +51,7 @@ def test_aotinductor_package_reproduces_eager_model(device, tmp_path):
                            parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
                            avg_num_neighbors=float(data["edge_index"].shape[1] / data["pos"].shape[0]),
                            per_type_energy_scales=1.0, per_type_energy_shifts=0.0).to(device).eval()
+    model_avg = float(data["edge_index"].shape[1] / data["pos"].shape[0])
     data = AtomicDataDict.to_device(data, device)
     assert model.metadata["nequip_custom_ops_libs"] == "nequip_amd" and model.metadata["r_max"] == "4.5"
     ref = model(dict(data))
@@ -72,3 +73,19 @@ def test_aotinductor_package_reproduces_eager_model(device, tmp_path):
     fscale = max(1.0, float(ref2["forces"].abs().max()))
     torch.testing.assert_close(out2["total_energy"], ref2["total_energy"], atol=2e-5 * len(pos), rtol=2e-5)
     torch.testing.assert_close(out2["forces"], ref2["forces"], atol=2e-5 * fscale, rtol=2e-5)
+    # parity proper: the compiled package against the CPU oracle (not only against the eager HIP model), on the box it
+    # was NOT compiled for -- bars of tests/test_baseline_size_parity.py
+    from oracle import model as omodel
+
+    cfg = dict(r_max=4.5, num_layers=3, l_max=2, parity=False, num_features=64, radial_mlp_depth=1,
+               radial_mlp_width=128, num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=model_avg,
+               model_dtype="float32")
+    weights = {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+    d2_cpu = syn.make_data(pos, types, 4.5, cell)
+    orc = omodel.energy_forces(d2_cpu, cfg, weights, with_virial=True)
+    df = float((orc["forces"] - out2["forces"].cpu()).abs().max())
+    assert df < 1e-4, f"compiled package: forces differ from the oracle by {df:.3e} eV/A"
+    fs = max(1.0, float(orc["forces"].abs().max()))
+    torch.testing.assert_close(out2["total_energy"].cpu(), orc["total_energy"], atol=5e-5 * len(pos), rtol=5e-5)
+    torch.testing.assert_close(out2["forces"].cpu(), orc["forces"], atol=5e-5 * fs, rtol=5e-5)
+    torch.testing.assert_close(out2["virial"].cpu().view(-1, 3, 3), orc["virial"], atol=5e-5 * len(pos) * fs, rtol=5e-4)

@@ -75,6 +75,21 @@ def test_calculator_matches_direct_model_call(device, periodic):
         assert "stress" not in calc.results
     with pytest.raises(ValueError):
         calc.calculate(FakeAtoms(["Xx"] * 3, pos[:3]))
+    # parity proper: calculator results (device neighbour list, unit conversion) against the CPU oracle on the host-built
+    # neighbour list of the same atoms
+    from oracle import model as omodel
+
+    cfg = dict(r_max=4.0, num_layers=2, l_max=2, parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=64,
+               num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=20.0, model_dtype="float32")
+    weights = {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+    orc = omodel.energy_forces(data, cfg, weights, with_virial=periodic)
+    np.testing.assert_allclose(e, 2.0 * float(orc["total_energy"]), rtol=5e-5, atol=5e-5 * len(pos))
+    fo = orc["forces"].numpy() * (2.0 / 0.5)
+    assert np.abs(f - fo).max() < 1e-4 * (2.0 / 0.5) * max(1.0, np.abs(orc["forces"].numpy()).max())
+    if periodic:
+        vol = abs(np.linalg.det(np.asarray(cell, dtype=np.float64)))
+        so = full_3x3_to_voigt_6_stress((-orc["virial"].numpy().reshape(3, 3) / vol)) * (2.0 / 0.5**3)
+        np.testing.assert_allclose(s, so, rtol=0, atol=5e-4 * max(1e-3, np.abs(so).max()))
 
 
 @pytest.mark.gpu
@@ -103,3 +118,16 @@ def test_calculator_from_compiled_model(device, tmp_path):
     np.testing.assert_allclose(e1, e0, rtol=2e-5, atol=2e-5 * len(pos))
     np.testing.assert_allclose(f1, f0, rtol=0, atol=2e-5 * max(1.0, np.abs(f0).max()))
     np.testing.assert_allclose(s1, s0, rtol=0, atol=2e-5 * max(1e-3, np.abs(s0).max()))
+    # parity proper: the calculator around the COMPILED package against the CPU oracle
+    from oracle import model as omodel
+
+    cfg = dict(r_max=4.0, num_layers=2, l_max=2, parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=64,
+               num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=20.0, model_dtype="float32")
+    weights = {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+    orc = omodel.energy_forces(syn.make_data(pos, types, 4.0, cell), cfg, weights, with_virial=True)
+    np.testing.assert_allclose(e1, float(orc["total_energy"]), rtol=5e-5, atol=5e-5 * len(pos))
+    fo = orc["forces"].numpy()
+    assert np.abs(f1 - fo).max() < 1e-4 * max(1.0, np.abs(fo).max())
+    vol = abs(np.linalg.det(np.asarray(cell, dtype=np.float64)))
+    so = full_3x3_to_voigt_6_stress(-orc["virial"].numpy().reshape(3, 3) / vol)
+    np.testing.assert_allclose(s1, so, rtol=0, atol=5e-4 * max(1e-3, np.abs(so).max()))

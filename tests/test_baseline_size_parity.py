@@ -153,3 +153,130 @@ def test_cfg4_shaped_training_step_parameter_gradients(device):
         worst = max(worst, float((r - p.grad.cpu()).abs().max()) / scale)
         torch.testing.assert_close(r, p.grad.cpu(), atol=tol * scale, rtol=tol * 10, msg=lambda m: f"{k}: {m}")
     print(f"[cfg-4 train] {len(grads_ref)} parameter tensors, worst |dgrad| / max|grad| = {worst:.2e}")
+
+
+# ---- round 4: the configurations the round-3 review found untested at their own shape ------------------------------
+@pytest.mark.gpu
+def test_cfg1_tutorial_hyper_parameters_aspirin_batch(device):
+    """BASELINE cfg-1 at its REAL hyper-parameters (configs/tutorial.yaml:19-25,205-223: r_max 5, l_max 1, parity=True,
+    32 features, 4 layers, radial MLP depth 2 / width 64) on ``bench.WORKLOADS['aspirin5']`` -- the batch of five 21-atom
+    molecules ``bench.py --workload aspirin5`` times -- against the oracle.  No cell, so no virial."""
+    import bench
+    from nequip_amd.data import AtomicDataDict
+
+    w = bench.WORKLOADS["aspirin5"]
+    assert (w["l_max"], w["num_features"], w["num_layers"], w["parity"], w["radial_mlp_depth"],
+            w["radial_mlp_width"], w["r_max"]) == (1, 32, 4, True, 2, 64, 5.0)
+    data, names = bench.build_box(w, seed=0)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 105
+    cfg = bench.model_cfg(w, e / n)
+    model = bench.build_model(cfg, names, device)
+    out = model(AtomicDataDict.to_device(data, device))
+    torch.cuda.synchronize()
+    ref = omodel.energy_forces(data, cfg, _weights(model))
+    f_ref, f_out = ref["forces"], out["forces"].cpu()
+    fscale = float(f_ref.abs().max())
+    df = float((f_ref - f_out).abs().max())
+    de = float((ref["total_energy"] - out["total_energy"].cpu()).abs().max())
+    print(f"[cfg-1 aspirin5] N={n} E={e} |dE|={de:.3e} max|dF|={df:.3e} eV/A (max|F|={fscale:.3e})")
+    torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=5e-5 * 21, rtol=5e-5)
+    assert df < 1e-4 * max(1.0, fscale), f"forces differ from the oracle by {df:.3e} eV/A"
+    torch.testing.assert_close(f_ref, f_out, atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+
+
+@pytest.mark.gpu
+def test_cfg5_model_cu_4000_atoms_large_box_launch_shapes(device):
+    """cfg-5's model on 10 x 10 x 10 fcc cells = 4000 Cu atoms (~170 k edges): ``nodes x chunks`` is 8000 here, so this
+    still runs the four-wavefronts-per-node launch; ``NQA_SPEC_WPN=1`` forces the ONE-wavefront-per-(node, chunk) shape
+    the 100 000-atom box runs with, at model level.  Both against the oracle."""
+    import bench
+    from nequip_amd.data import AtomicDataDict
+
+    w = dict(bench.WORKLOADS["cu100k"], reps=(10, 10, 10))
+    data, names = bench.build_box(w, seed=0)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 4000
+    cfg = bench.model_cfg(w, e / n)
+    model = bench.build_model(cfg, names, device)
+    _oracle_threads()
+    t0 = time.perf_counter()
+    ref = omodel.energy_forces(data, dict(cfg, oracle_edge_chunk=4096), _weights(model), with_virial=True)
+    print(f"[cfg-5 cu4000] oracle: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    old = os.environ.get("NQA_SPEC_WPN")
+    try:
+        for wpn in (None, "1"):
+            if wpn is None:
+                os.environ.pop("NQA_SPEC_WPN", None)
+            else:
+                os.environ["NQA_SPEC_WPN"] = wpn
+            out = model(AtomicDataDict.to_device(data, device))
+            torch.cuda.synchronize()
+            _compare(f"cfg-5 cu4000 wpn={wpn or 'auto'}", data, out, ref)
+    finally:
+        if old is None:
+            os.environ.pop("NQA_SPEC_WPN", None)
+        else:
+            os.environ["NQA_SPEC_WPN"] = old
+
+
+@pytest.mark.gpu
+def test_cfg4_full_batch_32_frames_training_step(device):
+    """cfg-4 at its full per-rank batch: 32 frames x 256 atoms = 8192 atoms (``bench.py --workload train256``), 5 species.
+    Loss, forces and the parameter gradients of the force-matching loss against autograd-through-autograd of the oracle
+    (edge ranges of 8192 under activation checkpointing: same arithmetic per edge)."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+
+    nframes = 32
+    frames = []
+    for f in range(nframes):
+        pos, types, cell, names = syn.random_frame(256, 5, seed=f)  # bench.py's rank-0 frames
+        frames.append(syn.make_data(pos, types, 4.5, cell))
+    data = AtomicDataDict.batched_from_list(frames)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 8192
+    cfg = dict(r_max=4.5, num_layers=3, l_max=2, parity=False, num_features=64, radial_mlp_depth=1,
+               radial_mlp_width=128, num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=e / n,
+               model_dtype="float32")
+    model = NequIPGNNModel(seed=5, model_dtype="float32", type_names=names, per_type_energy_scales=1.0,
+                           per_type_energy_shifts=0.0, **{k: v for k, v in cfg.items() if k != "model_dtype"})
+    gen = torch.Generator().manual_seed(0)
+    f_target = torch.randn(n, 3, generator=gen, dtype=torch.float64)
+    e_target = torch.randn(nframes, 1, generator=gen, dtype=torch.float64)
+
+    def loss_of(out, ft, et):
+        return (out["forces"] - ft).square().mean() + (out["total_energy"] - et).square().mean()
+
+    _oracle_threads()
+    t0 = time.perf_counter()
+    param_names = {k for k, _ in model.named_parameters()}
+    weights = {k.replace("model.func.", ""): v.detach().clone().requires_grad_(k in param_names)
+               for k, v in model.state_dict().items()}
+    out_ref = omodel.energy_forces(data, dict(cfg, oracle_edge_chunk=8192), weights, create_graph=True)
+    loss_ref = loss_of(out_ref, f_target, e_target)
+    names_w = [k for k, v in weights.items() if v.requires_grad]
+    grads_ref = dict(zip(names_w, torch.autograd.grad(loss_ref, [weights[k] for k in names_w])))
+    print(f"[cfg-4 full batch] oracle double backward: {time.perf_counter() - t0:.1f} s, N={n} E={e}")
+
+    model = model.to(device).train()
+    out = model(AtomicDataDict.to_device(data, device))
+    loss = loss_of(out, f_target.to(device), e_target.to(device))
+    loss.backward()
+    tol = 2e-4
+    torch.testing.assert_close(loss_ref.detach(), loss.detach().cpu(), atol=tol, rtol=tol)
+    df = float((out_ref["forces"].detach() - out["forces"].detach().cpu()).abs().max())
+    assert df < 1e-4, f"forces differ from the oracle by {df:.3e} eV/A (bar 1e-4)"
+    torch.testing.assert_close(out_ref["total_energy"].detach(), out["total_energy"].detach().cpu(), atol=5e-5 * 256,
+                               rtol=5e-5)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        key = k.replace("model.func.", "")
+        assert p.grad is not None, f"no gradient for {k}"
+        r = grads_ref[key]
+        scale = max(1e-3, float(r.abs().max()))
+        worst = max(worst, float((r - p.grad.cpu()).abs().max()) / scale)
+        torch.testing.assert_close(r, p.grad.cpu(), atol=tol * scale, rtol=tol * 10, msg=lambda m: f"{k}: {m}")
+    print(f"[cfg-4 full batch] max|dF|={df:.3e} eV/A, {len(grads_ref)} parameter tensors, "
+          f"worst |dgrad| / max|grad| = {worst:.2e}")

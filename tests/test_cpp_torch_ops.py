@@ -47,10 +47,17 @@ def test_library_exports_what_its_header_declares(cpp):
 
     header = open(os.path.join(ROOT, "include", "nequip_amd_torch.h")).read()
     declared = set(re.findall(r"\b(nqa_torch_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 5, declared
+    assert len(declared) == 8, declared
     for name in declared:
         assert hasattr(cpp, name), name
     assert cpp.nqa_torch_ops_registered_here() == 1
+    # the topology-cache contract: per-evaluation reuse is the default, cross-evaluation reuse is opt-in
+    if os.environ.get("NQA_TOPOLOGY_CACHE", "") == "":
+        assert cpp.nqa_torch_topology_cache_mode(-1) == 1
+        assert cpp.nqa_torch_topology_cache_mode(2) == 1 and cpp.nqa_torch_topology_cache_mode(-1) == 2
+        assert cpp.nqa_torch_topology_cache_mode(1) == 2
+    cpp.nqa_torch_topology_invalidate()
+    cpp.nqa_torch_begin_evaluation()
     for op in OPS:  # every op the library registers is documented in the header with its schema
         assert re.search(rf"\b{op}\(", header), op
 
@@ -340,3 +347,75 @@ def test_standalone_cpp_runner(device, tmp_path, exported, cpp):
             arr = np.fromfile(d / fn, dtype={"f32": np.float32, "f64": np.float64, "i64": np.int64}[dt]).reshape([int(s) for s in dims])
             err = float(np.abs(arr.astype(np.float64) - rt.double().numpy()).max())
             assert err <= 2e-5 * max(1.0, float(rt.abs().max())), (fn, err)
+
+
+_STALE = """
+import ctypes, sys, torch
+torch.ops.load_library(sys.argv[1])
+assert "nequip_amd" not in sys.modules
+lib = ctypes.CDLL(sys.argv[1])
+hip = ctypes.CDLL("libamdhip64.so")
+rec = torch.load(sys.argv[2])
+ops = torch.ops.nequip_amd
+x, y, w, key, ei_a, ei_b, vec, bw, cfg = [t.cuda() if isinstance(t, torch.Tensor) else t for t in rec]
+buf = ei_a.clone()                      # the host's ONE persistent index buffer
+def evaluate(new_evaluation):
+    if new_evaluation:
+        ops.edge_embed_fwd(vec, bw, *cfg)   # every exported energy graph starts with this op
+    return ops.tp_scatter_fwd(x, y, w, buf[0], buf[1], key)
+out_a = evaluate(True)
+# refill the buffer behind torch's back (no version bump), as a Kokkos / raw-HIP host would
+assert hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ei_b.data_ptr()), ctypes.c_size_t(buf.nbytes), 3) == 0
+torch.cuda.synchronize()
+ref_b = ops.tp_scatter_fwd(x, y, w, ei_b[0].clone(), ei_b[1].clone(), key)
+assert not torch.equal(ref_b, out_a)
+mode = lib.nqa_torch_topology_cache_mode(-1)
+assert mode == 1, mode
+out_b = evaluate(True)                  # default: a new evaluation never sees the CSRs of the previous one
+assert torch.equal(out_b, ref_b), "stale CSR reused across evaluations"
+# the opt-in persistent mode keeps entries across evaluations: this is the documented hazard, and invalidate() the way out
+lib.nqa_torch_topology_cache_mode(2)
+out_a2 = ops.tp_scatter_fwd(x, y, w, buf[0], buf[1], key)   # (entry built for the buffer's current content = graph B)
+assert hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ei_a.data_ptr()), ctypes.c_size_t(buf.nbytes), 3) == 0
+torch.cuda.synchronize()
+stale = evaluate(True)
+assert torch.equal(stale, ref_b), "mode 2 is expected to reuse the entry (that is its contract)"
+lib.nqa_torch_topology_invalidate()
+fresh = evaluate(True)
+assert torch.equal(fresh, out_a)
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_cpp_topology_cache_is_per_evaluation_by_default(device, tmp_path, cpp):
+    """a host without Python refills one persistent edge-index buffer out of band (no version bump).
+    The C++ registration must not serve the previous neighbour list's CSRs to the next evaluation."""
+    from nequip_amd.nn._tp_scatter_ops import plan_key
+    from nequip_amd.o3.irreps import Irreps
+    from nequip_amd.utils import synthetic as syn
+    from oracle import irreps as oir
+    from oracle import tp as otp
+
+    torch.manual_seed(1)
+    pos, types, cell, names = syn.water_box(n_side=3, seed=4)
+    data = syn.make_data(pos, types, 4.5, cell)
+    ei_a = data["edge_index"]
+    N, E = len(pos), ei_a.shape[1]
+    perm = torch.randperm(N)
+    ei_b = perm[ei_a]  # another graph with the same edge count, in the same buffer
+    f_in, f_out = "8x0e+8x1o+8x2e", "8x0e+8x1o+8x2e"
+    sh = Irreps.spherical_harmonics(2)
+    mid, instr = otp.build_instructions(f_in, str(sh), f_out)
+    key = plan_key(Irreps(f_in), sh, Irreps(oir.to_str(mid)), instr)
+    wn = sum(Irreps(f_in)[i[0]].mul for i in instr)
+    x, y, w = torch.randn(N, Irreps(f_in).dim), torch.randn(E, sh.dim), torch.randn(E, wn)
+    vec = torch.randn(E, 3, dtype=torch.float64)
+    bw = torch.arange(1, 9, dtype=torch.float64) * torch.pi
+    cfg = (2, True, False, 0, 1.0, 6.0, 1.0, True)
+    path = tmp_path / "stale.pt"
+    torch.save([x, y, w, key, ei_a, ei_b, vec, bw, cfg], path)
+    env = {k: v for k, v in os.environ.items() if k not in ("NQA_TOPOLOGY_CACHE", "NQA_TOPOLOGY_VERIFY")}
+    r = subprocess.run([sys.executable, "-c", _STALE, LIB, str(path)], capture_output=True, text=True, timeout=900,
+                       env=dict(env, PYTHONPATH=""), cwd="/tmp")
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])

@@ -52,6 +52,27 @@ def _ghost_representation(data):
     return torch.stack([ei[0], src_new]), types, owner
 
 
+def _oracle_of(model, data, num_layers):
+    """CPU oracle of the same periodic box: per-atom energies, total energy, forces."""
+    from oracle import model as omodel
+
+    cfg = dict(r_max=4.5, num_layers=num_layers, l_max=2, parity=False, num_features=16, radial_mlp_depth=1,
+               radial_mlp_width=32, num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=38.0, model_dtype="float32")
+    weights = {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+    return omodel.energy_forces(data, cfg, weights)
+
+
+def _edge_forces_to_atoms(edge_forces, edge_index, n):
+    """F_i = -dE/dpos_i from dE/d(edge vector): r_e = pos[src] - pos[dst] + shift (nequip/nn/utils.py:88-114; edge_index[0]
+    is the centre = dst, edge_index[1] the neighbour = src; periodic images / ghosts fold onto their owner)."""
+    g = edge_forces.detach().double().cpu()
+    f = torch.zeros(n, 3, dtype=torch.float64)
+    f.index_add_(0, edge_index[0], g)
+    f.index_add_(0, edge_index[1], -g)
+    return f
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_layers", [2, 3])
 def test_lammps_style_local_ghost_evaluation_matches_periodic(device, num_layers):
@@ -93,6 +114,15 @@ def test_lammps_style_local_ghost_evaluation_matches_periodic(device, num_layers
                                rtol=1e-6)
     f_a, f_b = out_a[K.EDGE_FORCE_KEY].detach(), out_b[K.EDGE_FORCE_KEY].detach()
     torch.testing.assert_close(f_b, f_a, atol=2e-5 * max(1.0, float(f_a.abs().max())), rtol=1e-5)
+    # parity proper: the local / ghost evaluation against the CPU oracle of the periodic box -- per-atom energies, total
+    # energy, and the pair forces folded onto the atoms (ghost -> owner) against the oracle's forces
+    orc = _oracle_of(model, data, num_layers)
+    torch.testing.assert_close(e_b.double().cpu().view(-1), orc["atomic_energy"].view(-1), atol=5e-5, rtol=5e-5)
+    torch.testing.assert_close(out_b[K.TOTAL_ENERGY_KEY].detach().double().cpu().view(-1), orc["total_energy"].view(-1),
+                               atol=5e-5 * n, rtol=5e-5)
+    f_atoms = _edge_forces_to_atoms(f_b, data["edge_index"], n)
+    df = float((f_atoms - orc["forces"]).abs().max())
+    assert df < 1e-4 * max(1.0, float(orc["forces"].abs().max())), f"ghost evaluation: forces differ from the oracle by {df:.3e}"
 
 
 class FakeMLIAPData(FakeLammpsData):
@@ -145,6 +175,13 @@ def test_mliap_wrapper_drives_the_model_like_lammps(device, tmp_path):
     torch.testing.assert_close(lmp.energy.double().view(()), ref[K.TOTAL_ENERGY_KEY].detach().sum().double(), atol=2e-5 * n, rtol=1e-6)
     f_ref = ref[K.EDGE_FORCE_KEY].detach()
     torch.testing.assert_close(lmp.pair_forces.double(), f_ref.double(), atol=2e-5 * max(1.0, float(f_ref.abs().max())), rtol=1e-5)
+    # parity proper: what LAMMPS receives against the CPU oracle of the periodic box
+    orc = _oracle_of(model, data, 3)
+    torch.testing.assert_close(lmp.eatoms.double().cpu(), orc["atomic_energy"].view(-1), atol=5e-5, rtol=5e-5)
+    torch.testing.assert_close(lmp.energy.double().cpu().view(-1), orc["total_energy"].view(-1), atol=5e-5 * n, rtol=5e-5)
+    f_atoms = _edge_forces_to_atoms(lmp.pair_forces, data["edge_index"], n)
+    df = float((f_atoms - orc["forces"]).abs().max())
+    assert df < 1e-4 * max(1.0, float(orc["forces"].abs().max())), f"ML-IAP wrapper: forces differ from the oracle by {df:.3e}"
     # a rank without work returns before touching anything
     empty = FakeMLIAPData(0, owner[:0].to(device), edge_vec[:0].to(device), ei_l[0, :0].to(device), ei_l[1, :0].to(device),
                           types_l[:0].to(device))

@@ -57,6 +57,32 @@ def test_uniform_models_have_no_segments():
     assert all(b._segments is None for b in m.modules() if isinstance(b, InteractionBlock))
 
 
+def test_preset_model_deepcopies_after_a_training_mode_sync():
+    """ADVICE r3: in training mode the segment MLP's last layer is a column gather of the parent's parameter (a non-leaf);
+    left on the module it made ``copy.deepcopy(model)`` raise after any training-mode forward (best-model snapshots, EMA
+    copies).  The interaction block releases it after the segment forward; pickling never carries derived tensors."""
+    import copy
+
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn.interaction_block import InteractionBlock
+
+    m = NequIPGNNModel(seed=0, r_max=4.0, type_names=["H", "O"], avg_num_neighbors=10.0, **PRESETS["M"]).train()
+    blocks = [b for b in m.modules() if isinstance(b, InteractionBlock) and b._segments is not None]
+    assert blocks
+    for b in blocks:
+        for sg in b._segments:
+            mlp = sg.mlp.sync()  # what the training-mode forward does first
+            assert mlp.mlp[mlp._last].weight.grad_fn is not None
+    m2 = copy.deepcopy(m)  # (raised "Only Tensors created explicitly by the user ... support the deepcopy protocol")
+    for b, b2 in zip(blocks, [b for b in m2.modules() if isinstance(b, InteractionBlock) and b._segments is not None]):
+        for sg, sg2 in zip(b._segments, b2._segments):
+            assert sg2.mlp._parent[0] is b2.edge_mlp and sg2.mlp._parent[0] is not b.edge_mlp
+            sg.mlp.release()
+            assert sg.mlp.mlp[sg.mlp._last].weight is None
+            w2 = sg2.mlp.sync().mlp[sg2.mlp._last].weight  # the copy derives its own columns from its own parameters
+            torch.testing.assert_close(w2, b2.edge_mlp.mlp[sg2.mlp._last].weight.index_select(1, sg2.mlp._cols))
+
+
 def _cfg(preset, n_avg):
     p = PRESETS[preset]
     return dict(r_max=4.5, num_layers=p["num_layers"], l_max=p["l_max"], parity=False, num_features=p["num_features"],
@@ -133,3 +159,6 @@ def test_preset_training_step_parameter_gradients(device):
         assert p.grad is not None, k
         torch.testing.assert_close(r, p.grad.cpu(), atol=2e-4 * max(1e-3, float(r.abs().max())), rtol=2e-3,
                                    msg=lambda m: f"{k}: {m}")
+    import copy
+
+    copy.deepcopy(model)  # a snapshot / EMA copy in the middle of training (no graph-attached tensors left on the modules)
