@@ -37,6 +37,22 @@ NQA_PLAN_FUSED_ROWS_OK = 8
 _P32 = POINTER(c_int32)
 
 
+class GateBlock(ctypes.Structure):
+    """``nqa_gate_block`` (include/nequip_amd.h): one block of a gate's output."""
+
+    _fields_ = [("out_off", c_int32), ("d", c_int32), ("mul", c_int32), ("val_off", c_int32), ("gate_off", c_int32),
+                ("act", c_int32), ("cst", c_double)]
+
+
+class NodePart(ctypes.Structure):
+    """``nqa_node_part`` (include/nequip_amd.h): one operand set + destination of ``nqa_node_fused``."""
+
+    _fields_ = [("x", c_void_p), ("packed", c_void_p), ("chunk_table", c_void_p), ("instr_table", c_void_p),
+                ("n_chunks", c_int32), ("n_instr", c_int32), ("n_types", c_int32), ("dim_in", c_int32),
+                ("out", c_void_p), ("addend", c_void_p), ("dim_out", c_int32), ("accumulate", c_int32),
+                ("scale", c_double), ("in_gate", c_void_p), ("n_in_gate", c_int32), ("pad", c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/nequip_amd.h declares
 SIGNATURES = {
     "nqa_abi_version": (c_int32, []),
@@ -185,6 +201,10 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32]
         + [c_int64, c_double, c_void_p],
     ),
+    "nqa_node_fused": (
+        c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p],
+    ),
+    "nqa_node_fused_plan": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, _P32, c_int32, _P32, c_int32]),
     "nqa_neighbor_list_workspace_bytes": (c_int64, [c_int64]),
     "nqa_neighbor_list_count": (
         c_int32,

@@ -198,6 +198,10 @@ def _full_nequip_energy_model(
         )
         prev_irreps_out = current_convnet.irreps_out
         modules[f"layer{layer_i}_convnet"] = current_convnet
+        if layer_i > 0:
+            # the previous layer's Gate is consumed by this layer's linear_1 / self-connection only: it may be folded into
+            # them (eval mode, GPU; nn/convnetlayer.py::defer_gate)
+            modules[f"layer{layer_i - 1}_convnet"].defer_gate = True
 
     if readout_mlp_hidden_layers_width is None:
         readout_mlp_hidden_layers_width = Irreps(feature_irreps_hidden[-1]).dim

@@ -6,7 +6,9 @@ import torch
 
 from ..data import AtomicDataDict
 from ..o3.irreps import Irreps
+from ..o3 import _node_kernels
 from ..o3.modules import Gate, NormActivation
+from ..utils.tracing import traceable
 from ._graph_mixin import GraphModuleMixin
 from .interaction_block import InteractionBlock
 from .utils import tp_path_exists
@@ -73,9 +75,26 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
                                 epsilon=1e-8, bias=False)
         return nonlin, layer_out
 
+    # Set by the model builder when the NEXT module of the network is a ConvNetLayer around an InteractionBlock: in eval mode
+    # on the GPU the gate is then not applied here but folded into its two consumers (linear_1 and the self-connection of the
+    # next block: one launch, o3/_node_kernels.py::fused_node_stage), and its backward into the launch that produces their
+    # input gradient.  The pre-gate rows travel as `data["_nqa_pregate"]`; NODE_FEATURES_KEY is not valid in between.
+    defer_gate: bool = False
+
+    def _gate_deferred(self, h: torch.Tensor) -> bool:
+        if not self.defer_gate or self.resnet or not isinstance(self.equivariant_nonlin, Gate):
+            return False
+        meta = self.equivariant_nonlin._kernel_meta
+        if meta is None or not h.is_cuda or h.dtype != torch.float32 or self.training or traceable():
+            return False
+        return _node_kernels.fusion_enabled() and meta.fusable()
+
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         old_x = data[AtomicDataDict.NODE_FEATURES_KEY]
         data = self.conv(data)
+        if self._gate_deferred(data[AtomicDataDict.NODE_FEATURES_KEY]):
+            data["_nqa_pregate"] = (data[AtomicDataDict.NODE_FEATURES_KEY], self.equivariant_nonlin._kernel_meta)
+            return data
         data[AtomicDataDict.NODE_FEATURES_KEY] = self.equivariant_nonlin(data[AtomicDataDict.NODE_FEATURES_KEY])
         if self.resnet:
             data[AtomicDataDict.NODE_FEATURES_KEY] = old_x + data[AtomicDataDict.NODE_FEATURES_KEY]

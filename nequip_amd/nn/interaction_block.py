@@ -12,6 +12,7 @@ from typing import Dict, Optional, Sequence, Union
 import torch
 
 from ..data import AtomicDataDict
+from ..o3 import _node_kernels
 from ..o3.irreps import Irreps
 from ..o3.modules import FullyConnectedTensorProduct, Linear
 from ..utils.wgrad import differentiable_parameters
@@ -109,6 +110,25 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         )
         self.is_first_layer = is_first_layer
 
+    def _fused_node_stage(self, data, h: torch.Tensor, gate_meta, num_local_nodes: int):
+        """``(x1, sc)`` of this block from the previous layer's pre-gate rows in one launch, or None when the conditions of
+        the fused kernel do not hold (then the caller applies the gate and takes the separate launches)."""
+        norm = self.avg_num_neighbors_norm
+        if (self.sc is None or not h.is_cuda or h.dtype != torch.float32 or traceable() or self.training
+                or not _node_kernels.fusion_enabled() or not norm.norm_shortcut or norm.norm_key in data
+                or self.sc._meta is None or self.linear_1.weight_numel == 0
+                or differentiable_parameters(self.training, self.sc.weight)
+                or differentiable_parameters(self.training, self.linear_1.weight)):
+            return None
+        table = data.get("_nqa_node_attrs_table")
+        if table is None or table.shape[0] > 16:
+            return None
+        types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: h.shape[0]].contiguous()
+        wp1 = self.linear_1.eval_weights(h.device, h.dtype)
+        wps = self.sc.eval_weights_typed(table, h.dtype)
+        return _node_kernels.fused_node_stage(h, types, gate_meta, wp1, self.linear_1._meta, float(norm.norm_scalar), wps,
+                                              self.sc._meta)
+
     def _use_segments(self, x: torch.Tensor, emb: torch.Tensor) -> bool:
         """Channel-segment evaluation: float32 on the GPU, not while tracing (the dispatcher-op form takes any irreps), every
         piece has a structure-specialised kernel and a radial-MLP view."""
@@ -165,9 +185,22 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         if not self.is_first_layer and x.shape[0] != num_local_nodes:
             x = x[:num_local_nodes]
 
+        # The previous layer left its Gate to this block (ConvNetLayer.defer_gate): `x` holds the PRE-gate rows.  Gate,
+        # linear_1 (with 1/sqrt(avg_num_neighbors)) and the typed self-connection then run as ONE launch, their backward
+        # + the gate's backward as one more (o3/_node_kernels.py::fused_node_stage); otherwise the gate is applied here.
+        pregate = data.pop("_nqa_pregate", None)
+        fused = None
+        if pregate is not None:
+            gate_meta = pregate[1]
+            fused = self._fused_node_stage(data, x, gate_meta, num_local_nodes)
+            if fused is None:
+                x = _node_kernels.gate(x, gate_meta)
+
         sc = None
         sc_stream = None
-        if self.sc is not None:
+        if fused is not None:
+            x1, sc = fused
+        elif self.sc is not None:
             node_attrs = data[AtomicDataDict.NODE_ATTRS_KEY]
             if not self.is_first_layer and node_attrs.shape[0] != num_local_nodes:
                 node_attrs = node_attrs[:num_local_nodes]
@@ -189,7 +222,9 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
                     sc = self.sc(x, node_attrs)
 
         norm = self.avg_num_neighbors_norm
-        if norm.norm_shortcut and x.is_cuda and not traceable() and norm.norm_key not in data:
+        if fused is not None:
+            x = x1
+        elif norm.norm_shortcut and x.is_cuda and not traceable() and norm.norm_key not in data:
             # one avg_num_neighbors for all types: 1/sqrt(avg) rides on the linear_1 launch (no separate N x D pass)
             x = self.linear_1(x, scale=norm.norm_scalar)
         else:

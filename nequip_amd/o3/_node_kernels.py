@@ -303,10 +303,43 @@ class GateMeta:
             in_off += mul * d
             out_off += mul * d
             goff += mul
+        # block form (nqa_gate_block, the fused node stage): (out_off, d, mul, val_off, gate_off, act, cst) per output block
+        self.blocks = []
+        off = 0
+        for (mul, _), (name, cst) in zip(irreps_scalars, act_scalars):
+            if mul > 0:
+                self.blocks.append((off, 1, mul, off, -1, _ACT_IDS[name], float(cst)))
+            off += mul
+        b_in, b_out, b_gate = self.ns + self.ng, self.ns, self.ns
+        for (mul, ir), (name, cst) in zip(irreps_gated, act_gates):
+            if mul > 0:
+                self.blocks.append((b_out, ir.dim, mul, b_in, b_gate, _ACT_IDS[name], float(cst)))
+            b_in += mul * ir.dim
+            b_out += mul * ir.dim
+            b_gate += mul
+        self._blocks_c = None
         zero = rec.pack(3, 0, 0, 0, 1.0, 0, 0)
         self._fwd = b"".join(r if r is not None else rec.pack(0, -1, 0, 0, 1.0, 0, 0) for r in fwd)
         self._bwd = b"".join(r if r is not None else zero for r in bwd)
         self._dev = {}
+
+    def blocks_c(self):
+        """The blocks as a ctypes array of ``nqa_gate_block`` (host memory, kept alive by this object)."""
+        if self._blocks_c is None:
+            arr = (_lib.GateBlock * max(len(self.blocks), 1))()
+            for k, b in enumerate(self.blocks):
+                arr[k] = _lib.GateBlock(*b)
+            self._blocks_c = arr
+        return self._blocks_c, len(self.blocks)
+
+    def fusable(self) -> bool:
+        """What ``nqa_node_fused`` asks of a gate: gated blocks with d >= 3, everything a multiple of 4."""
+        for out_off, d, mul, val_off, gate_off, act, cst in self.blocks:
+            if gate_off >= 0 and d < 3:
+                return False
+            if (out_off | mul | val_off | max(gate_off, 0)) & 3:
+                return False
+        return (self.din & 3) == 0 and (self.dout & 3) == 0
 
     def device_tables(self, device):
         key = str(device)
@@ -366,3 +399,135 @@ class _GateBwdFn(torch.autograd.Function):
 
 def gate(x, meta: GateMeta):
     return _GateFn.apply(x, meta)
+
+
+# ---- fused node stage (nqa_node_fused): Gate folded into its consumers / into the producers of its gradient -------------
+def fusion_enabled() -> bool:
+    """The fused node stage needs the default fp16-split packing; ``NQA_NO_NODE_FUSION=1`` keeps the separate launches."""
+    return (os.environ.get("NQA_NO_NODE_FUSION", "") in ("", "0") and os.environ.get("NQA_NODE_F16", "") != "0"
+            and not exact_fp32())
+
+
+class FusedPart:
+    """One operand set + destination of a fused launch: ``out = scale * x @ W(meta.fwd tables)`` (+ addend)."""
+
+    def __init__(self, x, wp, meta: NodeLinearMeta, scale: float = 1.0, in_gate: Optional[GateMeta] = None,
+                 accumulate: bool = False, addend=None):
+        self.x, self.wp, self.meta, self.scale = x, wp, meta, float(scale)
+        self.in_gate, self.accumulate, self.addend = in_gate, accumulate, addend
+
+
+def _fill_part(cp, part: FusedPart, out, keep: list):
+    lib_tables = part.meta.host_tables("fwd")
+    ct, nchunks, it, ninstr = lib_tables
+    wf = packed_weights(part.wp, part.meta, "fwd")
+    keep.append(wf)
+    cp.x = part.x.data_ptr()
+    cp.packed = wf.data_ptr()
+    cp.chunk_table = ctypes.cast(ct, ctypes.c_void_p)
+    cp.instr_table = ctypes.cast(it, ctypes.c_void_p)
+    cp.n_chunks, cp.n_instr, cp.n_types = nchunks, ninstr, part.wp.shape[0]
+    cp.dim_in = part.x.shape[1]
+    cp.out = out.data_ptr() if out is not None else None
+    cp.addend = part.addend.data_ptr() if part.addend is not None else None
+    cp.dim_out = out.shape[1] if out is not None else 0
+    cp.accumulate = 1 if part.accumulate else 0
+    cp.scale = part.scale
+    if part.in_gate is not None:
+        arr, n = part.in_gate.blocks_c()
+        cp.in_gate = ctypes.cast(arr, ctypes.c_void_p)
+        cp.n_in_gate = n
+    else:
+        cp.in_gate = None
+        cp.n_in_gate = 0
+
+
+def launch_fused(parts: Sequence[FusedPart], types, out_gate: Optional[GateMeta] = None, gate_h=None) -> List[torch.Tensor]:
+    """``nqa_node_fused``: returns the destination tensors (one per non-accumulating part).  With ``out_gate`` the single
+    destination is the gradient w.r.t. the gate's input rows ``gate_h``."""
+    lib = _lib.load()
+    x0 = parts[0].x
+    N, dev = x0.shape[0], x0.device
+    keep: list = []
+    cparts = (_lib.NodePart * len(parts))()
+    outs = []
+    nbytes = 0
+    flops = 0.0
+    for k, part in enumerate(parts):
+        assert part.x.dtype == torch.float32 and part.x.is_contiguous() and part.x.shape[0] == N
+        if part.accumulate:
+            out = None
+        else:
+            dout = out_gate.din if out_gate is not None else part.meta.dout
+            out = torch.empty((N, dout), dtype=torch.float32, device=dev)
+            outs.append(out)
+            nbytes += 4 * N * dout
+        if k == 0 or part.x.data_ptr() != parts[0].x.data_ptr():
+            nbytes += 4 * N * part.x.shape[1]
+        chunks, instr = part.meta.fwd
+        flops += 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(i[1] for i in instr[c[4]:c[5]]) for c in chunks)
+        _fill_part(cparts[k], part, out, keep)
+    if out_gate is not None:
+        arr, n = out_gate.blocks_c()
+        og, nog, gh, gdim = ctypes.cast(arr, ctypes.c_void_p), n, gate_h.data_ptr(), out_gate.din
+        nbytes += 4 * N * out_gate.din
+    else:
+        og, nog, gh, gdim = None, 0, None, 0
+    tp = _ptr(types) if types is not None else ctypes.c_void_p()
+    with torch.cuda.device(dev), ktimer.region("node_fused", nbytes, flops):
+        rc = lib.nqa_node_fused(ctypes.cast(cparts, ctypes.c_void_p), len(parts), tp, N, og, nog, gh, gdim, _stream(dev))
+    _lib.check(rc, "nqa_node_fused")
+    return outs
+
+
+def _scaled(wp: torch.Tensor, scale: float) -> torch.Tensor:
+    """``wp * scale`` as a constant riding on ``wp`` (eval mode: folded once per weight version)."""
+    if scale == 1.0:
+        return wp
+    cached = getattr(wp, "_nqa_scaled", None)
+    if cached is None or cached[0] != (wp._version, scale):
+        cached = ((wp._version, scale), (wp * scale).contiguous())
+        wp._nqa_scaled = cached
+    return cached[1]
+
+
+class _FusedNodeStageFn(torch.autograd.Function):
+    """``(h, types) -> (x1, sc)`` with ``x = Gate(h)`` (or ``x = h`` without a gate), ``x1 = scale * linear_1(x)``,
+    ``sc = self_connection(x, types)`` -- one launch; backward ``(g_x1, g_sc) -> g_h`` one launch (constant weights)."""
+
+    @staticmethod
+    def forward(ctx, h, types, gate_meta, wp1, meta1, scale1, wps, metas):
+        h = h.contiguous()
+        parts = [FusedPart(h, wp1, meta1, scale1, in_gate=gate_meta)]
+        if wps is not None:
+            parts.append(FusedPart(h, wps, metas, 1.0, in_gate=gate_meta))
+        outs = launch_fused(parts, types if wps is not None and wps.shape[0] > 1 else None)
+        ctx.save_for_backward(h, types, wp1, wps)
+        ctx.gate_meta, ctx.meta1, ctx.metas, ctx.scale1 = gate_meta, meta1, metas, scale1
+        return (outs[0], outs[1]) if wps is not None else (outs[0], None)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g1, gs):
+        h, types, wp1, wps = ctx.saved_tensors
+        gate_meta, meta1, metas = ctx.gate_meta, ctx.meta1, ctx.metas
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 8
+        N = h.shape[0]
+        if g1 is None:
+            g1 = torch.zeros((N, meta1.dout), dtype=h.dtype, device=h.device)
+        parts = [FusedPart(g1.contiguous(), _scaled(meta_transposed_weights(meta1, wp1), ctx.scale1), _transposed(meta1))]
+        if wps is not None and gs is not None:
+            parts.append(FusedPart(gs.contiguous(), meta_transposed_weights(metas, wps), _transposed(metas), accumulate=True))
+        typed = len(parts) > 1 and wps.shape[0] > 1
+        if gate_meta is not None:
+            (gh,) = launch_fused(parts, types if typed else None, out_gate=gate_meta, gate_h=h)
+        else:
+            (gh,) = launch_fused(parts, types if typed else None)
+        return gh, None, None, None, None, None, None, None
+
+
+def fused_node_stage(h, types, gate_meta: Optional[GateMeta], wp1, meta1: NodeLinearMeta, scale1: float, wps=None,
+                     metas: Optional[NodeLinearMeta] = None):
+    """``x1, sc = scale1 * linear_1(Gate(h)), sc(Gate(h), types)`` (``sc`` None without self-connection weights)."""
+    return _FusedNodeStageFn.apply(h, types, gate_meta, wp1, meta1, scale1, wps, metas)

@@ -55,6 +55,7 @@ REGIONS = {
     "radial_mlp_bwd": ([lambda k: re.search(r"radial_mlp_bwd\w*_kernel", k) is not None],
                        [plain("radial_mlp_transpose_w1_kernel", "radial_mlp_split_w1_bwd_kernel")]),
     "node_linear": ([plain("node_linear_kernel", "node_linear_mfma_kernel", "node_linear_")], []),
+    "node_fused": ([plain("node_fused_kernel")], []),
     "gate": ([plain("gate_fwd_kernel", "gate_bwd_kernel")], []),
     "edge_embed_fwd": ([plain("edge_embed_fwd_kernel")], []),
     "edge_embed_bwd": ([plain("edge_embed_bwd_kernel")], []),

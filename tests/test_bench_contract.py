@@ -34,7 +34,8 @@ def test_bench_line_on_a_small_box(device):
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     # every hand-written kernel family of the path ran (no region missing = nothing fell off the HIP path)
     ran = set(d["kernels_ms_per_step"])
-    assert {"tp_fwd", "radial_mlp_fwd", "radial_mlp_bwd", "node_linear", "gate", "edge_embed_fwd", "edge_embed_bwd"} <= ran
+    assert {"tp_fwd", "radial_mlp_fwd", "radial_mlp_bwd", "node_linear", "node_fused", "edge_embed_fwd",
+            "edge_embed_bwd"} <= ran  # (node_fused: Gate + linear_1 + self-connection of a layer boundary, one launch)
     assert ran & {"tp_bwd_fused", "tp_bwd_edge"}
 
 
@@ -59,7 +60,7 @@ def test_bench_line_traffic_is_measured_for_the_dominant_kernel(device):
     assert rf["frac_traffic"] is not None and 0 < rf["frac_traffic"] < 1.0
     regions = dict(rf["other_kernels"], **{rf["kernel"]: rf})
     for name, k in regions.items():
-        if name.startswith(("tp_", "radial_mlp", "node_linear", "gate")):
+        if name.startswith(("tp_", "radial_mlp", "node_linear", "node_fused", "gate")):
             assert k["traffic"] is not None and k["traffic"] > 0, (name, k)
     for name, k in regions.items():
         if name.startswith("radial_mlp"):  # the MLP is priced on what it executes: 3 products per fp32 product
