@@ -407,6 +407,20 @@ int nqa_node_fused_plan(const nqa_node_part* parts, int32_t n_parts, const nqa_g
                         int32_t* chunks_out, int32_t chunks_cap, int32_t* instr_out, int32_t instr_cap);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-atom energy head in one launch per direction.  After the last convolution the reference runs Gate (scalars only) ->
+ *   ScalarMLP readout of depth 0 (x @ W alpha, nequip/nn/mlp.py:262-268; built at nequip/model/nequip_models.py:371-381)
+ *   -> PerTypeScaleShift (float64 addcmul, nequip/nn/atomwise.py:116-284), and autograd the same chain backwards.
+ *   backward == 0:  out[z] (float64) = shift[type z] + scale[type z] * double( sum_c W[c] cst act(h[z, c]) )
+ *   backward != 0:  out[z, c] (float32) = float(grad_e[z] * scale[type z]) * W[c] * cst act'(h[z, c])
+ *   h [N, dim] float32 (dim a multiple of 4), readout_weight [dim] float32 with alpha folded in, scales / shifts float64 of
+ *   length 0 (absent), 1 (shared) or one per type (atom_types required), act as for nqa_gate (0 identity, 1 silu, 2 tanh).
+ *   The dot product is accumulated in float32 and scaled / shifted in float64, as the reference does.
+ * ------------------------------------------------------------------------------------------- */
+int nqa_energy_head(int32_t backward, const void* h, const void* readout_weight, const void* scales, int32_t n_scales,
+                    const void* shifts, int32_t n_shifts, const int64_t* atom_types, const void* grad_e, void* out,
+                    int32_t dim, int32_t act, double cst, int64_t num_nodes, nqa_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Paired radial weights.  InteractionBlock.edge_mlp (nequip/nn/interaction_block.py:119-127,190-192) is a function of
  *   the edge length alone, and a neighbour list holds every interaction as (i <- j, S) and (j <- i, -S): the reference
  *   evaluates the MLP twice per pair.  nqa_edge_pairs finds the pairs of a list:

@@ -205,6 +205,11 @@ SIGNATURES = {
         c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p],
     ),
     "nqa_node_fused_plan": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, _P32, c_int32, _P32, c_int32]),
+    "nqa_energy_head": (
+        c_int32,
+        [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+         c_double, c_int64, c_void_p],
+    ),
     "nqa_neighbor_list_workspace_bytes": (c_int64, [c_int64]),
     "nqa_neighbor_list_count": (
         c_int32,

@@ -29,7 +29,7 @@ GEN_DIR = os.path.join(HERE, "generated")
 SPEC_DIR = os.path.join(HERE, "generated_spec")
 
 SOURCES = ["plan.cpp", "csr.hip", "tp_generic.hip", "edge_embed.hip", "edge_vectors.hip", "radial_mlp.hip", "node_ops.hip",
-           "neighbor_list.hip", "wgrad.hip", "edge_pairs.hip"]
+           "neighbor_list.hip", "wgrad.hip", "edge_pairs.hip", "energy_head.hip"]
 ARCH = "gfx950"
 
 

@@ -226,6 +226,11 @@ def _full_nequip_energy_model(
     )
     modules["per_atom_energy_readout"] = per_atom_energy_readout
     modules["per_type_energy_scale_shift"] = per_type_energy_scale_shift
+    # eval mode on the GPU: the last layer's Gate, the readout and the scale / shift run as one launch per direction
+    # (nn/_energy_head.py).  The link is a plain list entry: no second registration of the module, no new state-dict keys.
+    if readout_mlp_hidden_layers_depth == 0:
+        per_atom_energy_readout.__dict__["_scale_shift"] = [per_type_energy_scale_shift]
+        modules[f"layer{num_layers - 1}_convnet"].defer_gate = True
     # nequip/model/energy_modules.py: total energy = sum of per-atom energies per frame
     modules["total_energy_sum"] = AtomwiseReduce(
         irreps_in=per_type_energy_scale_shift.irreps_out,

@@ -68,6 +68,12 @@ class PerTypeScaleShift(GraphModuleMixin, torch.nn.Module):
         self.shifts_shortcut = self.shifts.numel() == 1
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        if data.pop("_nqa_energy_scaled", False):
+            # the fused energy head (nn/_energy_head.py) has produced `field` in float64 with this module's scales and
+            # shifts applied
+            if self.out_field != self.field:
+                data[self.out_field] = data[self.field]
+            return data
         if not (self.has_scales or self.has_shifts):
             data[self.out_field] = data[self.field].to(self.out_dtype)
             return data

@@ -410,6 +410,43 @@ class ScalarMLP(GraphModuleMixin, torch.nn.Module):
         )
         self.irreps_out[self.out_field] = Irreps([(self.mlp_module.dims[-1], (0, 1))])
 
+    def _energy_head(self, data, h: torch.Tensor, gate_meta):
+        """Gate (scalars only) + this depth-0 readout + the following PerTypeScaleShift as one launch (nn/_energy_head.py);
+        None when the shapes / modes do not fit (the caller then applies the gate and the modules run one by one)."""
+        tail = self.__dict__.get("_scale_shift")
+        fn = self.mlp_module
+        if (tail is None or fn.num_layers != 1 or fn.has_bias or fn.dims[-1] != 1 or not h.is_cuda or h.dtype != torch.float32
+                or self.training or traceable() or h.shape[1] % 4 != 0 or len(gate_meta.blocks) != 1
+                or gate_meta.blocks[0][4] >= 0 or os.environ.get("NQA_NO_ENERGY_HEAD", "") not in ("", "0")
+                or differentiable_parameters(self.training, fn.mlp[0].weight)):
+            return None
+        ss = tail[0]
+        if ss.field != self.out_field or ss.out_field != self.out_field:
+            return None
+        lin = fn.mlp[0]
+        key = (lin.weight._version, lin.weight.data_ptr(), h.device)
+        cached = self.__dict__.get("_head_w")
+        if cached is None or cached[0] != key:
+            cached = (key, (lin.weight.detach().view(-1) * lin.alpha_value).to(torch.float32).contiguous())
+            self.__dict__["_head_w"] = cached
+        types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: h.shape[0]].contiguous()
+        _, _, _, _, _, act, cst = gate_meta.blocks[0]
+        from ._energy_head import energy_head
+
+        return energy_head(h, cached[1], ss.scales.view(-1) if ss.has_scales else None,
+                           ss.shifts.view(-1) if ss.has_shifts else None, types, act, cst)
+
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
+        pregate = data.pop("_nqa_pregate", None)
+        if pregate is not None:  # the last convolution layer left its Gate to this module (ConvNetLayer.defer_gate)
+            h, gate_meta = pregate
+            e = self._energy_head(data, h, gate_meta)
+            if e is not None:
+                data[self.out_field] = e
+                data["_nqa_energy_scaled"] = True  # PerTypeScaleShift has been applied (it passes the field on)
+                return data
+            from ..o3 import _node_kernels
+
+            data[self.field] = _node_kernels.gate(h, gate_meta)
         data[self.out_field] = self.mlp_module(data[self.field])
         return data

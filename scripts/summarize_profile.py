@@ -56,6 +56,7 @@ REGIONS = {
                        [plain("radial_mlp_transpose_w1_kernel", "radial_mlp_split_w1_bwd_kernel")]),
     "node_linear": ([plain("node_linear_kernel", "node_linear_mfma_kernel", "node_linear_")], []),
     "node_fused": ([plain("node_fused_kernel")], []),
+    "energy_head": ([plain("energy_head_fwd_kernel", "energy_head_bwd_kernel")], []),
     "gate": ([plain("gate_fwd_kernel", "gate_bwd_kernel")], []),
     "edge_embed_fwd": ([plain("edge_embed_fwd_kernel")], []),
     "edge_embed_bwd": ([plain("edge_embed_bwd_kernel")], []),

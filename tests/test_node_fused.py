@@ -263,3 +263,67 @@ def test_model_takes_the_fused_path_in_eval_mode(device, monkeypatch):
     fs = max(1.0, float(ref["forces"].abs().max()))
     torch.testing.assert_close(out["total_energy"], ref["total_energy"], atol=2e-5 * len(pos), rtol=2e-6)
     torch.testing.assert_close(out["forces"], ref["forces"], atol=3e-6 * fs, rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_types,per_type", [(1, False), (3, True), (2, False)])
+def test_energy_head_matches_the_module_chain(device, n_types, per_type):
+    """``nqa_energy_head`` against Gate(scalars) -> ScalarMLP(depth 0) -> PerTypeScaleShift as the modules compute them
+    (float32 readout, float64 scale / shift), values and the gradient w.r.t. the pre-gate scalars."""
+    from nequip_amd.nn._energy_head import energy_head
+
+    torch.manual_seed(3)
+    n, d = 1001, 64
+    h = (torch.randn(n, d) * 2.0).to(device).requires_grad_(True)
+    w = (torch.rand(d, 1) * 2 * 3 ** 0.5 - 3 ** 0.5).to(device)
+    alpha = 1.0 / d ** 0.5
+    types = torch.randint(0, n_types, (n,), device=device)
+    scales = (torch.rand(n_types if per_type else 1, dtype=torch.float64) + 0.5).to(device)
+    shifts = torch.randn(n_types if per_type else 1, dtype=torch.float64).to(device)
+    cst = 1.6791767923989418
+    e = energy_head(h, (w.view(-1) * alpha).contiguous(), scales, shifts, types, 1, cst)
+    assert e.dtype == torch.float64 and e.shape == (n, 1)
+    (g,) = torch.autograd.grad(e.sum(), h)
+    h2 = h.detach().clone().requires_grad_(True)
+    x = cst * SILU(h2)
+    e32 = torch.mm(x, w * alpha)
+    sc = scales[types].view(-1, 1) if per_type else scales.view(1, 1)
+    sh = shifts[types].view(-1, 1) if per_type else shifts.view(1, 1)
+    ref = torch.addcmul(sh, sc, e32.to(torch.float64))
+    (g2,) = torch.autograd.grad(ref.sum(), h2)
+    torch.testing.assert_close(e, ref, atol=2e-6 * float(ref.abs().max()), rtol=0)
+    torch.testing.assert_close(g, g2, atol=2e-6 * float(g2.abs().max()), rtol=0)
+    # a weighted sum as the loss (a non-trivial incoming gradient), scales only
+    c = torch.randn(n, 1, dtype=torch.float64, device=device)
+    e = energy_head(h, (w.view(-1) * alpha).contiguous(), scales, None, types, 1, cst)
+    (g,) = torch.autograd.grad((e * c).sum(), h)
+    ref = sc * torch.mm(cst * SILU(h2), w * alpha).to(torch.float64)
+    (g2,) = torch.autograd.grad((ref * c).sum(), h2)
+    torch.testing.assert_close(g, g2, atol=2e-6 * float(g2.abs().max()), rtol=0)
+
+
+@pytest.mark.gpu
+def test_model_runs_the_energy_head_and_matches_the_module_chain(device, monkeypatch):
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn import _energy_head
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=4)
+    data = AtomicDataDict.to_device(syn.make_data(pos, types, 4.5, cell), device)
+    model = NequIPGNNModel(seed=0, model_dtype="float32", r_max=4.5, type_names=names, num_layers=2, l_max=1, parity=False,
+                           num_features=32, radial_mlp_depth=1, radial_mlp_width=64, avg_num_neighbors=38.0,
+                           per_type_energy_scales={"H": 1.3, "O": 0.7}, per_type_energy_shifts={"H": -1.0, "O": 2.0}
+                           ).to(device).eval()
+    calls = []
+    real = _energy_head._launch
+    monkeypatch.setattr(_energy_head, "_launch", lambda b, *a: (calls.append(b), real(b, *a))[1])
+    out = model(dict(data))
+    assert calls == [0, 1]
+    monkeypatch.setenv("NQA_NO_ENERGY_HEAD", "1")
+    calls.clear()
+    ref = model(dict(data))
+    assert calls == []
+    torch.testing.assert_close(out["atomic_energy"], ref["atomic_energy"], atol=1e-5, rtol=1e-6)
+    torch.testing.assert_close(out["total_energy"], ref["total_energy"], atol=1e-5 * len(pos), rtol=1e-6)
+    torch.testing.assert_close(out["forces"], ref["forces"], atol=3e-6 * max(1.0, float(ref["forces"].abs().max())), rtol=0)
