@@ -301,6 +301,24 @@ int nqa_radial_mlp_fwd_tangent(int32_t dtype, int32_t mode, const void* edge_emb
                                int32_t hidden, int32_t out_features, int64_t num_edges, void* out, void* workspace,
                                int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream);
 
+/* The last layer of a DEEPER radial MLP (ScalarMLPFunction with hidden_layers_depth >= 2, nequip/nn/mlp.py:81-196; the
+ *   reference's tutorial model uses depth 2 / width 64, configs/tutorial.yaml:222-223) on the same GEMM cores:
+ *     nqa_radial_mlp_last_fwd:  out [E, out_features] = silu(pre) @ (w alpha)
+ *     nqa_radial_mlp_last_bwd:  grad_pre [E, hidden]  = ((grad_out (+ grad_out2)) @ (w alpha)^T) * silu'(pre)
+ *   `pre` [E, hidden] are the PRE-activations of the layer's input -- for depth 2 the output of nqa_radial_mlp_fwd on the
+ *   first two weight matrices (out_features = hidden width), whose gradient nqa_radial_mlp_bwd then takes on to the edge
+ *   embedding; deeper stacks chain nqa_radial_mlp_last_fwd.  hidden 64 or 128, out_features % 4 == 0, float32, mode
+ *   NQA_MLP_F16X3 (fp32-accurate two-plane fp16 split; workspaces as for nqa_radial_mlp_fwd / _bwd in that mode).
+ *   Inference (first order) only: training-mode deep MLPs stay on the ATen formulation. */
+int nqa_radial_mlp_last_fwd(int32_t dtype, int32_t mode, const void* pre, const void* w, double alpha, int32_t hidden,
+                            int32_t out_features, int64_t num_edges, void* out, void* workspace, int64_t workspace_bytes,
+                            int32_t workspace_ready, nqa_stream stream);
+int nqa_radial_mlp_last_bwd(int32_t dtype, int32_t mode, const void* pre, const void* w, double alpha,
+                            const void* grad_out, const void* grad_out2, int32_t hidden, int32_t out_features,
+                            int64_t num_edges, void* grad_pre, void* workspace, int64_t workspace_bytes,
+                            int32_t workspace_ready, nqa_stream stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * Node-side channel mixing in one launch: replaces e3nn o3.Linear (linear_1 / linear_2,
  *   nequip/nn/interaction_block.py:82-87,129-138,177,201), the self-connection

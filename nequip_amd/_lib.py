@@ -205,6 +205,16 @@ SIGNATURES = {
         c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p],
     ),
     "nqa_node_fused_plan": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, _P32, c_int32, _P32, c_int32]),
+    "nqa_radial_mlp_last_fwd": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_void_p, c_double, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+         c_void_p],
+    ),
+    "nqa_radial_mlp_last_bwd": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p,
+         c_int64, c_int32, c_void_p],
+    ),
     "nqa_energy_head": (
         c_int32,
         [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,

@@ -804,7 +804,10 @@ __global__ __launch_bounds__(NW * 64, 2) void radial_mlp_fwd_bf16x6_kernel(const
 // k-steps of unit i) runs straight across block boundaries; the next block's embedding row is requested one tile early.
 // F16: the second GEMM on the two-plane fp16 split (three products per k-step, weight tiles of 16 KiB, tile_scale from
 // the prepass) instead of the three-plane bf16 split (six products, 24 KiB tiles).
-template <int H, bool F16>
+// XIN: the last layer of a deeper MLP (nqa_radial_mlp_last_fwd): `emb` holds the PRE-activations [E, H] of the layer's
+// input (written by the previous fused launch); the hidden rows are silu(pre), loaded in the accumulator layout of the
+// K = num_basis MFMA they replace (four float4 per 32-channel block and lane).  W0 / a0 / nb are unused.
+template <int H, bool F16, bool XIN = false>
 __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const float* __restrict__ emb,
                                                                        const float* __restrict__ W0,
                                                                        const u32x4* __restrict__ Wf, float a0, int nb,
@@ -834,6 +837,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
   if (u0 >= u1) return;  // (workgroup-uniform)
 
   auto load_ev = [&](int64_t blk, float (&ev)[kMaxNb]) __attribute__((always_inline)) {
+    if constexpr (XIN) return;  // (the pre-activation rows are loaded where they are consumed)
     const int64_t row = blk * kMlpRows + wv * 32 + l31;
     const float* __restrict__ er = emb + (row < E ? row : (E - 1)) * nb;
     if (nb == kMaxNb) {
@@ -871,24 +875,42 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
 
   u32x4 bh[KS], bm[F16 ? 1 : KS], bl[KS];
   float row_scale = 1.f;  // F16: inverse of the power of two this lane's row was multiplied by
-  auto hidden = [&](const float (&e)[kMaxNb], bool row_ok) __attribute__((always_inline)) {
+  auto hidden = [&](const float (&e)[kMaxNb], bool row_ok, int64_t hblk) __attribute__((always_inline)) {
     float hv[F16 ? (H / 32) * 16 : 1];
-    float w0v[H / 32][kMaxNb / 2];  // all requests first: one L2 latency per block, not sixteen
+    float w0v[XIN ? 1 : H / 32][kMaxNb / 2];  // all requests first: one L2 latency per block, not sixteen
+    float4 pin[XIN ? H / 32 : 1][4];
+    if constexpr (XIN) {
+      // register r of the 32 x 32 accumulator layout <-> hidden channel 32 kb + (r & 3) + 8 (r >> 2) + 4 half of edge row l31
+      const int64_t row = hblk * kMlpRows + wv * 32 + l31;
+      const float* __restrict__ pr = emb + (row < E ? row : (E - 1)) * H + 4 * half;
 #pragma unroll
-    for (int kb = 0; kb < H / 32; ++kb)
+      for (int kb = 0; kb < H / 32; ++kb)
 #pragma unroll
-      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
-        const int c = 2 * s2 + half;
-        w0v[kb][s2] = W0[(c < nb ? c : 0) * H + kb * 32 + l31];
-      }
+        for (int g = 0; g < 4; ++g) pin[kb][g] = *reinterpret_cast<const float4*>(pr + kb * 32 + 8 * g);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < H / 32; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+          const int c = 2 * s2 + half;
+          w0v[kb][s2] = W0[(c < nb ? c : 0) * H + kb * 32 + l31];
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < H / 32; ++kb) {
       f32x16 hacc = {0};
+      if constexpr (XIN) {
 #pragma unroll
-      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
-        const float av = (2 * s2 + half) < nb ? w0v[kb][s2] * a0 : 0.f;
-        const float bv = half ? e[2 * s2 + 1] : e[2 * s2];
-        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          hacc[4 * g] = pin[kb][g].x; hacc[4 * g + 1] = pin[kb][g].y; hacc[4 * g + 2] = pin[kb][g].z; hacc[4 * g + 3] = pin[kb][g].w;
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+          const float av = (2 * s2 + half) < nb ? w0v[kb][s2] * a0 : 0.f;
+          const float bv = half ? e[2 * s2 + 1] : e[2 * s2];
+          hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, hacc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -925,7 +947,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
       }
     }
   };
-  hidden(ev, blk * kMlpRows + wv * 32 + l31 < E);
+  hidden(ev, blk * kMlpRows + wv * 32 + l31 < E, blk);
 
   float* __restrict__ tb = tbuf + wv * (32 * kTS);
   // bf16: pa + pb (large + small partial products).  F16: (pa + pb) * rs * tile_scale with rs the row scale of the unit
@@ -972,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
       ++blk;
 #pragma unroll
       for (int c = 0; c < kMaxNb; ++c) ev[c] = evn[c];
-      hidden(ev, blk * kMlpRows + wv * 32 + l31 < E);
+      hidden(ev, blk * kMlpRows + wv * 32 + l31 < E, blk);
     }
     const int buf = (int)(i & 1);
     if (left > 1) stage_store(buf ^ 1);
@@ -1051,7 +1073,9 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
 // new scale -- whenever a chunk's largest magnitude would leave fp16's range.  S is set three bits below the limit, so
 // later chunks up to 8x larger pass without a rescale.  Both factors are powers of two: exact.  The error of a product
 // is 2^-22 of the row's (running) maximum x the chunk's weight maximum, the rounding level of the fp32 sum itself.
-template <int H, int TM, bool PAIR = false, bool F16 = false>
+// XIN (nqa_radial_mlp_last_bwd, TM = 0): the last layer of a deeper MLP -- `emb` holds the pre-activations P [E, H] of the
+// layer's input, the result is grad_P = (g W^T) silu'(P) written to `g_emb` as [E, H]; no first-layer GEMV.
+template <int H, int TM, bool PAIR = false, bool F16 = false, bool XIN = false>
 __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(const float* __restrict__ emb,
                                                                     const float* __restrict__ W0,
                                                                     const u32x4* __restrict__ Wb,
@@ -1091,17 +1115,19 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(const floa
   const int64_t myrow = blk0 + wv * 32 + l31;
   const bool row_ok = myrow < E;
 
-  for (int i = tid; i < H * kMaxNb; i += 256) {
-    const int k = i / kMaxNb, c = i - k * kMaxNb;
-    const float v = c < nb ? W0[c * H + k] * a0 : 0.f;
-    w0s[i] = v;
-    w0t[c * H + k] = v;
-  }
-  for (int i = tid; i < kMlpRows * kMaxNb; i += 256) {
-    const int r = i / kMaxNb, c = i - r * kMaxNb;
-    const int64_t rr = blk0 + r < E ? blk0 + r : E - 1;  // clamped, unpredicated load; masked below
-    const float v = emb[rr * nb + (c < nb ? c : nb - 1)];
-    es[i] = (c < nb && blk0 + r < E) ? v : 0.f;
+  if constexpr (!XIN) {
+    for (int i = tid; i < H * kMaxNb; i += 256) {
+      const int k = i / kMaxNb, c = i - k * kMaxNb;
+      const float v = c < nb ? W0[c * H + k] * a0 : 0.f;
+      w0s[i] = v;
+      w0t[c * H + k] = v;
+    }
+    for (int i = tid; i < kMlpRows * kMaxNb; i += 256) {
+      const int r = i / kMaxNb, c = i - r * kMaxNb;
+      const int64_t rr = blk0 + r < E ? blk0 + r : E - 1;  // clamped, unpredicated load; masked below
+      const float v = emb[rr * nb + (c < nb ? c : nb - 1)];
+      es[i] = (c < nb && blk0 + r < E) ? v : 0.f;
+    }
   }
   float cvr[kMaxNb];
   if (TM == 2) {
@@ -1301,6 +1327,27 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(const floa
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = ldexpf(acc[t][r], -sr[r]);
+  }
+  if constexpr (XIN) {
+    // grad_P[row][col] = G_h[row][col] silu'(P[row][col]) straight from the accumulator layout: register r of tile t is
+    // (row = 32 wv + (r & 3) + 8 (r >> 2) + 4 half, col = 32 t + l31) -- 128-byte runs per (row, half)
+    static_assert(!XIN || TM == 0, "XIN is an inference backward");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = t * 32 + l31;
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = blk0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        pv[r] = emb[(row < E ? row : (E - 1)) * H + col];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = blk0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < E) g_emb[row * H + col] = acc[t][r] * silu_grad_f(pv[r]);
+      }
+    }
+    return;
   }
   // epilogue (exact fp32): pre-activations recomputed on MFMA in the accumulator layout, g_pre = g_h * silu'(pre),
   // one pass through LDS for the NB-wide GEMV -- identical to the fp32 kernel
@@ -1764,6 +1811,96 @@ int nqa_radial_mlp_bwd_paired(int32_t dtype, int32_t mode, const void* edge_embe
   return mlp_bwd_impl(dtype, mode, 0, edge_embedding, nullptr, nullptr, nullptr, w0, alpha0, w1, alpha1,
                       grad_edge_weight, grad_edge_weight2, num_basis, hidden, out_features, num_edges,
                       grad_edge_embedding, workspace, workspace_bytes, workspace_ready, stream);
+}
+
+// ---- the last layer of a deeper MLP on the same GEMM cores (depth >= 2: nequip/nn/mlp.py:81-196 with
+// hidden_layers_depth >= 2, e.g. configs/tutorial.yaml:222-223) -------------------------------------------------------
+int nqa_radial_mlp_last_fwd(int32_t dtype, int32_t mode, const void* pre, const void* w, double alpha, int32_t hidden,
+                            int32_t out_features, int64_t num_edges, void* out, void* workspace, int64_t workspace_bytes,
+                            int32_t workspace_ready, nqa_stream stream) {
+  if (dtype != NQA_F32 || mode != NQA_MLP_F16X3) {
+    set_error("nqa_radial_mlp_last_fwd: float32 on the two-plane fp16 split (NQA_MLP_F16X3) only");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (num_edges < 0 || (hidden != 64 && hidden != 128) || out_features <= 0 || out_features % 4 != 0 ||
+      (num_edges > 0 && (!pre || !w || !out))) {
+    set_error("nqa_radial_mlp_last_fwd: invalid argument (hidden 64 / 128, out_features % 4 == 0)");
+    return hidden != 64 && hidden != 128 ? NQA_ERR_UNSUPPORTED : NQA_ERR_INVALID;
+  }
+  if (num_edges == 0) return NQA_OK;
+  const int64_t need = nqa_radial_mlp_workspace_bytes(mode, 0, hidden, out_features);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("nqa_radial_mlp_last_fwd: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static const int num_cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const unsigned grid = (unsigned)((num_edges + kMlpRows - 1) / kMlpRows);
+  const int ntiles = (out_features + 31) / 32;
+  u32x4* wf = static_cast<u32x4*>(workspace);
+  float* ts = reinterpret_cast<float*>(static_cast<char*>(workspace) + (int64_t)ntiles * (hidden / 16) * 2 * 1024);
+  if (!workspace_ready)
+    hipLaunchKernelGGL(radial_mlp_split_w1_fwd_f16_kernel, dim3((unsigned)ntiles), dim3(256), 0, s,
+                       static_cast<const float*>(w), (float)alpha, hidden, out_features, wf, ts);
+  const int64_t units = (int64_t)grid * ntiles;
+  const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
+  const float* p = static_cast<const float*>(pre);
+  float* o = static_cast<float*>(out);
+  if (hidden == 128)
+    hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<128, true, true>), dim3(gb), dim3(256), 0, s, p, nullptr, wf, 1.f,
+                       0, out_features, num_edges, o, ts);
+  else
+    hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<64, true, true>), dim3(gb), dim3(256), 0, s, p, nullptr, wf, 1.f, 0,
+                       out_features, num_edges, o, ts);
+  return launch_status("nqa_radial_mlp_last_fwd");
+}
+
+int nqa_radial_mlp_last_bwd(int32_t dtype, int32_t mode, const void* pre, const void* w, double alpha,
+                            const void* grad_out, const void* grad_out2, int32_t hidden, int32_t out_features,
+                            int64_t num_edges, void* grad_pre, void* workspace, int64_t workspace_bytes,
+                            int32_t workspace_ready, nqa_stream stream) {
+  if (dtype != NQA_F32 || mode != NQA_MLP_F16X3) {
+    set_error("nqa_radial_mlp_last_bwd: float32 on the two-plane fp16 split (NQA_MLP_F16X3) only");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (num_edges < 0 || (hidden != 64 && hidden != 128) || out_features <= 0 || out_features % 4 != 0 ||
+      (num_edges > 0 && (!pre || !w || !grad_out || !grad_pre))) {
+    set_error("nqa_radial_mlp_last_bwd: invalid argument (hidden 64 / 128, out_features % 4 == 0)");
+    return hidden != 64 && hidden != 128 ? NQA_ERR_UNSUPPORTED : NQA_ERR_INVALID;
+  }
+  if (num_edges == 0) return NQA_OK;
+  if (workspace == nullptr || workspace_bytes < nqa_radial_mlp_workspace_bytes(mode, 1, hidden, out_features)) {
+    set_error("nqa_radial_mlp_last_bwd: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)((num_edges + kMlpRows - 1) / kMlpRows);
+  const int nchunks = (out_features + 31) / 32;
+  u32x4* wb = static_cast<u32x4*>(workspace);
+  int* ce = reinterpret_cast<int*>(static_cast<char*>(workspace) + (int64_t)nchunks * 2 * 2 * (hidden / 32) * 1024);
+  if (!workspace_ready)
+    hipLaunchKernelGGL(radial_mlp_split_w1_bwd_f16_kernel, dim3((unsigned)nchunks), dim3(256), 0, s,
+                       static_cast<const float*>(w), (float)alpha, hidden, out_features, wb, ce);
+  const float* p = static_cast<const float*>(pre);
+  const float* g = static_cast<const float*>(grad_out);
+  const float* g2 = static_cast<const float*>(grad_out2);
+  float* o = static_cast<float*>(grad_pre);
+#define NQA_MLP_LAST_BWD(HH, PP)                                                                                        \
+  hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, 0, PP, true, true>), dim3(grid), dim3(256), 0, s, p, nullptr, wb, \
+                     g, 1.f, 0, out_features, num_edges, o, 0, nullptr, nullptr, nullptr, g2, ce)
+  if (hidden == 128) {
+    if (g2 != nullptr) NQA_MLP_LAST_BWD(128, true);
+    else NQA_MLP_LAST_BWD(128, false);
+  } else {
+    if (g2 != nullptr) NQA_MLP_LAST_BWD(64, true);
+    else NQA_MLP_LAST_BWD(64, false);
+  }
+#undef NQA_MLP_LAST_BWD
+  return launch_status("nqa_radial_mlp_last_bwd");
 }
 
 int64_t nqa_radial_mlp_train_tiles(int64_t num_edges) {

@@ -196,6 +196,53 @@ class _RadialMLPFn(torch.autograd.Function):
         return g_emb, None, None, None, None, None, None
 
 
+def _launch_last(pre, w, alpha: float, cache: _WeightImages, g=None):
+    """The last layer of a deeper MLP on the fused kernels' GEMM cores: ``silu(pre) @ (w alpha)`` (``g is None``,
+    ``nqa_radial_mlp_last_fwd``) or ``(g @ (w alpha)^T) * silu'(pre)`` (``nqa_radial_mlp_last_bwd``)."""
+    from ._topology import _ptr, current_stream_ptr
+
+    lib = _lib.load()
+    E, H = pre.shape
+    W = w.shape[1]
+    mode = _lib.NQA_MLP_F16X3
+    backward = 0 if g is None else 1
+    ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, backward, H, W)
+    ws, ready = cache.get(w, mode, backward, ws_bytes)
+    flops = 2.0 * E * H * W
+    if g is None:
+        out = torch.empty((E, W), dtype=pre.dtype, device=pre.device)
+        with torch.cuda.device(pre.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (H + W), flops):
+            rc = lib.nqa_radial_mlp_last_fwd(_lib.NQA_F32, mode, _ptr(pre), _ptr(w), alpha, H, W, E, _ptr(out), _ptr(ws),
+                                             ws_bytes, int(ready), current_stream_ptr(pre.device))
+        _lib.check(rc, "nqa_radial_mlp_last_fwd")
+        return out
+    out = torch.empty_like(pre)
+    with torch.cuda.device(pre.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * H + W), flops):
+        rc = lib.nqa_radial_mlp_last_bwd(_lib.NQA_F32, mode, _ptr(pre), _ptr(w), alpha, _ptr(g), None, H, W, E, _ptr(out),
+                                         _ptr(ws), ws_bytes, int(ready), current_stream_ptr(pre.device))
+    _lib.check(rc, "nqa_radial_mlp_last_bwd")
+    return out
+
+
+class _RadialMLPLastFn(torch.autograd.Function):
+    """``pre -> silu(pre) @ (w alpha)``: one more layer on top of the fused two-layer kernel (depth >= 2 MLPs, inference:
+    differentiable w.r.t. ``pre`` only)."""
+
+    @staticmethod
+    def forward(ctx, pre, w, alpha: float, cache: _WeightImages):
+        pre = pre.contiguous()
+        out = _launch_last(pre, w, alpha, cache)
+        ctx.save_for_backward(pre, w)
+        ctx.alpha, ctx.cache = alpha, cache
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        pre, w = ctx.saved_tensors
+        return _launch_last(pre, w, ctx.alpha, ctx.cache, g=g.contiguous()), None, None, None
+
+
 def _silu_derivs(p):
     """silu'(p), silu''(p)."""
     sig = torch.sigmoid(p)
@@ -364,7 +411,40 @@ class ScalarMLPFunction(_WeightCacheMixin, torch.nn.Module):
             self._alphas = (self.mlp[0].alpha_value, self.mlp[2].alpha_value)
         return ok
 
+    def _deep_ok(self, x: torch.Tensor) -> bool:
+        """Depth >= 2 (three or more weight matrices, e.g. the tutorial's 8-64-64-W): the first two layers on the fused
+        two-layer kernel (its output = the pre-activations of the second hidden layer), every further layer on
+        ``nqa_radial_mlp_last_fwd / _bwd``.  Inference, float32, no bias, hidden widths 64 / 128, fp16-split modes."""
+        if (not x.is_cuda or x.dtype != torch.float32 or self.num_layers < 3 or not self.is_nonlinear or self.has_bias
+                or traceable() or os.environ.get("NQA_MLP_DEEP_ATEN", "") not in ("", "0")):
+            return False
+        ok = getattr(self, "_deep_supported", None)
+        if ok is None:
+            lib = _lib.load()
+            ok = (all(h in (64, 128) for h in self.dims[1:-1]) and self.dims[-1] % 4 == 0
+                  and bool(lib.nqa_radial_mlp_supported(_lib.NQA_F32, self.dims[0], self.dims[1], self.dims[2])))
+            self._deep_supported = ok
+            self._deep_alphas = [self.mlp[2 * k].alpha_value for k in range(self.num_layers)]
+        mode = radial_mlp_mode()
+        return (ok and forward_mode(mode) == _lib.NQA_MLP_F16X3 and backward_mode(mode) == _lib.NQA_MLP_F16X3
+                and not differentiable_parameters(self.training, *[self.mlp[2 * k].weight for k in range(self.num_layers)]))
+
+    def _forward_deep(self, x):
+        caches = self.__dict__.get("_deep_images")
+        if caches is None:
+            caches = self.__dict__["_deep_images"] = [_WeightImages() for _ in range(self.num_layers)]
+        ws = [self.mlp[2 * k].weight for k in range(self.num_layers)]
+        for k in range(1, self.num_layers):
+            caches[k].validate(ws[k])
+        al = self._deep_alphas
+        pre = _RadialMLPFn.apply(x, ws[0].detach(), ws[1].detach(), al[0], al[1], radial_mlp_mode(), caches[1])
+        for k in range(2, self.num_layers):
+            pre = _RadialMLPLastFn.apply(pre, ws[k].detach(), al[k], caches[k])
+        return pre
+
     def forward(self, x):
+        if self._deep_ok(x):
+            return self._forward_deep(x)
         # GPU, float32, two layers of a supported shape: fused MFMA kernels (the hidden layer stays on chip).  Eval mode:
         # weights are constants (inference Function, gradient w.r.t. the embedding only).  Training: the same kernels
         # inside a twice-differentiable Function pair that also produces the parameter gradients.

@@ -188,6 +188,19 @@ def main():
         out[f"{tag}_x"], out[f"{tag}_y"], out[f"{tag}_cot"], out[f"{tag}_gx"] = _np(x), _np(y), _np(cot), _np(grads[0])
         for i, (p, gp_) in enumerate(zip(m.parameters(), grads[1:])):
             out[f"{tag}_w{i}"], out[f"{tag}_gw{i}"] = _np(p), _np(gp_)
+    # round 4: the tutorial's radial MLP shape (configs/tutorial.yaml:222-223: depth 2, width 64) -- own generator, so the
+    # draws of every other fixture stay what they were
+    g2 = torch.Generator().manual_seed(4242)
+    torch.manual_seed(44)
+    m = mlp.ScalarMLPFunction(input_dim=8, output_dim=96, hidden_layers_depth=2, hidden_layers_width=64,
+                              nonlinearity="silu", bias=False)
+    x = (torch.randn(300, 8, generator=g2) * 0.7).requires_grad_(True)
+    y = m(x)
+    cot = torch.randn(y.shape, generator=g2)
+    grads = torch.autograd.grad((y * cot).sum(), [x] + list(m.parameters()))
+    out["d2w_x"], out["d2w_y"], out["d2w_cot"], out["d2w_gx"] = _np(x), _np(y), _np(cot), _np(grads[0])
+    for i, (p, gp_) in enumerate(zip(m.parameters(), grads[1:])):
+        out[f"d2w_w{i}"], out[f"d2w_gw{i}"] = _np(p), _np(gp_)
     np.savez_compressed(os.path.join(HERE, "ref_scalar_mlp.npz"), **out)
 
     # ---- a6 + readout helpers ------------------------------------------------------------------------------------

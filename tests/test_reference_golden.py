@@ -58,7 +58,7 @@ def test_oracle_radial_basis_matches_reference():
 
 def test_oracle_scalar_mlp_matches_reference():
     f = _load("ref_scalar_mlp.npz")
-    for tag, nw in (("d1", 2), ("d2", 3), ("d0", 1)):
+    for tag, nw in (("d1", 2), ("d2", 3), ("d0", 1), ("d2w", 3)):
         ws = [f[f"{tag}_w{i}"].clone().requires_grad_(True) for i in range(nw)]
         x = f[tag + "_x"].clone().requires_grad_(True)
         y = onn.scalar_mlp(x, ws, "silu")
@@ -103,7 +103,7 @@ def test_host_modules_match_reference():
     _close(d4[K.TOTAL_ENERGY_KEY], f["e_total"], 1e-13)
 
     m = _load("ref_scalar_mlp.npz")
-    for tag, (width, depth, dout) in {"d1": (64, 1, 96), "d2": (32, 2, 40), "d0": (None, 0, 24)}.items():
+    for tag, (width, depth, dout) in {"d1": (64, 1, 96), "d2": (32, 2, 40), "d0": (None, 0, 24), "d2w": (64, 2, 96)}.items():
         mlp = ScalarMLPFunction(8, dout, depth, width)
         params = list(mlp.parameters())
         with torch.no_grad():
@@ -212,12 +212,62 @@ def test_edge_embed_kernel_matches_reference(device, name, dtype, tol):
     _close(gv.cpu(), f["gvec_" + name], tol * 10)
 
 
+def _set_mlp_mode(monkeypatch, mode):
+    """f16x3: the default (two-plane fp16 split in both directions); bf16x6: the three-plane bf16 split; fp32: exact MFMA."""
+    monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if mode == "fp32" else "0")
+    for var in ("NQA_MLP_FWD_F16", "NQA_MLP_BWD_F16"):
+        if mode == "bf16x6":
+            monkeypatch.setenv(var, "0")
+        else:
+            monkeypatch.delenv(var, raising=False)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+def test_deep_radial_mlp_kernels_match_reference(device, monkeypatch):
+    """The reference's tutorial radial MLP (depth 2, width 64: configs/tutorial.yaml:222-223) through the HIP path --
+    ``nqa_radial_mlp_fwd`` (first two layers) + ``nqa_radial_mlp_last_fwd``, backward ``nqa_radial_mlp_last_bwd`` +
+    ``nqa_radial_mlp_bwd`` -- against outputs and input gradients of the reference's own ``ScalarMLPFunction``."""
+    from nequip_amd.nn import mlp as M
+
+    _set_mlp_mode(monkeypatch, "f16x3")
+    m = _load("ref_scalar_mlp.npz")
+    mlp = M.ScalarMLPFunction(8, 96, 2, 64)
+    with torch.no_grad():
+        for i, p in enumerate(mlp.parameters()):
+            p.copy_(m[f"d2w_w{i}"])
+    mlp = mlp.to(device).eval()
+    x = m["d2w_x"].to(device).requires_grad_(True)
+    assert mlp._deep_ok(x), "depth 2 / width 64 must run on the fused kernels"
+    calls = []
+    real = M._launch_last
+    monkeypatch.setattr(M, "_launch_last", lambda *a, **k: (calls.append(k.get("g") is not None), real(*a, **k))[1])
+    y = mlp(x)
+    _close(y.detach().cpu(), m["d2w_y"], 5e-6)
+    (gx,) = torch.autograd.grad((y * m["d2w_cot"].to(device)).sum(), [x])
+    _close(gx.cpu(), m["d2w_gx"], 1e-5)
+    assert calls == [False, True]
+    # ragged row counts, width 128, a third hidden layer: against the ATen formulation of the same module
+    for depth, width, dout, rows in ((2, 128, 320, 1), (3, 64, 36, 131), (2, 64, 704, 1000)):
+        torch.manual_seed(depth * 100 + width)
+        net = M.ScalarMLPFunction(8, dout, depth, width).to(device).eval()
+        xx = (torch.randn(rows, 8, device=device) * 0.7).requires_grad_(True)
+        assert net._deep_ok(xx)
+        yy = net(xx)
+        cot = torch.randn_like(yy)
+        (g1,) = torch.autograd.grad((yy * cot).sum(), [xx])
+        x2 = xx.detach().clone().requires_grad_(True)
+        ref = net.mlp(x2)
+        (g2,) = torch.autograd.grad((ref * cot).sum(), [x2])
+        assert float((yy - ref).abs().max()) <= 5e-6 * max(1.0, float(ref.abs().max()))
+        assert float((g1 - g2).abs().max()) <= 1e-5 * max(1.0, float(g2.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "fp32"])
 def test_radial_mlp_kernel_matches_reference(device, mode, monkeypatch):
     from nequip_amd.nn.mlp import ScalarMLPFunction
 
-    monkeypatch.setenv("NQA_MLP_EXACT_FP32", "1" if mode == "fp32" else "0")
+    _set_mlp_mode(monkeypatch, mode)
     m = _load("ref_scalar_mlp.npz")
     mlp = ScalarMLPFunction(8, 96, 1, 64)
     with torch.no_grad():
