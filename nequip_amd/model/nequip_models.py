@@ -138,6 +138,7 @@ def _full_nequip_energy_model(
     readout_mlp_nonlinearity: Optional[str] = "silu",
     num_bessels: int = 8,
     bessel_trainable: bool = False,
+    per_edge_type_cutoff: Optional[Dict[str, Union[float, Dict[str, float]]]] = None,
     polynomial_cutoff_p: int = 6,
     avg_num_neighbors: Optional[Union[float, Dict[str, float]]] = None,
     per_type_energy_scales: Optional[Union[float, Dict[str, float]]] = None,
@@ -156,7 +157,8 @@ def _full_nequip_energy_model(
 
     type_embed = NodeTypeEmbed(type_names=type_names, num_features=type_embed_num_features)
     spharm = SphericalHarmonicEdgeAttrs(irreps_edge_sh=irreps_edge_sh, irreps_in=type_embed.irreps_out)
-    edge_norm = EdgeLengthNormalizer(r_max=r_max, type_names=type_names, irreps_in=spharm.irreps_out)
+    edge_norm = EdgeLengthNormalizer(r_max=r_max, type_names=type_names, per_edge_type_cutoff=per_edge_type_cutoff,
+                                     irreps_in=spharm.irreps_out)
     bessel_encode = BesselEdgeLengthEncoding(
         num_bessels=num_bessels,
         trainable=bessel_trainable,
@@ -198,6 +200,9 @@ def _full_nequip_energy_model(
         )
         prev_irreps_out = current_convnet.irreps_out
         modules[f"layer{layer_i}_convnet"] = current_convnet
+        if not edge_norm.symmetric:
+            # cutoff(A <- B) != cutoff(B <- A): the two directed edges of a pair no longer share their radial weights
+            current_convnet.conv.paired_radial_ok = False
         if layer_i > 0:
             # the previous layer's Gate is consumed by this layer's linear_1 / self-connection only: it may be folded into
             # them (eval mode, GPU; nn/convnetlayer.py::defer_gate)

@@ -58,7 +58,7 @@ class _EdgeEmbedFn(torch.autograd.Function):
         nbytes = E * (24 + out_dtype.itemsize * (((lmax + 1) ** 2 if cfg["want_sh"] else 0) + (cfg["nb"] if cfg["want_emb"] else 0)))
         with torch.cuda.device(vec.device), ktimer.region("edge_embed_fwd", nbytes):
             rc = lib.nqa_edge_embed_fwd(
-                _dt(out_dtype), max(lmax, 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(), cfg["nb"],
+                _dt(out_dtype), max(lmax, 0), _ptr(vec), E, cfg["rmax_recip"], _ptr(cfg.get("rmax_edge")), cfg["nb"],
                 _ptr(bessel_weights), cfg["p"], cfg["factor"], _ptr(sh), _ptr(emb), ctypes.c_void_p(),
                 current_stream_ptr(vec.device),
             )  # fmt: skip
@@ -91,7 +91,7 @@ class _EdgeEmbedBwdFn(torch.autograd.Function):
         nbytes = E * (48 + cfg["dtype"].itemsize * (((cfg["lmax"] + 1) ** 2 if g_sh is not None else 0) + (cfg["nb"] if g_emb is not None else 0)))
         with torch.cuda.device(vec.device), ktimer.region("edge_embed_bwd", nbytes):
             rc = lib.nqa_edge_embed_bwd(
-                _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
+                _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], _ptr(cfg.get("rmax_edge")),
                 cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(g_vec),
                 current_stream_ptr(vec.device),
             )  # fmt: skip
@@ -121,7 +121,7 @@ def _edge_embed_second_order(vec, bw, g_sh, g_emb, c, cfg, need_vec: bool, need_
     gg_emb = torch.empty_like(g_emb) if (g_emb is not None and need_gemb) else None
     with torch.cuda.device(vec.device):
         rc = lib.nqa_edge_embed_bwd_bwd(
-            _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], ctypes.c_void_p(),
+            _dt(cfg["dtype"]), max(cfg["lmax"], 0), _ptr(vec), E, cfg["rmax_recip"], _ptr(cfg.get("rmax_edge")),
             cfg["nb"], _ptr(bw), cfg["p"], cfg["factor"], _ptr(g_sh), _ptr(g_emb), _ptr(c), _ptr(gg_sh),
             _ptr(gg_emb), _ptr(g_vec2), current_stream_ptr(vec.device),
         )  # fmt: skip
@@ -129,24 +129,58 @@ def _edge_embed_second_order(vec, bw, g_sh, g_emb, c, cfg, need_vec: bool, need_
     return g_vec2, gg_sh, gg_emb
 
 
+def cutoff_partialdict_to_tensor(partial_dict: Dict, type_names: List[str], r_max: float) -> torch.Tensor:
+    """``{"H": 2.0, "C": {"H": 4.0}}`` -> ``[num_types, num_types]`` float64 cutoffs, rows = centre type, missing entries =
+    ``r_max`` (semantics of ``nequip/nn/embedding/utils.py:16-85``)."""
+    rows = []
+    for centre in type_names:
+        entry = partial_dict.get(centre, None)
+        if entry is None:
+            rows.append([float(r_max)] * len(type_names))
+        elif isinstance(entry, (int, float)):
+            rows.append([float(entry)] * len(type_names))
+        else:
+            rows.append([float(entry.get(other, r_max)) for other in type_names])
+    return torch.as_tensor(rows, dtype=_GLOBAL_DTYPE).contiguous()
+
+
 class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):
-    """Holds ``1/r_max``; the product ``r * (1/r_max)`` itself is formed inside the fused radial kernel
-    (``nequip/nn/embedding/_edge.py:65-80``).  Per-edge-type cutoffs are not wired yet."""
+    """Holds ``1/r_max`` -- one number, or one per (centre type, neighbour type) with ``per_edge_type_cutoff``
+    (``nequip/nn/embedding/_edge.py:19-80``); the product ``r * (1/r_max)`` itself is formed inside the fused radial kernel,
+    which takes the per-edge reciprocal cutoffs as an ``[E]`` float64 operand (``rmax_recip_edge`` of ``nqa_edge_embed_*``)."""
 
     def __init__(self, r_max: float, type_names: List[str], per_edge_type_cutoff: Optional[Dict] = None,
+                 edge_type_field: str = AtomicDataDict.EDGE_TYPE_KEY,
                  norm_length_field: str = AtomicDataDict.NORM_LENGTH_KEY, irreps_in=None):
         super().__init__()
-        if per_edge_type_cutoff is not None:
-            raise NotImplementedError("per_edge_type_cutoff is outside the benchmarked path (SURVEY.md 8)")
         self.r_max = float(r_max)
         self.num_types = len(type_names)
+        self.edge_type_field = edge_type_field
         self.norm_length_field = norm_length_field
-        self.register_buffer("_rmax_recip", torch.as_tensor(1.0 / self.r_max, dtype=_GLOBAL_DTYPE))
-        self._init_irreps(irreps_in=irreps_in, irreps_out={self.norm_length_field: Irreps("1x0e")})
+        self._per_edge_type = per_edge_type_cutoff is not None
+        if self._per_edge_type:
+            table = cutoff_partialdict_to_tensor(per_edge_type_cutoff, list(type_names), self.r_max)
+            assert float(table.max()) <= self.r_max + 1e-12, "per-edge-type cutoffs cannot exceed r_max"
+            rmax_recip = table.reciprocal().view(-1)  # row-major (centre type, neighbour type)
+            self.symmetric = bool(torch.equal(table, table.t()))
+        else:
+            rmax_recip = torch.as_tensor(1.0 / self.r_max, dtype=_GLOBAL_DTYPE)
+            self.symmetric = True
+        self.register_buffer("_rmax_recip", rmax_recip)
+        irreps_out = {self.norm_length_field: Irreps("1x0e")}
+        if self._per_edge_type:
+            irreps_out[self.edge_type_field] = None
+        self._init_irreps(irreps_in=irreps_in, irreps_out=irreps_out)
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         data = with_edge_vectors_(data, with_lengths=False)
         data["_nqa_rmax_recip"] = 1.0 / self.r_max
+        if self._per_edge_type:
+            if self.edge_type_field not in data:  # with_edge_type_ (nequip/nn/utils.py:121-133)
+                data[self.edge_type_field] = torch.index_select(
+                    data[AtomicDataDict.ATOM_TYPE_KEY].view(-1), 0, data[AtomicDataDict.EDGE_INDEX_KEY].view(-1)).view(2, -1)
+            et = data[self.edge_type_field]
+            data["_nqa_rmax_recip_edge"] = torch.index_select(self._rmax_recip, 0, et[0] * self.num_types + et[1])
         return data
 
 
@@ -162,12 +196,13 @@ class BesselEdgeLengthEncoding(GraphModuleMixin, torch.nn.Module):
         self.cutoff = cutoff
         self.num_bessels = num_bessels
         self.trainable = trainable
-        if trainable:
-            raise NotImplementedError("trainable Bessel roots are outside the benchmarked path")
         self.edge_invariant_field = edge_invariant_field
         self.norm_length_field = norm_length_field
         bessel_weights = torch.linspace(1.0, num_bessels, num_bessels, dtype=_GLOBAL_DTYPE).unsqueeze(0)
-        self.register_buffer("bessel_weights", bessel_weights)
+        if trainable:  # (nequip/nn/embedding/_edge.py:117-120)
+            self.bessel_weights = torch.nn.Parameter(bessel_weights)
+        else:
+            self.register_buffer("bessel_weights", bessel_weights)
         self.factor = 1.0
         self._init_irreps(
             irreps_in=irreps_in,
@@ -175,11 +210,35 @@ class BesselEdgeLengthEncoding(GraphModuleMixin, torch.nn.Module):
         )
         self._output_dtype = torch.get_default_dtype()
 
+    def _forward_differentiable_weights(self, data, vec, rmax_edge):
+        """Trainable Bessel roots WHILE they are being trained: the reference's ATen formulation (_edge.py:136-150,
+        cutoffs.py:17-27), which autograd differentiates w.r.t. the roots to any order (force-matching training).  With
+        constant roots -- eval mode, or ``trainable=False`` -- the fused kernel evaluates the same expression."""
+        r = torch.linalg.norm(vec, dim=-1, keepdim=True)
+        x = r * (rmax_edge.view(-1, 1) if rmax_edge is not None else float(data["_nqa_rmax_recip"]))
+        bessel = (torch.sinc(x * self.bessel_weights) * self.bessel_weights).to(self._output_dtype)
+        p = float(self.cutoff.p)
+        cut = 1.0 - ((p + 1.0) * (p + 2.0) / 2.0) * torch.pow(x, p) + p * (p + 2.0) * torch.pow(x, p + 1.0) \
+            - (p * (p + 1.0) / 2) * torch.pow(x, p + 2.0)
+        cut = (cut * (x < 1.0)).to(self._output_dtype)
+        emb = bessel * cut
+        return emb * self.factor if self.factor != 1.0 else emb
+
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         data = with_edge_vectors_(data, with_lengths=False)
+        vec = data[AtomicDataDict.EDGE_VECTORS_KEY]
+        rmax_edge = data.get("_nqa_rmax_recip_edge")
+        if self.trainable and self.bessel_weights.requires_grad and torch.is_grad_enabled() and self.training:
+            data[self.edge_invariant_field] = self._forward_differentiable_weights(data, vec, rmax_edge)
+            return data
+        if rmax_edge is not None and traceable():
+            raise NotImplementedError("per-edge-type cutoffs are not part of the dispatcher-op (compile) form of the edge "
+                                      "embedding: evaluate this model eagerly")
         cfg = dict(dtype=self._output_dtype, lmax=0, want_sh=False, want_emb=True, nb=self.num_bessels,
                    rmax_recip=float(data["_nqa_rmax_recip"]), p=float(self.cutoff.p), factor=float(self.factor))
-        data[self.edge_invariant_field] = _embed(data[AtomicDataDict.EDGE_VECTORS_KEY], self.bessel_weights.view(-1), cfg)
+        if rmax_edge is not None:
+            cfg["rmax_edge"] = rmax_edge.contiguous()
+        data[self.edge_invariant_field] = _embed(vec, self.bessel_weights.detach().view(-1), cfg)
         return data
 
 

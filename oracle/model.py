@@ -94,8 +94,13 @@ def energy_model(data, cfg, weights, specs=None):
     else:
         vec = onn.edge_vectors(pos, edge_index, data.get("cell"), data.get("edge_cell_shift"), batch)
     edge_attrs = onn.sh_edge_attrs(vec, cfg["l_max"], dt)
+    pt = cfg.get("per_edge_type_cutoff_table")  # [T, T] float64, rows = centre type (EdgeLengthNormalizer, _edge.py:27-52)
+    bw = weights.get("bessel_encode.bessel_weights")  # trained roots (bessel_trainable), else the buffer 1..num_bessels
     edge_emb, _ = onn.bessel_embedding(
-        vec, r_max, cfg.get("num_bessels", 8), cfg.get("polynomial_cutoff_p", 6), dt
+        vec, r_max, cfg.get("num_bessels", 8), cfg.get("polynomial_cutoff_p", 6), dt,
+        bessel_weights=None if bw is None else bw.to(vec.dtype).view(1, -1),
+        per_edge_type_cutoff=None if pt is None else torch.as_tensor(pt, dtype=vec.dtype),
+        edge_types=None if pt is None else torch.stack([types[edge_index[0]], types[edge_index[1]]]),
     )
     norm = torch.tensor(1.0 / math.sqrt(cfg["avg_num_neighbors"]), dtype=dt)  # nequip/nn/norm.py:39
     acts_norm = cfg.get("convnet_nonlinearity_scalars", {"e": "silu"})["e"]

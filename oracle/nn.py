@@ -37,10 +37,17 @@ def polynomial_cutoff(x, p=6.0):
     return out * (x < 1.0)
 
 
-def bessel_embedding(edge_vec, r_max, num_bessels=8, p=6.0, model_dtype=torch.float32, bessel_weights=None):
-    """EdgeLengthNormalizer -> BesselEdgeLengthEncoding (x PolynomialCutoff) -> ApplyFactor(2 pi / r_max^2)."""
+def bessel_embedding(edge_vec, r_max, num_bessels=8, p=6.0, model_dtype=torch.float32, bessel_weights=None,
+                     per_edge_type_cutoff=None, edge_types=None):
+    """EdgeLengthNormalizer -> BesselEdgeLengthEncoding (x PolynomialCutoff) -> ApplyFactor(2 pi / r_max^2).
+    ``per_edge_type_cutoff`` [T, T] (rows = centre type) with ``edge_types`` [2, E]: _edge.py:71-78."""
     r = edge_vec.square().sum(1, keepdim=True).sqrt()  # utils.py:117
-    x = r * torch.as_tensor(1.0 / r_max, dtype=edge_vec.dtype)  # _edge.py:79
+    if per_edge_type_cutoff is not None:
+        T = per_edge_type_cutoff.shape[0]
+        recip = per_edge_type_cutoff.reciprocal().view(-1)  # _edge.py:52
+        x = r * torch.index_select(recip, 0, edge_types[0] * T + edge_types[1]).unsqueeze(-1)  # :74-79
+    else:
+        x = r * torch.as_tensor(1.0 / r_max, dtype=edge_vec.dtype)  # _edge.py:79
     if bessel_weights is None:
         bessel_weights = torch.linspace(1.0, num_bessels, num_bessels, dtype=edge_vec.dtype).unsqueeze(0)
     bessel = (torch.sinc(x * bessel_weights) * bessel_weights).to(model_dtype)  # _edge.py:140-142

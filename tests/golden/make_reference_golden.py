@@ -173,6 +173,29 @@ def main():
                     f"gvec_{dt_name}": _np(gv)})
     torch.set_default_dtype(torch.float32)
     out.update(vec=_np(vec), r_max=np.float64(r_max), bessel_weights=_np(bessel.bessel_weights))
+    # round 4: per-edge-type cutoffs (_edge.py:27-52,71-78) and trained Bessel roots (_edge.py:117-120) -- own generator, the
+    # draws of every other fixture stay what they were
+    g3 = torch.Generator().manual_seed(777)
+    pt_cut = {"A": 3.0, "B": {"A": 4.0, "B": 2.5}}
+    types = torch.randint(0, 2, (40,), generator=g3)
+    ei = torch.randint(0, 40, (2, 96), generator=g3)
+    cot3 = torch.randn(96, 8, generator=g3, dtype=torch.float64)
+    for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dt)
+        normalizer = _edge.EdgeLengthNormalizer(r_max=r_max, type_names=["A", "B"], per_edge_type_cutoff=pt_cut)
+        bessel = _edge.BesselEdgeLengthEncoding(cutoff=cutoffs.PolynomialCutoff(6), num_bessels=8, trainable=True)
+        with torch.no_grad():
+            bessel.bessel_weights.mul_(1.0 + 0.03 * torch.randn(1, 8, generator=torch.Generator().manual_seed(5), dtype=torch.float64))
+        v = vec.clone().requires_grad_(True)
+        data = {K.EDGE_VECTORS_KEY: v, K.ATOM_TYPE_KEY: types, K.EDGE_INDEX_KEY: ei}
+        data = bessel(normalizer(data))
+        emb = data[K.EDGE_EMBEDDING_KEY]
+        gv, gw = torch.autograd.grad((emb * cot3.to(emb.dtype)).sum(), [v, bessel.bessel_weights])
+        out.update({f"pt_emb_{dt_name}": _np(emb), f"pt_gvec_{dt_name}": _np(gv), f"pt_gw_{dt_name}": _np(gw),
+                    f"pt_normed_{dt_name}": _np(data["normed_edge_lengths"])})
+    torch.set_default_dtype(torch.float32)
+    out.update(pt_types=_np(types), pt_edge_index=_np(ei), pt_cot=_np(cot3), pt_bessel_weights=_np(bessel.bessel_weights),
+               pt_cutoffs=np.array([[3.0, 3.0], [4.0, 2.5]]))
     np.savez_compressed(os.path.join(HERE, "ref_radial_basis.npz"), **out)
 
     # ---- a4: ScalarMLPFunction as the radial MLP ---------------------------------------------------------------

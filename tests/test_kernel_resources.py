@@ -31,19 +31,27 @@ def _find(kernels, *needles):
 def test_radial_mlp_kernels_fit_their_occupancy_targets():
     ks = kr.kernels_of(_objects("radial_mlp.o")[0])
     # inference defaults (two-plane fp16 split): two workgroups of four wavefronts per CU, nothing spilled
-    fwd = _find(ks, "radial_mlp_fwd_split_bal_kernel<128, true>")         # 224 VGPRs, 51 200 B
-    bwd = _find(ks, "radial_mlp_bwd_split_kernel<128, 0, false, true>")   # 188 VGPRs, 78 848 B
+    fwd = _find(ks, "radial_mlp_fwd_split_bal_kernel<128, true, false>")         # 224 VGPRs, 51 200 B
+    bwd = _find(ks, "radial_mlp_bwd_split_kernel<128, 0, false, true, false>")   # 188 VGPRs, 78 848 B
     for r in (fwd, bwd):
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0
         assert kr.waves_per_simd(r["vgpr"]) >= 2 and 2 * r["lds"] <= 160 * 1024
     assert fwd["vgpr"] <= 232 and bwd["vgpr"] <= 200
     # the fp16 split must not cost registers against the bf16 split it replaces
-    assert fwd["vgpr"] <= _find(ks, "radial_mlp_fwd_split_bal_kernel<128, false>")["vgpr"]
-    assert bwd["vgpr"] <= _find(ks, "radial_mlp_bwd_split_kernel<128, 0, false, false>")["vgpr"]
+    assert fwd["vgpr"] <= _find(ks, "radial_mlp_fwd_split_bal_kernel<128, false, false>")["vgpr"]
+    assert bwd["vgpr"] <= _find(ks, "radial_mlp_bwd_split_kernel<128, 0, false, false, false>")["vgpr"]
     # training epilogues on the same main loop
     for tm in (1, 2):
-        r = _find(ks, f"radial_mlp_bwd_split_kernel<128, {tm}, false, true>")  # 192 / 200 VGPRs
+        r = _find(ks, f"radial_mlp_bwd_split_kernel<128, {tm}, false, true, false>")  # 192 / 200 VGPRs
         assert r["vgpr_spill"] == 0 and kr.waves_per_simd(r["vgpr"]) >= 2
+
+
+    # round 4: the last-layer variants of deeper MLPs (pre-activations as input) stay within the same budgets
+    for needle in ("radial_mlp_fwd_split_bal_kernel<128, true, true>", "radial_mlp_fwd_split_bal_kernel<64, true, true>",
+                   "radial_mlp_bwd_split_kernel<128, 0, false, true, true>", "radial_mlp_bwd_split_kernel<64, 0, false, true, true>",
+                   "radial_mlp_bwd_split_kernel<64, 0, true, true, true>"):
+        r = _find(ks, needle)
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and kr.waves_per_simd(r["vgpr"]) >= 2
 
 
 def test_node_kernels_keep_three_or_four_wavefronts_per_simd():
@@ -58,6 +66,9 @@ def test_node_kernels_keep_three_or_four_wavefronts_per_simd():
     assert 4 * f16["lds"] <= 160 * 1024  # LDS does not cap the occupancy below the register limit
     for name in ("gate_fwd_kernel<float>", "gate_bwd_kernel<float>"):
         assert _find(ks, name)["vgpr_spill"] == 0
+    fused = _find(ks, "node_fused_kernel")  # 162 VGPRs, 4 x (8320 + 1536) B: the fused layer-boundary stage
+    assert fused["vgpr_spill"] == 0 and fused["scratch"] == 0 and kr.waves_per_simd(fused["vgpr"]) >= 3
+    assert 3 * fused["lds"] <= 160 * 1024
 
 
 def test_cfg3_tensor_product_kernels():

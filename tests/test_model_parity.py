@@ -109,6 +109,34 @@ def test_batched_molecules_no_cell(device):
     torch.testing.assert_close(ref["forces"], out["forces"].cpu(), atol=5e-5 * max(1.0, fscale), rtol=5e-5)
 
 
+@pytest.mark.gpu
+def test_per_edge_type_cutoffs_and_trained_bessel_roots(device):
+    """``per_edge_type_cutoff`` (asymmetric: reverse-edge pairing off) and perturbed Bessel roots as a trained
+    ``bessel_trainable`` model has them (nequip/nn/embedding/_edge.py:27-52,117-120), eval mode, against the oracle."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn.embedding import cutoff_partialdict_to_tensor
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=4, seed=6)
+    data = syn.make_data(pos, types, 4.5, cell)
+    pt = {"H": 3.2, "O": {"H": 4.0, "O": 4.5}}
+    cfg = _cfg(num_features=16, radial_mlp_width=64, avg_num_neighbors=38.0)
+    model = NequIPGNNModel(seed=2, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2, parity=False,
+                           num_features=16, radial_mlp_depth=1, radial_mlp_width=64, avg_num_neighbors=38.0,
+                           per_edge_type_cutoff=pt, bessel_trainable=True)
+    with torch.no_grad():
+        model.model.func.bessel_encode.bessel_weights.mul_(1.0 + 0.02 * torch.randn(1, 8, dtype=torch.float64))
+    model = model.to(device).eval()
+    out = model(AtomicDataDict.to_device(data, device))
+    cfg["per_edge_type_cutoff_table"] = cutoff_partialdict_to_tensor(pt, list(names), 4.5)
+    ref = omodel.energy_forces(data, cfg, _weights(model), with_virial=True)
+    fscale = float(ref["forces"].abs().max())
+    torch.testing.assert_close(ref["total_energy"], out["total_energy"].cpu(), atol=5e-5 * len(pos), rtol=5e-5)
+    torch.testing.assert_close(ref["forces"], out["forces"].cpu(), atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+    assert float((ref["forces"] - out["forces"].cpu()).abs().max()) < 1e-4 * max(1.0, fscale)
+
+
 # ---- the BASELINE.json model shapes themselves (the kernels bench.py times: 64 / 128 features, radial MLP 8-128-W) ----
 def _baseline_case(device, data, names, cfg, what):
     """Energy within 5e-5 per atom abs/rel, forces within 1e-4 eV/A *absolute* (BASELINE.json north_star) and 5e-5

@@ -56,6 +56,53 @@ def test_oracle_radial_basis_matches_reference():
     torch.testing.assert_close(f["bessel_weights"].view(-1).double(), torch.linspace(1.0, 8.0, 8, dtype=torch.float64))
 
 
+def _pt_case(f):
+    types, ei = f["pt_types"].long(), f["pt_edge_index"].long()
+    return types, ei, torch.stack([types[ei[0]], types[ei[1]]])
+
+
+def test_per_edge_type_cutoff_and_trained_bessel_roots_match_reference():
+    """Fixtures made by the reference's EdgeLengthNormalizer(per_edge_type_cutoff=...) + BesselEdgeLengthEncoding(
+    trainable=True) with perturbed roots: the oracle, and the host modules' training-mode (ATen) evaluation incl. the
+    gradient w.r.t. the roots (CPU)."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.nn.embedding import BesselEdgeLengthEncoding, EdgeLengthNormalizer, PolynomialCutoff
+
+    f = _load("ref_radial_basis.npz")
+    r_max = float(f["r_max"])
+    factor = 2 * math.pi / (r_max * r_max)
+    types, ei, et = _pt_case(f)
+    for name, dt, tol in (("f64", torch.float64, 1e-13), ("f32", torch.float32, 2e-6)):
+        v = f["vec"].clone().requires_grad_(True)
+        w = f["pt_bessel_weights"].clone().requires_grad_(True)
+        emb, _ = onn.bessel_embedding(v, r_max, 8, 6.0, dt, bessel_weights=w, per_edge_type_cutoff=f["pt_cutoffs"],
+                                      edge_types=et)
+        _close(emb.detach() / factor, f["pt_emb_" + name], tol)
+        gv, gw = torch.autograd.grad((emb / factor * f["pt_cot"].to(dt)).sum(), [v, w])
+        _close(gv, f["pt_gvec_" + name], tol * 10)
+        _close(gw, f["pt_gw_" + name], tol * 100)
+        # host modules, training mode (differentiable roots -> the ATen formulation)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dt)
+        try:
+            norm = EdgeLengthNormalizer(r_max=r_max, type_names=["A", "B"], per_edge_type_cutoff={"A": 3.0, "B": {"A": 4.0, "B": 2.5}})
+            enc = BesselEdgeLengthEncoding(cutoff=PolynomialCutoff(6), num_bessels=8, trainable=True).train()
+        finally:
+            torch.set_default_dtype(old)
+        assert not norm.symmetric and isinstance(enc.bessel_weights, torch.nn.Parameter)
+        with torch.no_grad():
+            enc.bessel_weights.copy_(f["pt_bessel_weights"])
+        v2 = f["vec"].clone().requires_grad_(True)
+        data = enc(norm({K.EDGE_VECTORS_KEY: v2, K.ATOM_TYPE_KEY: types, K.EDGE_INDEX_KEY: ei}))
+        torch.testing.assert_close(data["_nqa_rmax_recip_edge"] * v2.detach().norm(dim=1), f["pt_normed_f64"].view(-1),
+                                   atol=1e-13, rtol=1e-13)
+        e2 = data[K.EDGE_EMBEDDING_KEY]
+        _close(e2.detach(), f["pt_emb_" + name], tol)
+        gv2, gw2 = torch.autograd.grad((e2 * f["pt_cot"].to(dt)).sum(), [v2, enc.bessel_weights])
+        _close(gv2, f["pt_gvec_" + name], tol * 10)
+        _close(gw2, f["pt_gw_" + name], tol * 100)
+
+
 def test_oracle_scalar_mlp_matches_reference():
     f = _load("ref_scalar_mlp.npz")
     for tag, nw in (("d1", 2), ("d2", 3), ("d0", 1), ("d2w", 3)):
@@ -210,6 +257,35 @@ def test_edge_embed_kernel_matches_reference(device, name, dtype, tol):
     assert (emb[0] == 0).all() and (emb[1] == 0).all()
     (gv,) = torch.autograd.grad((emb * f["cot_" + name].to(device)).sum(), [v])
     _close(gv.cpu(), f["gvec_" + name], tol * 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 2e-6)])
+def test_edge_embed_kernel_per_edge_type_cutoff_and_trained_roots(device, name, dtype, tol):
+    """The HIP kernel with an [E] operand of reciprocal cutoffs and non-integer Bessel roots (eval mode of a model trained
+    with ``bessel_trainable``) against the reference-generated fixture: embedding and its VJP."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.nn.embedding import BesselEdgeLengthEncoding, EdgeLengthNormalizer, PolynomialCutoff
+
+    f = _load("ref_radial_basis.npz")
+    types, ei, _ = _pt_case(f)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        norm = EdgeLengthNormalizer(r_max=float(f["r_max"]), type_names=["A", "B"],
+                                    per_edge_type_cutoff={"A": 3.0, "B": {"A": 4.0, "B": 2.5}})
+        enc = BesselEdgeLengthEncoding(cutoff=PolynomialCutoff(6), num_bessels=8, trainable=True)
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        enc.bessel_weights.copy_(f["pt_bessel_weights"])
+    norm, enc = norm.to(device).eval(), enc.to(device).eval()
+    v = f["vec"].to(device).requires_grad_(True)
+    data = enc(norm({K.EDGE_VECTORS_KEY: v, K.ATOM_TYPE_KEY: types.to(device), K.EDGE_INDEX_KEY: ei.to(device)}))
+    emb = data[K.EDGE_EMBEDDING_KEY]
+    _close(emb.detach().cpu(), f["pt_emb_" + name], tol)
+    (gv,) = torch.autograd.grad((emb * f["pt_cot"].to(device=device, dtype=dtype)).sum(), [v])
+    _close(gv.cpu(), f["pt_gvec_" + name], tol * 10)
 
 
 def _set_mlp_mode(monkeypatch, mode):
