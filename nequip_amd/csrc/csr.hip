@@ -8,7 +8,8 @@
 // (ascending original edge id inside a node), which makes the floating point summation order -- and
 // therefore the result -- independent of scheduling.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstdint>
 #include <string>
@@ -69,9 +70,8 @@ static int end_bit_for(int64_t N) {
 
 static size_t cub_temp_bytes(int64_t E, int end_bit) {
   size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                     (const int32_t*)nullptr, (int32_t*)nullptr, (int)E, 0, end_bit,
-                                     (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
+                                  (int32_t*)nullptr, (unsigned int)E, 0u, (unsigned int)end_bit, (hipStream_t)0);
   return bytes;
 }
 
@@ -129,8 +129,9 @@ int nqa_csr_build(const int64_t* key, const int64_t* other, int64_t num_nodes, i
   const unsigned gridE = (unsigned)((num_edges + 255) / 256);
   hipLaunchKernelGGL(csr_prepare_kernel, dim3(gridE), dim3(256), 0, s, key, num_edges, num_nodes, key_in, val_in,
                      status_flag);
-  hipError_t err = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, (const int32_t*)key_in, key_out,
-                                                      (const int32_t*)val_in, edge_id, (int)num_edges, 0, eb, s);
+  // rocPRIM's device radix sort (stable; only the low `eb` key bits are sorted)
+  hipError_t err = rocprim::radix_sort_pairs(cub_tmp, cub_bytes, (const int32_t*)key_in, key_out, (const int32_t*)val_in,
+                                             edge_id, (unsigned int)num_edges, 0u, (unsigned int)eb, s);
   if (err != hipSuccess) {
     set_error(std::string("nqa_csr_build(sort): ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;

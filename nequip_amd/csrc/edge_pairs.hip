@@ -15,7 +15,8 @@
 // orientation.  Anything else (odd E, a missing reverse edge, duplicates, shifts outside [-8, 7], > 2^26 atoms) clears
 // the `ok` flag and the caller keeps the per-edge evaluation.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstdint>
 #include <string>
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void pair_expand_kernel(const uint32_t* __rest
 
 static size_t ep_cub_bytes(int64_t E) {
   size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)E, 0, 64, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
+                                  (int32_t*)nullptr, (unsigned int)E, 0u, 64u, (hipStream_t)0);
   return bytes;
 }
 
@@ -188,8 +189,8 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
     const ST* sh = static_cast<const ST*>(edge_cell_shift);                                                     \
     hipLaunchKernelGGL(edge_pairs_key_kernel<ST>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src, sh, E,         \
                        num_nodes, keys, vals, ok);                                                              \
-    if (hipcub::DeviceRadixSort::SortPairs(p, cub_bytes, keys, keys_sorted, vals, vals_sorted, (int)E, 0, 64,   \
-                                           s) != hipSuccess) {                                                  \
+    if (rocprim::radix_sort_pairs(p, cub_bytes, keys, keys_sorted, vals, vals_sorted, (unsigned int)E, 0u, 64u,  \
+                                  s) != hipSuccess) {                                                           \
       set_error("nqa_edge_pairs: radix sort failed");                                                           \
       return NQA_ERR_LAUNCH;                                                                                    \
     }                                                                                                          \
