@@ -79,7 +79,10 @@ struct NFStage {  // one (instruction, atom type, 32-channel K slab) step of a c
   bool valid;
 };
 
-template <int D>
+// PIPE: the stage loop of node_linear_wave_bf16_unit<D, true, PIPE = true> (node_ops.hip): one wait per stage, at its top, for
+// loads requested a full stage earlier -- the x slab, the gate scalars and BOTH K blocks' weight fragments of stage s + 1 go
+// out right after the slab of stage s is in LDS (second fragment buffer, loop unrolled by two); two wavefronts per SIMD.
+template <int D, bool PIPE>
 __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NFChunk& ch, int64_t g,
                                                 float* __restrict__ xs, float* __restrict__ gs) {
   constexpr int NZT = 32 / D;
@@ -113,10 +116,10 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     xz[v] = idx / RUN4;
     xo[v] = (idx - xz[v] * RUN4) * 4;
   }
-  auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
+  auto slot_ok = [&](int v) __attribute__((always_inline)) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
 
-  auto fill = [&](NFStage& st) {
-    const NFInstr& in = a.instr[st.q];
+  auto fill = [&](NFStage& st) __attribute__((always_inline)) {
+    const NFInstr& in = a.instr[__builtin_amdgcn_readfirstlane(st.q)];  // (scalar index: the tables stay in the kernel-argument segment)
     st.mul_in = in.mul_in;
     st.x_off = in.x_off;
     st.gate_off = in.gate_off;
@@ -125,19 +128,19 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     st.set = in.set;
     st.frag_off = in.frag_off;
     st.exp_off = in.exp_off;
-    const NFSet& s = a.sets[in.set];
+    const NFSet& s = a.sets[__builtin_amdgcn_readfirstlane(in.set)];
     st.n_types = s.n_types;
     st.din = s.din;
     st.xp = s.x;
   };
-  auto first_stage = [&]() {
+  auto first_stage = [&]() __attribute__((always_inline)) {
     NFStage st{};
     st.q = ch.instr_begin;
     st.valid = ch.instr_begin < ch.instr_end;
     if (st.valid) fill(st);
     return st;
   };
-  auto next_stage = [&](NFStage st) {
+  auto next_stage = [&](NFStage st) __attribute__((always_inline)) {
     if (!st.valid) return st;
     st.k0 += kNLK3;
     if (st.k0 >= st.mul_in) {
@@ -152,7 +155,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   };
 
   // x slab of a stage: unconditional loads from clamped addresses (see node_linear_wave_bf16_unit)
-  auto load_x = [&](float4 (&xr)[XV4], const NFStage& st) {
+  auto load_x = [&](float4 (&xr)[XV4], const NFStage& st) __attribute__((always_inline)) {
     const int kk = min(kNLK3, st.mul_in - st.k0) * D;
     const float* __restrict__ xb0 = st.xp + st.x_off + st.k0 * D;
     if (((st.din | st.x_off | kk) & 3) == 0) {
@@ -174,7 +177,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
       }
     }
   };
-  auto store_x = [&](const float4 (&xr)[XV4], const NFStage& st) {
+  auto store_x = [&](const float4 (&xr)[XV4], const NFStage& st) __attribute__((always_inline)) {
     const int xkk = min(kNLK3, st.mul_in - st.k0) * D;
     const bool actv = st.gate_off == -1;  // (wave-uniform) activation of a scalar block while it is staged
 #pragma unroll
@@ -203,7 +206,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   };
   // gate scalars of a stage's channels: [NZT atoms][32 channels], activated once when they go to LDS.  (The host only asks
   // for gated blocks with d >= 3, multiplicities and offsets that are multiples of 4.)
-  auto load_g = [&](float4 (&gr)[XG4], const NFStage& st) {
+  auto load_g = [&](float4 (&gr)[XG4], const NFStage& st) __attribute__((always_inline)) {
     if constexpr (D > 1) {
       if (st.gate_off >= 0) {
         const int kc = min(kNLK3, st.mul_in - st.k0);
@@ -218,7 +221,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
       }
     }
   };
-  auto store_g = [&](const float4 (&gr)[XG4], const NFStage& st) {
+  auto store_g = [&](const float4 (&gr)[XG4], const NFStage& st) __attribute__((always_inline)) {
     if constexpr (D > 1) {
       if (st.gate_off >= 0) {
         const int kc = min(kNLK3, st.mul_in - st.k0);
@@ -242,8 +245,8 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
 
   nl_u32x4 Af[2][2];  // [tile][plane]
   int we_blk = 0;
-  auto load_a = [&](const NFStage& st, int k16) {
-    const NFSet& s = a.sets[st.set];
+  auto load_a = [&](const NFStage& st, int k16) __attribute__((always_inline)) {
+    const NFSet& s = a.sets[__builtin_amdgcn_readfirstlane(st.set)];
     const nl_u32x4* __restrict__ p = s.wf + (int64_t)st.t * s.frag_stride + st.frag_off + lane +
                                      ((int64_t)(k16 * nct + ct0) * 2) * 64;
     Af[0][0] = p[0]; Af[0][1] = p[64];
@@ -253,7 +256,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   f32x16n acc0 = {0}, acc1 = {0};
   constexpr int kUnset = 1 << 20;
   int Scol = kUnset;
-  auto block = [&](int s, bool on, bool gated) {
+  auto block = [&](int s, bool on, bool gated) __attribute__((always_inline)) {
     const float* __restrict__ xb = xs + zl * S + m;
     float bq[8];
 #pragma unroll
@@ -319,6 +322,59 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   float4 gr0[XG4];
   NFStage cur = first_stage();
   NFStage ld = cur;
+  if constexpr (PIPE) {
+    nl_u32x4 Ap[2][2][2][2];  // [buffer][K block][tile][plane]
+    int wep[2][2];
+    auto load_a2 = [&](int b, const NFStage& st) __attribute__((always_inline)) {
+      const NFSet& s = a.sets[__builtin_amdgcn_readfirstlane(st.set)];
+      const int k16a = st.k0 >> 4;
+      const bool second = st.k0 + 16 < st.mul_in;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int k16 = (kb == 1 && second) ? k16a + 1 : k16a;
+        const nl_u32x4* __restrict__ p = s.wf + (int64_t)st.t * s.frag_stride + st.frag_off + lane +
+                                         ((int64_t)(k16 * nct + ct0) * 2) * 64;
+        Ap[b][kb][0][0] = p[0]; Ap[b][kb][0][1] = p[64];
+        if (two_tiles) { Ap[b][kb][1][0] = p[128]; Ap[b][kb][1][1] = p[192]; }
+        wep[b][kb] = s.wexp[__builtin_amdgcn_readfirstlane(st.t * s.exp_stride + st.exp_off + k16)];
+      }
+    };
+    auto blocks = [&](int b, const NFStage& st) __attribute__((always_inline)) {
+      const bool bsel = col_ok && (st.n_types == 1 || tzj == st.t);
+      const bool gated = st.gate_off >= 0;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int tl2 = 0; tl2 < 2; ++tl2) {
+          Af[tl2][0] = Ap[b][kb][tl2][0];
+          Af[tl2][1] = Ap[b][kb][tl2][1];
+        }
+        we_blk = wep[b][kb];
+        block(kb, bsel && (st.k0 + 16 * kb < st.mul_in), gated);
+      }
+    };
+    if (ld.valid) { load_x(xr0, ld); load_g(gr0, ld); load_a2(0, ld); ld = next_stage(ld); }
+    asm volatile("" ::"v"(tzj));  // (consume the atom-type load once, outside the loop: see node_linear_wave_bf16_unit)
+    while (cur.valid) {
+      store_x(xr0, cur);
+      store_g(gr0, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ld.valid) { load_x(xr0, ld); load_g(gr0, ld); load_a2(1, ld); }
+      __builtin_amdgcn_sched_barrier(0);
+      blocks(0, cur);
+      cur = ld;
+      ld = next_stage(ld);
+      if (!cur.valid) break;
+      store_x(xr0, cur);
+      store_g(gr0, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ld.valid) { load_x(xr0, ld); load_g(gr0, ld); load_a2(0, ld); }
+      __builtin_amdgcn_sched_barrier(0);
+      blocks(1, cur);
+      cur = ld;
+      ld = next_stage(ld);
+    }
+  } else {
   if (ld.valid) { load_x(xr0, ld); load_g(gr0, ld); ld = next_stage(ld); }
   while (cur.valid) {
     store_x(xr0, cur);
@@ -342,6 +398,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
       }
     }
     cur = next_stage(cur);
+  }
   }
 
   // ---- epilogue: accumulators -> the wavefront's slab -> contiguous runs per atom, through the chunk's epilogue
@@ -484,8 +541,13 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   }
 }
 
-__global__ __launch_bounds__(64 * kNLWavesPerWG, 3) void node_fused_kernel(const NodeFusedArgs a) {
+template <bool PIPE>
+__global__ __launch_bounds__(64 * kNLWavesPerWG, PIPE ? 2 : 3) void node_fused_kernel(const NodeFusedArgs a_kernarg) {
   __shared__ __align__(16) float xs_all[kNLWavesPerWG * (kNLXS + kNFGS)];
+  // The tables are read where the dispatch packet put them (the kernel-argument segment; this kernel's only argument sits at
+  // its start): with the by-value parameter the compiler kept a 3 KiB private copy of the struct per lane -- scratch stores
+  // at the top of every wavefront and scratch loads for every table access -- once the stage loop was unrolled.
+  const NodeFusedArgs& a = *(const NodeFusedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int unit = (int)blockIdx.x * kNLWavesPerWG + wv;
   if (unit >= a.grp_begin[a.n_groups]) return;
@@ -498,11 +560,11 @@ __global__ __launch_bounds__(64 * kNLWavesPerWG, 3) void node_fused_kernel(const
   const NFChunk ch = a.chunks[a.grp_chunk0[gi] + local % n];
   const int64_t g = (int64_t)(local / n);
   switch (ch.d) {
-    case 1: node_fused_unit<1>(a, ch, g, xs, gs); break;
-    case 3: node_fused_unit<3>(a, ch, g, xs, gs); break;
-    case 5: node_fused_unit<5>(a, ch, g, xs, gs); break;
-    case 7: node_fused_unit<7>(a, ch, g, xs, gs); break;
-    case 9: node_fused_unit<9>(a, ch, g, xs, gs); break;
+    case 1: node_fused_unit<1, PIPE>(a, ch, g, xs, gs); break;
+    case 3: node_fused_unit<3, PIPE>(a, ch, g, xs, gs); break;
+    case 5: node_fused_unit<5, PIPE>(a, ch, g, xs, gs); break;
+    case 7: node_fused_unit<7, PIPE>(a, ch, g, xs, gs); break;
+    case 9: node_fused_unit<9, PIPE>(a, ch, g, xs, gs); break;
     default: break;
   }
 }
@@ -752,8 +814,13 @@ int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* a
       set_error("nqa_node_fused: too many work units for one launch");
       return NQA_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(node_fused_kernel, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)), dim3(64 * kNLWavesPerWG),
-                       0, s, a);
+    const char* pe = std::getenv("NQA_NODE_PIPE");  // (0: the block-by-block fragment loads, three wavefronts per SIMD)
+    if (pe == nullptr || pe[0] != '0')
+      hipLaunchKernelGGL(node_fused_kernel<true>, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
+                         dim3(64 * kNLWavesPerWG), 0, s, a);
+    else
+      hipLaunchKernelGGL(node_fused_kernel<false>, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
+                         dim3(64 * kNLWavesPerWG), 0, s, a);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

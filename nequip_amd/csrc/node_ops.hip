@@ -611,7 +611,15 @@ struct NodeStage {  // one (instruction, atom type, 32-channel K slab) step of a
   bool valid;
 };
 
-template <int D, bool F16>
+// PIPE (F16 only; round 4): the stage loop restructured around how the memory counter retires.  vmcnt retires IN ORDER, and
+// across the branches of this loop the compiler waits with vmcnt(0): in the loop above the weight fragments of a stage's
+// second K block are requested AFTER the next stage's x slab, so waiting for them drains the slab prefetch as well -- every
+// stage pays the full HBM latency twice (ISA: `s_waitcnt vmcnt(0)` in front of both MFMA groups; per-unit timeline 8-10 k
+// cycles per stage for ~1.5 k cycles of issue).  Here a stage has ONE wait, at its top, for loads that were all requested a
+// full stage earlier: x slab AND both K blocks' fragments of stage s+1 go out right after the slab of stage s has been
+// written to LDS, into a second fragment buffer (the stage loop is unrolled by two so that both buffers are addressed
+// statically); inside a stage nothing waits on memory.  64 fragment registers instead of 16: two wavefronts per SIMD.
+template <int D, bool F16, bool PIPE = false>
 __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPackedArgs& pa, const NodeChunk& ch, int64_t g,
                                                            float* __restrict__ xs, int unit) {
   constexpr int NPL = F16 ? 2 : 3;  // operand planes
@@ -851,6 +859,58 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
   float4 xr0[XV4];
   NodeStage cur = first_stage();
   NodeStage ld = cur;  // the stage whose slab is requested next
+  if constexpr (PIPE && F16) {
+    nl_u32x4 Ap[2][2][2][2];  // [buffer][K block][tile][plane]
+    int wep[2][2];
+    auto load_a2 = [&](int b, const NodeStage& st) {
+      const int k16a = st.k0 >> 4;
+      const bool second = st.k0 + 16 < st.mul_in;  // (a slab of <= 16 channels repeats its block with B = 0)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int k16 = (kb == 1 && second) ? k16a + 1 : k16a;
+        const nl_u32x4* __restrict__ p = pa.wf + (int64_t)st.t * pa.frag_stride + pa.frag_off[st.q] + lane +
+                                         ((int64_t)(k16 * nct + ct0) * 2) * 64;
+        Ap[b][kb][0][0] = p[0]; Ap[b][kb][0][1] = p[64];
+        if (two_tiles) { Ap[b][kb][1][0] = p[128]; Ap[b][kb][1][1] = p[192]; }
+        // (scalar load: a vector load here would sit in the in-order vmcnt queue behind the slab prefetch)
+        wep[b][kb] = pa.wexp[__builtin_amdgcn_readfirstlane(st.t * pa.exp_stride + a.instr[st.q].pad + k16)];
+      }
+    };
+    auto blocks = [&](int b, const NodeStage& st) {
+      const bool bsel = col_ok && (a.n_types == 1 || tzj == st.t);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int tl2 = 0; tl2 < 2; ++tl2) {
+          Af[0][tl2][0] = Ap[b][kb][tl2][0];
+          Af[0][tl2][1] = Ap[b][kb][tl2][1];
+        }
+        we_blk = wep[b][kb];
+        block(0, kb, bsel && (st.k0 + 16 * kb < st.mul_in));
+      }
+    };
+    if (ld.valid) { load_x(xr0, ld); load_a2(0, ld); ld = next_stage(ld); }
+    // the atom type of this lane's column was requested at the top of the unit: consume the load HERE, once -- its first use
+    // inside the loop would otherwise carry a vmcnt(0) into every stage
+    asm volatile("" ::"v"(tzj));
+    while (cur.valid) {
+      store_x(xr0, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ld.valid) { load_x(xr0, ld); load_a2(1, ld); }
+      __builtin_amdgcn_sched_barrier(0);
+      blocks(0, cur);
+      cur = ld;
+      ld = next_stage(ld);
+      if (!cur.valid) break;
+      store_x(xr0, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ld.valid) { load_x(xr0, ld); load_a2(0, ld); }
+      __builtin_amdgcn_sched_barrier(0);
+      blocks(1, cur);
+      cur = ld;
+      ld = next_stage(ld);
+    }
+  } else {
   if (ld.valid) { load_x(xr0, ld); ld = next_stage(ld); }
   while (cur.valid) {
     store_x(xr0, cur);
@@ -873,6 +933,7 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
       }
     }
     cur = next_stage(cur);
+  }
   }
   if (tl) {
     stamp();
@@ -966,6 +1027,29 @@ __global__ __launch_bounds__(64 * kNLWavesPerWG, 3) void node_linear_wave_bf16_k
     case 5: node_linear_wave_bf16_unit<5, F16>(pa, ch, g, xs, unit); break;
     case 7: node_linear_wave_bf16_unit<7, F16>(pa, ch, g, xs, unit); break;
     case 9: node_linear_wave_bf16_unit<9, F16>(pa, ch, g, xs, unit); break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(64 * kNLWavesPerWG, 2) void node_linear_pipe_kernel(const NodeLinearPackedArgs pa) {
+  __shared__ __align__(16) float xs_all[kNLWavesPerWG * kNLXS];
+  const NodeLinearArgs<float>& a = pa.base;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int unit = (int)blockIdx.x * kNLWavesPerWG + wv;
+  if (unit >= pa.grp_begin[pa.n_groups]) return;
+  float* xs = xs_all + wv * kNLXS;
+  int gi = 0;
+  while (gi + 1 < pa.n_groups && unit >= pa.grp_begin[gi + 1]) ++gi;
+  const int local = unit - pa.grp_begin[gi];
+  const int n = pa.grp_n[gi];
+  const NodeChunk ch = a.chunks[pa.grp_chunk0[gi] + local % n];
+  const int64_t g = (int64_t)(local / n);
+  switch (ch.d) {
+    case 1: node_linear_wave_bf16_unit<1, true, true>(pa, ch, g, xs, unit); break;
+    case 3: node_linear_wave_bf16_unit<3, true, true>(pa, ch, g, xs, unit); break;
+    case 5: node_linear_wave_bf16_unit<5, true, true>(pa, ch, g, xs, unit); break;
+    case 7: node_linear_wave_bf16_unit<7, true, true>(pa, ch, g, xs, unit); break;
+    case 9: node_linear_wave_bf16_unit<9, true, true>(pa, ch, g, xs, unit); break;
     default: break;
   }
 }
@@ -1491,7 +1575,13 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
       set_error("nqa_node_linear_packed: too many work units for one launch");
       return NQA_ERR_UNSUPPORTED;
     }
-    if (node_f16())
+    // (NQA_NODE_PIPE=0: the round-3 stage loop -- three wavefronts per SIMD, fragments requested block by block)
+    const char* pe = std::getenv("NQA_NODE_PIPE");
+    const bool pipe = pe == nullptr || pe[0] != '0';
+    if (node_f16() && pipe && (a.dbg & 64) == 0)
+      hipLaunchKernelGGL(node_linear_pipe_kernel, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
+                         dim3(64 * kNLWavesPerWG), 0, s, pa);
+    else if (node_f16())
       hipLaunchKernelGGL(node_linear_wave_bf16_kernel<true>, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
                          dim3(64 * kNLWavesPerWG), 0, s, pa);
     else
