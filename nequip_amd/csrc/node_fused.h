@@ -71,6 +71,29 @@ struct NodeFusedArgs {
 };
 static_assert(sizeof(NodeFusedArgs) <= 3900, "kernel arguments must stay below 4 KiB");
 
+// Activations of the fused stage: one v_exp_f32 + one v_rcp_f32 per value (1 ulp each) instead of expf() and an IEEE
+// division -- a unit re-activates the gate scalars of every slab it stages (8 per lane and stage), which at ~20
+// instructions per silu was a third of the stage's vector instructions.
+__device__ __forceinline__ float nf_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float nf_act(int act, float x, float cst) {
+  if (act == 1) return cst * x * nf_sigmoid(x);
+  if (act == 2) return cst * tanhf(x);
+  return x;
+}
+__device__ __forceinline__ float nf_act_grad(int act, float x, float cst) {
+  if (act == 1) {
+    const float s = nf_sigmoid(x);
+    return cst * s * (1.f + x * (1.f - s));
+  }
+  if (act == 2) {
+    const float t = tanhf(x);
+    return cst * (1.f - t * t);
+  }
+  return 1.f;
+}
+
 struct NFStage {  // one (instruction, atom type, 32-channel K slab) step of a chunk; wave-uniform
   int q, t, k0;
   int mul_in, x_off, gate_off, act, set, n_types, din, frag_off, exp_off;
@@ -186,10 +209,10 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
         float4 r = xr[v];
         if (actv) {
-          r.x = act_eval(st.act, r.x, st.cst);
-          r.y = act_eval(st.act, r.y, st.cst);
-          r.z = act_eval(st.act, r.z, st.cst);
-          r.w = act_eval(st.act, r.w, st.cst);
+          r.x = nf_act(st.act, r.x, st.cst);
+          r.y = nf_act(st.act, r.y, st.cst);
+          r.z = nf_act(st.act, r.z, st.cst);
+          r.w = nf_act(st.act, r.w, st.cst);
         }
         r.x = (zok && xo[v] + 0 < xkk) ? r.x : 0.f;
         r.y = (zok && xo[v] + 1 < xkk) ? r.y : 0.f;
@@ -232,10 +255,10 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
           if (gz < NZT) {
             const bool zok = zbase + gz < a.N;
             float4 r;
-            r.x = (zok && go + 0 < kc) ? act_eval(st.act, gr[v].x, st.cst) : 0.f;
-            r.y = (zok && go + 1 < kc) ? act_eval(st.act, gr[v].y, st.cst) : 0.f;
-            r.z = (zok && go + 2 < kc) ? act_eval(st.act, gr[v].z, st.cst) : 0.f;
-            r.w = (zok && go + 3 < kc) ? act_eval(st.act, gr[v].w, st.cst) : 0.f;
+            r.x = (zok && go + 0 < kc) ? nf_act(st.act, gr[v].x, st.cst) : 0.f;
+            r.y = (zok && go + 1 < kc) ? nf_act(st.act, gr[v].y, st.cst) : 0.f;
+            r.z = (zok && go + 2 < kc) ? nf_act(st.act, gr[v].z, st.cst) : 0.f;
+            r.w = (zok && go + 3 < kc) ? nf_act(st.act, gr[v].w, st.cst) : 0.f;
             *reinterpret_cast<float4*>(gs + gz * GS + go) = r;
           }
         }
@@ -486,10 +509,10 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
       }
       const int64_t col = ch.ev_off + (int64_t)ch.c0 * D + eo;
       const float4 hv = *reinterpret_cast<const float4*>(a.h + zg * a.hdim + col);
-      r.x *= scale * act_grad(ch.act, hv.x, ch.cst);
-      r.y *= scale * act_grad(ch.act, hv.y, ch.cst);
-      r.z *= scale * act_grad(ch.act, hv.z, ch.cst);
-      r.w *= scale * act_grad(ch.act, hv.w, ch.cst);
+      r.x *= scale * nf_act_grad(ch.act, hv.x, ch.cst);
+      r.y *= scale * nf_act_grad(ch.act, hv.y, ch.cst);
+      r.z *= scale * nf_act_grad(ch.act, hv.z, ch.cst);
+      r.w *= scale * nf_act_grad(ch.act, hv.w, ch.cst);
       *reinterpret_cast<float4*>(dst.out + zg * dst.dout + col) = r;
     }
   } else {
@@ -523,14 +546,14 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         float go[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float ag = act_eval(ch.act, gq[c], ch.cst);
+          const float ag = nf_act(ch.act, gq[c], ch.cst);
           float s = 0.f;
 #pragma unroll
           for (int mm = 0; mm < D; ++mm) {
             s += rr[c * D + mm] * hh[c * D + mm];
             rr[c * D + mm] *= ag;
           }
-          go[c] = s * act_grad(ch.act, gq[c], ch.cst);
+          go[c] = s * nf_act_grad(ch.act, gq[c], ch.cst);
         }
 #pragma unroll
         for (int q4 = 0; q4 < D; ++q4)
@@ -814,8 +837,11 @@ int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* a
       set_error("nqa_node_fused: too many work units for one launch");
       return NQA_ERR_UNSUPPORTED;
     }
-    const char* pe = std::getenv("NQA_NODE_PIPE");  // (0: the block-by-block fragment loads, three wavefronts per SIMD)
-    if (pe == nullptr || pe[0] != '0')
+    // NQA_NODE_PIPE=1: the one-wait-per-stage loop at two wavefronts per SIMD.  Measured (cfg-3 and cu20k, same box): no
+    // faster -- these kernels are bound by how many vector instructions a stage issues with three wavefronts sharing a
+    // SIMD, not by the waits of one wavefront, and the second fragment buffer costs the third wavefront.
+    const char* pe = std::getenv("NQA_NODE_PIPE");
+    if (pe != nullptr && pe[0] == '1')
       hipLaunchKernelGGL(node_fused_kernel<true>, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
                          dim3(64 * kNLWavesPerWG), 0, s, a);
     else

@@ -1575,9 +1575,10 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
       set_error("nqa_node_linear_packed: too many work units for one launch");
       return NQA_ERR_UNSUPPORTED;
     }
-    // (NQA_NODE_PIPE=0: the round-3 stage loop -- three wavefronts per SIMD, fragments requested block by block)
+    // NQA_NODE_PIPE=1: the one-wait-per-stage loop (two wavefronts per SIMD); measured no faster than the default, see
+    // node_fused.h
     const char* pe = std::getenv("NQA_NODE_PIPE");
-    const bool pipe = pe == nullptr || pe[0] != '0';
+    const bool pipe = pe != nullptr && pe[0] == '1';
     if (node_f16() && pipe && (a.dbg & 64) == 0)
       hipLaunchKernelGGL(node_linear_pipe_kernel, dim3((unsigned)((nblk + kNLWavesPerWG - 1) / kNLWavesPerWG)),
                          dim3(64 * kNLWavesPerWG), 0, s, pa);
