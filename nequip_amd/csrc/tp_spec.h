@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 namespace nqa {
@@ -172,6 +173,14 @@ __device__ __forceinline__ void spec_halve(const float* in, float* out, bool bit
 // float, K <= 16: transposing butterfly.  Four halving steps inside each 16-lane row leave lane r of every row with
 // the row-partial sum of value r; two gfx950 half-exchanges (v_permlane16_swap / v_permlane32_swap) then all-reduce
 // the four rows.  ~(3K + 10) VALU instructions instead of ~13K, and a single coalesced store.
+// A lane beyond the last channel of a partial chunk duplicates the clamped channel's work (all-lanes kernels): its partial
+// sums must not enter a wave reduction.
+template <typename T, int K>
+__device__ __forceinline__ void spec_mask_dup(T* __restrict__ q, bool own) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) q[k] = own ? q[k] : T(0);
+}
+
 template <typename T, int K>
 __device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, T* __restrict__ dst, int lane) {
   if constexpr (sizeof(T) != 4 || (K > 16)) {
