@@ -203,10 +203,11 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   auto store_x = [&](const float4 (&xr)[XV4], const NFStage& st) __attribute__((always_inline)) {
     const int xkk = min(kNLK3, st.mul_in - st.k0) * D;
     const bool actv = st.gate_off == -1;  // (wave-uniform) activation of a scalar block while it is staged
+    // (wave-uniform) a complete slab of a complete atom group needs no masking: everything a lane loaded is its own
+    const bool whole = xkk == kNLK3 * D && zbase + NZT <= a.N;
 #pragma unroll
     for (int v = 0; v < XV4; ++v) {
       if (slot_ok(v)) {
-        const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
         float4 r = xr[v];
         if (actv) {
           r.x = nf_act(st.act, r.x, st.cst);
@@ -214,10 +215,13 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
           r.z = nf_act(st.act, r.z, st.cst);
           r.w = nf_act(st.act, r.w, st.cst);
         }
-        r.x = (zok && xo[v] + 0 < xkk) ? r.x : 0.f;
-        r.y = (zok && xo[v] + 1 < xkk) ? r.y : 0.f;
-        r.z = (zok && xo[v] + 2 < xkk) ? r.z : 0.f;
-        r.w = (zok && xo[v] + 3 < xkk) ? r.w : 0.f;
+        if (!whole) {
+          const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
+          r.x = (zok && xo[v] + 0 < xkk) ? r.x : 0.f;
+          r.y = (zok && xo[v] + 1 < xkk) ? r.y : 0.f;
+          r.z = (zok && xo[v] + 2 < xkk) ? r.z : 0.f;
+          r.w = (zok && xo[v] + 3 < xkk) ? r.w : 0.f;
+        }
         float* __restrict__ d = xs + xz[v] * S + xo[v];
         if constexpr (kVecLds) {
           *reinterpret_cast<float4*>(d) = r;
@@ -279,7 +283,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   f32x16n acc0 = {0}, acc1 = {0};
   constexpr int kUnset = 1 << 20;
   int Scol = kUnset;
-  auto block = [&](int s, bool on, bool gated) __attribute__((always_inline)) {
+  auto block = [&](int s, bool on, bool gated, bool masked) __attribute__((always_inline)) {
     const float* __restrict__ xb = xs + zl * S + m;
     float bq[8];
 #pragma unroll
@@ -292,10 +296,17 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         bq[4] *= g1.x; bq[5] *= g1.y; bq[6] *= g1.z; bq[7] *= g1.w;
       }
     }
+    // Columns are independent in the product, and a column that is never stored (lanes beyond the group's atoms: they read a
+    // clamped atom's rows) may hold anything; rows beyond the slab and atoms beyond N were zero-filled when the slab was
+    // staged.  Only a TYPED stage has to silence columns: atoms whose type is not the staged weight set's.
+    if (masked) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bq[e] = on ? bq[e] : 0.f;
+    }
     const int we = we_blk;
     float mx = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(on ? bq[e] : 0.f));
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(bq[e]));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     int shift = 0;
     if (mx > 0.f && mx < 3.0e38f) {
@@ -322,7 +333,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     nl_u32x4 Bh, Bl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v0 = on ? bq[2 * e] * qs : 0.f, v1 = on ? bq[2 * e + 1] * qs : 0.f;
+      const float v0 = bq[2 * e] * qs, v1 = bq[2 * e + 1] * qs;
       uint32_t x, y;
       nl_split_pair_f16(v0, v1, x, y);
       Bh[e] = x; Bl[e] = y;
@@ -373,7 +384,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
           Af[tl2][1] = Ap[b][kb][tl2][1];
         }
         we_blk = wep[b][kb];
-        block(kb, bsel && (st.k0 + 16 * kb < st.mul_in), gated);
+        block(kb, bsel, gated, st.n_types > 1);
       }
     };
     if (ld.valid) { load_x(xr0, ld); load_g(gr0, ld); load_a2(0, ld); ld = next_stage(ld); }
@@ -412,7 +423,8 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
 #pragma unroll
     for (int s16 = 0; s16 < kNLK3 / 16; ++s16) {
       const bool exists = cur.k0 + 16 * s16 < cur.mul_in;
-      block(s16, bsel && exists, gated);
+      (void)exists;
+      block(s16, bsel, gated, cur.n_types > 1);
       if (s16 + 1 < kNLK3 / 16) {
         __builtin_amdgcn_sched_barrier(0);
         const bool nexists = cur.k0 + 16 * (s16 + 1) < cur.mul_in;

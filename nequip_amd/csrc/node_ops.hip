@@ -710,15 +710,19 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
   };
   auto store_x = [&](const float4 (&xr)[XV4], const NodeStage& st) {
     const int xkk = min(kNLK3, st.mul_in - st.k0) * D;
+    // (wave-uniform) a complete slab of a complete atom group needs no masking
+    const bool whole = xkk == kNLK3 * D && zbase + NZT <= a.N;
 #pragma unroll
     for (int v = 0; v < XV4; ++v) {
       if (slot_ok(v)) {
-        const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
-        float4 r;
-        r.x = (zok && xo[v] + 0 < xkk) ? xr[v].x : 0.f;
-        r.y = (zok && xo[v] + 1 < xkk) ? xr[v].y : 0.f;
-        r.z = (zok && xo[v] + 2 < xkk) ? xr[v].z : 0.f;
-        r.w = (zok && xo[v] + 3 < xkk) ? xr[v].w : 0.f;
+        float4 r = xr[v];
+        if (!whole) {
+          const bool zok = xz[v] < NZT && zbase + xz[v] < a.N;
+          r.x = (zok && xo[v] + 0 < xkk) ? r.x : 0.f;
+          r.y = (zok && xo[v] + 1 < xkk) ? r.y : 0.f;
+          r.z = (zok && xo[v] + 2 < xkk) ? r.z : 0.f;
+          r.w = (zok && xo[v] + 3 < xkk) ? r.w : 0.f;
+        }
         float* __restrict__ d = xs + xz[v] * S + xo[v];
         if constexpr (kVecLds) {
           *reinterpret_cast<float4*>(d) = r;
@@ -757,11 +761,18 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
     float bq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bq[e] = xb[(16 * s + 8 * half + e) * D];
+    // Columns are independent in the product and a column that is never stored (lanes beyond the group's atoms) may hold
+    // anything; rows beyond the slab / atoms beyond N were zero-filled when the slab was staged.  Only TYPED launches have to
+    // silence columns (atoms of another type than the staged weight set's).
+    if (a.n_types > 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bq[e] = on ? bq[e] : 0.f;
+    }
     if constexpr (F16) {
       const int we = we_blk;
       float mx = 0.f;  // the column's largest magnitude in this K block (its other 8 values sit in lane ^ 32)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(on ? bq[e] : 0.f));
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(bq[e]));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       int shift = 0;
       if (mx > 0.f && mx < 3.0e38f) {
@@ -788,7 +799,7 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
       nl_u32x4 Bh, Bl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v0 = on ? bq[2 * e] * qs : 0.f, v1 = on ? bq[2 * e + 1] * qs : 0.f;
+        const float v0 = bq[2 * e] * qs, v1 = bq[2 * e + 1] * qs;
         uint32_t x, y;
         nl_split_pair_f16(v0, v1, x, y);
         Bh[e] = x; Bl[e] = y;
@@ -811,7 +822,7 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
     nl_u32x4 Bh, Bm, Bl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float v0 = on ? bq[2 * e] : 0.f, v1 = on ? bq[2 * e + 1] : 0.f;
+      const float v0 = bq[2 * e], v1 = bq[2 * e + 1];
       uint32_t x, y, zz;
       nl_split_pair(v0, v1, x, y, zz);
       Bh[e] = x; Bm[e] = y; Bl[e] = zz;

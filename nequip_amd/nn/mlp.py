@@ -472,7 +472,7 @@ class ScalarMLPFunction(_WeightCacheMixin, torch.nn.Module):
         return self.mlp(x)
 
 
-class ScalarMLP(GraphModuleMixin, torch.nn.Module):
+class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
     """Apply an MLP to a scalar node field (the per-atom energy readout, ``nequip_models.py:371-381``)."""
 
     def __init__(self, output_dim: int, hidden_layers_depth: int = 0, hidden_layers_width: Optional[int] = None,

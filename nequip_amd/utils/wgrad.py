@@ -73,7 +73,7 @@ class _WeightCacheMixin:
     (``p.data.copy_()`` style writes bypass the version counter the cache is keyed on -- call
     ``invalidate_weight_cache()`` after such a write)."""
 
-    _weight_cache_attrs = ("_eval_wp", "_weight_images")
+    _weight_cache_attrs = ("_eval_wp", "_weight_images", "_deep_images", "_head_w")
 
     def invalidate_weight_cache(self) -> None:
         for name in self._weight_cache_attrs:
