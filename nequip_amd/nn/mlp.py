@@ -504,6 +504,10 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
         if ss.field != self.out_field or ss.out_field != self.out_field:
             return None
         lin = fn.mlp[0]
+        if torch.is_grad_enabled() and lin.weight.requires_grad and not h.requires_grad:
+            # nothing upstream asks for a gradient but the readout weight does (an energy-only backward in eval mode): the
+            # module chain, whose `mm` gives that gradient -- the fused head treats the weight as a constant
+            return None
         key = (lin.weight._version, lin.weight.data_ptr(), h.device)
         cached = self.__dict__.get("_head_w")
         if cached is None or cached[0] != key:
