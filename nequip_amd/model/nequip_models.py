@@ -150,98 +150,83 @@ def _full_nequip_energy_model(
     convnet_nonlinearity_scalars: Dict[str, str] = {"e": "silu", "o": "tanh"},
     convnet_nonlinearity_gates: Dict[str, str] = {"e": "silu", "o": "tanh"},
 ):
-    assert all(tn.isalnum() for tn in type_names)
-    assert len(radial_mlp_depth) == len(radial_mlp_width) == len(feature_irreps_hidden)
-    num_layers = len(radial_mlp_depth)
-    assert all(l == 0 for l in Irreps(feature_irreps_hidden[-1]).ls)
+    if not all(name.isalnum() for name in type_names):
+        raise AssertionError("type names must be alphanumeric")
+    depths, widths, hidden = list(radial_mlp_depth), list(radial_mlp_width), list(feature_irreps_hidden)
+    if not (len(depths) == len(widths) == len(hidden)):
+        raise AssertionError("radial_mlp_depth, radial_mlp_width and feature_irreps_hidden list one entry per layer")
+    if any(l != 0 for l in Irreps(hidden[-1]).ls):
+        raise AssertionError("the last layer keeps scalars only (the readout acts on them)")
 
-    type_embed = NodeTypeEmbed(type_names=type_names, num_features=type_embed_num_features)
-    spharm = SphericalHarmonicEdgeAttrs(irreps_edge_sh=irreps_edge_sh, irreps_in=type_embed.irreps_out)
-    edge_norm = EdgeLengthNormalizer(r_max=r_max, type_names=type_names, per_edge_type_cutoff=per_edge_type_cutoff,
-                                     irreps_in=spharm.irreps_out)
-    bessel_encode = BesselEdgeLengthEncoding(
-        num_bessels=num_bessels,
-        trainable=bessel_trainable,
-        cutoff=PolynomialCutoff(polynomial_cutoff_p),
-        edge_invariant_field=AtomicDataDict.EDGE_EMBEDDING_KEY,
-        irreps_in=edge_norm.irreps_out,
-    )
-    factor = ApplyFactor(
-        in_field=AtomicDataDict.EDGE_EMBEDDING_KEY,
-        factor=(2 * math.pi) / (r_max * r_max),
-        irreps_in=bessel_encode.irreps_out,
-        fold_into=bessel_encode,
-    )
-    modules = {
-        "type_embed": type_embed,
-        "spharm": spharm,
-        "edge_norm": edge_norm,
-        "bessel_encode": bessel_encode,
-        "factor": factor,
-    }
-    prev_irreps_out = factor.irreps_out
+    chain = _Chain()
+    # ---- geometry: type embedding, spherical harmonics, normalised lengths, Bessel x cutoff (x 2 pi / r_max^2, folded) ----
+    chain.add("type_embed", lambda prev: NodeTypeEmbed(type_names=type_names, num_features=type_embed_num_features))
+    chain.add("spharm", lambda prev: SphericalHarmonicEdgeAttrs(irreps_edge_sh=irreps_edge_sh, irreps_in=prev))
+    edge_norm = chain.add("edge_norm", lambda prev: EdgeLengthNormalizer(
+        r_max=r_max, type_names=type_names, per_edge_type_cutoff=per_edge_type_cutoff, irreps_in=prev))
+    bessel = chain.add("bessel_encode", lambda prev: BesselEdgeLengthEncoding(
+        num_bessels=num_bessels, trainable=bessel_trainable, cutoff=PolynomialCutoff(polynomial_cutoff_p),
+        edge_invariant_field=AtomicDataDict.EDGE_EMBEDDING_KEY, irreps_in=prev))
+    chain.add("factor", lambda prev: ApplyFactor(in_field=AtomicDataDict.EDGE_EMBEDDING_KEY,
+                                                 factor=(2 * math.pi) / (r_max * r_max), irreps_in=prev, fold_into=bessel))
 
-    for layer_i in range(num_layers):
-        current_convnet = ConvNetLayer(
-            irreps_in=prev_irreps_out,
-            feature_irreps_hidden=feature_irreps_hidden[layer_i],
-            convolution_kwargs={
-                "radial_mlp_depth": radial_mlp_depth[layer_i],
-                "radial_mlp_width": radial_mlp_width[layer_i],
-                "use_sc": (layer_i != 0) and convnet_sc,
-                "is_first_layer": layer_i == 0,
-                "avg_num_neighbors": avg_num_neighbors,
-                "type_names": type_names,
-            },
-            resnet=(layer_i != 0) and convnet_resnet,
-            nonlinearity_type=convnet_nonlinearity_type,
-            nonlinearity_scalars=convnet_nonlinearity_scalars,
-            nonlinearity_gates=convnet_nonlinearity_gates,
-        )
-        prev_irreps_out = current_convnet.irreps_out
-        modules[f"layer{layer_i}_convnet"] = current_convnet
-        if not edge_norm.symmetric:
-            # cutoff(A <- B) != cutoff(B <- A): the two directed edges of a pair no longer share their radial weights
-            current_convnet.conv.paired_radial_ok = False
-        if layer_i > 0:
-            # the previous layer's Gate is consumed by this layer's linear_1 / self-connection only: it may be folded into
-            # them (eval mode, GPU; nn/convnetlayer.py::defer_gate)
-            modules[f"layer{layer_i - 1}_convnet"].defer_gate = True
+    # ---- message passing ----
+    convnets = []
+    for k, (irreps_k, depth_k, width_k) in enumerate(zip(hidden, depths, widths)):
+        first = k == 0
+        conv_kwargs = dict(radial_mlp_depth=depth_k, radial_mlp_width=width_k, use_sc=convnet_sc and not first,
+                           is_first_layer=first, avg_num_neighbors=avg_num_neighbors, type_names=type_names)
+        convnets.append(chain.add(f"layer{k}_convnet", lambda prev: ConvNetLayer(
+            irreps_in=prev, feature_irreps_hidden=irreps_k, convolution_kwargs=conv_kwargs,
+            resnet=convnet_resnet and not first, nonlinearity_type=convnet_nonlinearity_type,
+            nonlinearity_scalars=convnet_nonlinearity_scalars, nonlinearity_gates=convnet_nonlinearity_gates)))
 
-    if readout_mlp_hidden_layers_width is None:
-        readout_mlp_hidden_layers_width = Irreps(feature_irreps_hidden[-1]).dim
-    per_atom_energy_readout = ScalarMLP(
-        output_dim=1,
-        hidden_layers_depth=readout_mlp_hidden_layers_depth,
-        hidden_layers_width=readout_mlp_hidden_layers_width,
-        nonlinearity=readout_mlp_nonlinearity,
-        bias=False,
-        forward_weight_init=True,
-        field=AtomicDataDict.NODE_FEATURES_KEY,
-        out_field=AtomicDataDict.PER_ATOM_ENERGY_KEY,
-        irreps_in=prev_irreps_out,
-    )
-    per_type_energy_scale_shift = PerTypeScaleShift(
-        type_names=type_names,
-        field=AtomicDataDict.PER_ATOM_ENERGY_KEY,
-        out_field=AtomicDataDict.PER_ATOM_ENERGY_KEY,
-        scales=per_type_energy_scales,
-        shifts=per_type_energy_shifts,
-        irreps_in=per_atom_energy_readout.irreps_out,
-    )
-    modules["per_atom_energy_readout"] = per_atom_energy_readout
-    modules["per_type_energy_scale_shift"] = per_type_energy_scale_shift
-    # eval mode on the GPU: the last layer's Gate, the readout and the scale / shift run as one launch per direction
-    # (nn/_energy_head.py).  The link is a plain list entry: no second registration of the module, no new state-dict keys.
-    if readout_mlp_hidden_layers_depth == 0:
-        per_atom_energy_readout.__dict__["_scale_shift"] = [per_type_energy_scale_shift]
-        modules[f"layer{num_layers - 1}_convnet"].defer_gate = True
-    # nequip/model/energy_modules.py: total energy = sum of per-atom energies per frame
-    modules["total_energy_sum"] = AtomwiseReduce(
-        irreps_in=per_type_energy_scale_shift.irreps_out,
-        reduce="sum",
-        field=AtomicDataDict.PER_ATOM_ENERGY_KEY,
-        out_field=AtomicDataDict.TOTAL_ENERGY_KEY,
-    )
-    energy_model = SequentialGraphNetwork(modules)
-    return ForceStressOutput(energy_model, do_derivatives)
+    # ---- energy head: readout -> per-type scale / shift (float64) -> per-frame sum ----
+    readout_width = Irreps(hidden[-1]).dim if readout_mlp_hidden_layers_width is None else readout_mlp_hidden_layers_width
+    energy = AtomicDataDict.PER_ATOM_ENERGY_KEY
+    readout = chain.add("per_atom_energy_readout", lambda prev: ScalarMLP(
+        output_dim=1, hidden_layers_depth=readout_mlp_hidden_layers_depth, hidden_layers_width=readout_width,
+        nonlinearity=readout_mlp_nonlinearity, bias=False, forward_weight_init=True,
+        field=AtomicDataDict.NODE_FEATURES_KEY, out_field=energy, irreps_in=prev))
+    scale_shift = chain.add("per_type_energy_scale_shift", lambda prev: PerTypeScaleShift(
+        type_names=type_names, field=energy, out_field=energy, scales=per_type_energy_scales,
+        shifts=per_type_energy_shifts, irreps_in=prev))
+    chain.add("total_energy_sum", lambda prev: AtomwiseReduce(irreps_in=prev, reduce="sum", field=energy,
+                                                             out_field=AtomicDataDict.TOTAL_ENERGY_KEY))
+
+    _plan_fusions(convnets, edge_norm, readout, scale_shift, readout_mlp_hidden_layers_depth)
+    return ForceStressOutput(SequentialGraphNetwork(chain.modules), do_derivatives)
+
+
+class _Chain:
+    """The module sequence under construction: ``add(name, factory)`` builds the next module from the irreps the previous
+    one leaves behind (names and order are the reference's: they are the state-dict keys)."""
+
+    def __init__(self):
+        self.modules = {}
+        self._irreps = None
+
+    def add(self, name: str, factory):
+        module = factory(self._irreps)
+        self.modules[name] = module
+        self._irreps = module.irreps_out
+        return module
+
+
+def _plan_fusions(convnets, edge_norm, readout, scale_shift, readout_depth: int) -> None:
+    """What the eval-mode GPU path may fuse across module boundaries (none of it changes a module's parameters or keys):
+
+    * a Gate between two convolution layers is consumed by the next layer's ``linear_1`` / self-connection only, so it may be
+      folded into them (``ConvNetLayer.defer_gate`` -> ``o3/_node_kernels.py::fused_node_stage``);
+    * the last layer's Gate, a depth-0 readout and the scale / shift run as one launch per direction (``nn/_energy_head.py``);
+      the readout finds the scale / shift module through a plain list entry -- no second registration, no new keys;
+    * asymmetric per-edge-type cutoffs (cutoff(A <- B) != cutoff(B <- A)): the two directed edges of a pair no longer share
+      their radial weights, the reverse-edge pairing is switched off."""
+    for layer in convnets[:-1]:
+        layer.defer_gate = True
+    if readout_depth == 0:
+        readout.__dict__["_scale_shift"] = [scale_shift]
+        convnets[-1].defer_gate = True
+    if not edge_norm.symmetric:
+        for layer in convnets:
+            layer.conv.paired_radial_ok = False
