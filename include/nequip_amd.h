@@ -394,6 +394,9 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
  *   for nqa_gate).  Gated blocks need d >= 3; gated / activated blocks need offsets, multiplicities and row widths that
  *   are multiples of 4 (NQA_ERR_INVALID otherwise: the caller keeps the separate launches).  Float32, fp16-split packing
  *   (NQA_ERR_UNSUPPORTED under NQA_NODE_F16=0); at most 48 merged instructions; tables are HOST pointers.
+ *   atom_order (optional, int32 [N], device): the order in which the work units walk the atoms -- ANY permutation gives the
+ *   same results; a unit skips the typed stages of atom types none of its atoms has, so an order that groups the atoms by
+ *   type makes the typed self-connection (at most 16 types) one pass per atom instead of one per type.
  * nqa_node_fused_plan: the merged tables of such a launch, for host-side tests -- chunk records of 12 int32 {o_off, d,
  *   mul_out, c0, instr_begin, instr_end, dst, epilogue (0 plain, 1 scalar block, 2 gated block of the output gate), ev_off,
  *   eg_off, act, cst (float bits)}, instruction records of 8 int32 {x_off, mul_in, frag_off, exp_off, gate_off (>= 0 gate
@@ -418,9 +421,9 @@ typedef struct nqa_node_part {
   int32_t n_in_gate, pad;
 } nqa_node_part;
 
-int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* atom_types, int64_t num_nodes,
-                   const nqa_gate_block* out_gate, int32_t n_out_gate, const void* gate_h, int32_t gate_dim,
-                   nqa_stream stream);
+int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* atom_types, const int32_t* atom_order,
+                   int64_t num_nodes, const nqa_gate_block* out_gate, int32_t n_out_gate, const void* gate_h,
+                   int32_t gate_dim, nqa_stream stream);
 int nqa_node_fused_plan(const nqa_node_part* parts, int32_t n_parts, const nqa_gate_block* out_gate, int32_t n_out_gate,
                         int32_t* chunks_out, int32_t chunks_cap, int32_t* instr_out, int32_t instr_cap);
 

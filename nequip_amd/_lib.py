@@ -202,7 +202,7 @@ SIGNATURES = {
         + [c_int64, c_double, c_void_p],
     ),
     "nqa_node_fused": (
-        c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p],
+        c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p],
     ),
     "nqa_node_fused_plan": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, _P32, c_int32, _P32, c_int32]),
     "nqa_radial_mlp_last_fwd": (

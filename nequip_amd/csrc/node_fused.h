@@ -61,6 +61,9 @@ struct NodeFusedArgs {
   NFDst dsts[2];
   const float* __restrict__ h;  // epilogue operand (pre-gate rows of the gate whose backward the epilogue applies)
   const int64_t* __restrict__ types;
+  // optional: the order in which the units walk the atoms (row r of the launch is atom perm[r]).  ANY permutation gives the
+  // same results; one that groups the atoms by type lets a unit skip the typed stages of the types it does not hold.
+  const int32_t* __restrict__ perm;
   int64_t N;
   int32_t hdim, n_chunks, n_groups, pad;
   NFChunk chunks[kNFMaxChunks];
@@ -125,9 +128,21 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
   const int zl = min(zlr, NZT - 1);
   const int cw = min(kNLW, ch.mul_out - ch.c0);
   const int64_t zbase = g * NZT;
-  const int64_t z = zbase + zl;
-  const bool col_ok = (zlr < NZT) && (z < a.N);
+  // row r of this launch -> atom (clamped rows: unconditional loads from valid addresses)
+  auto atom = [&](int64_t r) __attribute__((always_inline)) -> int64_t {
+    const int64_t rc = r < a.N ? r : a.N - 1;
+    return a.perm != nullptr ? (int64_t)a.perm[rc] : rc;
+  };
+  const bool col_ok = (zlr < NZT) && (zbase + zl < a.N);
+  const int64_t z = atom(zbase + zl);
   const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
+  // atom types present in this unit (typed operand sets have at most 16 types): the stages of absent types are skipped
+  unsigned present = 0xffffu;
+  if (a.types != nullptr) {
+    present = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) present |= (__any(col_ok && tzj == t) ? 1u : 0u) << t;
+  }
   const int nct = (ch.mul_out + 31) / 32;
   const int ct0 = ch.c0 / 32;
   const bool two_tiles = cw > 32;
@@ -156,11 +171,25 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     st.din = s.din;
     st.xp = s.x;
   };
+  // (st.k0 == 0) move on to the next (instruction, type) whose type some atom of this unit has
+  auto settle = [&](NFStage st) __attribute__((always_inline)) {
+    while (st.valid && st.n_types > 1) {
+      while (st.t < st.n_types && ((present >> st.t) & 1u) == 0u) ++st.t;
+      if (st.t < st.n_types) break;
+      st.t = 0;
+      if (++st.q < ch.instr_end) fill(st);
+      else st.valid = false;
+    }
+    return st;
+  };
   auto first_stage = [&]() __attribute__((always_inline)) {
     NFStage st{};
     st.q = ch.instr_begin;
     st.valid = ch.instr_begin < ch.instr_end;
-    if (st.valid) fill(st);
+    if (st.valid) {
+      fill(st);
+      st = settle(st);
+    }
     return st;
   };
   auto next_stage = [&](NFStage st) __attribute__((always_inline)) {
@@ -173,6 +202,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         if (++st.q < ch.instr_end) fill(st);
         else st.valid = false;
       }
+      st = settle(st);
     }
     return st;
   };
@@ -184,14 +214,14 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     if (((st.din | st.x_off | kk) & 3) == 0) {
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int64_t zg = atom(zbase + min(xz[v], NZT - 1));
         const int eo = min(xo[v], kk - 4);
         xr[v] = *reinterpret_cast<const float4*>(xb0 + zg * st.din + eo);
       }
     } else {
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int64_t zg = atom(zbase + min(xz[v], NZT - 1));
         const float* __restrict__ p = xb0 + zg * st.din;
         xr[v].x = p[min(xo[v] + 0, kk - 1)];
         xr[v].y = p[min(xo[v] + 1, kk - 1)];
@@ -242,7 +272,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         for (int v = 0; v < XG4; ++v) {
           const int idx = lane + v * 64;
           const int gz = idx / GQ, go = (idx - gz * GQ) * 4;
-          const int64_t zg = min(zbase + min(gz, NZT - 1), a.N - 1);
+          const int64_t zg = atom(zbase + min(gz, NZT - 1));
           gr[v] = *reinterpret_cast<const float4*>(gb0 + zg * st.din + min(go, kc - 4));
         }
       }
@@ -469,8 +499,9 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
       const int idx = lane + v * 64;
       const int ez = idx / RUN4E;
       const int eo = (idx - ez * RUN4E) * 4;
-      const int64_t zg = zbase + ez;
+      const int64_t zr = zbase + ez;  // row of the launch
       if (ez >= NZT) continue;
+      const int64_t zg = atom(zr);
       const float* __restrict__ sp = xs + ez * SE + eo;
       const int64_t o = zg * dst.dout + ch.o_off + (int64_t)ch.c0 * D + eo;
       if (fast) {
@@ -481,7 +512,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
           r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
         }
         *reinterpret_cast<float4*>(dst.out + o) = r;
-      } else if (zg < a.N && eo < run) {
+      } else if (zr < a.N && eo < run) {
         float4 r;
         if constexpr (kVecE) {
           r = *reinterpret_cast<const float4*>(sp);
@@ -510,8 +541,8 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
       const int idx = lane + v * 64;
       const int ez = idx / RUN4E;
       const int eo = (idx - ez * RUN4E) * 4;
-      const int64_t zg = zbase + ez;
-      if (ez >= NZT || zg >= a.N || eo >= run) continue;
+      if (ez >= NZT || zbase + ez >= a.N || eo >= run) continue;
+      const int64_t zg = atom(zbase + ez);
       const float* __restrict__ sp = xs + ez * SE + eo;
       float4 r;
       if constexpr (kVecE) {
@@ -538,8 +569,8 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         const int idx = lane + it * 64;
         const int ez = idx / NG;
         const int u0 = (idx - ez * NG) * 4;
-        const int64_t zg = zbase + ez;
-        if (ez >= NZT || zg >= a.N || u0 >= cw) continue;
+        if (ez >= NZT || zbase + ez >= a.N || u0 >= cw) continue;
+        const int64_t zg = atom(zbase + ez);
         const float* __restrict__ sp = xs + ez * SE + u0 * D;
         const float* __restrict__ hrow = a.h + zg * a.hdim;
         float* __restrict__ orow = dst.out + zg * dst.dout;
@@ -759,9 +790,9 @@ std::string nf_plan(const nqa_node_part* parts, int32_t n_parts, const nqa_gate_
 
 extern "C" {
 
-int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* atom_types, int64_t num_nodes,
-                   const nqa_gate_block* out_gate, int32_t n_out_gate, const void* gate_h, int32_t gate_dim,
-                   nqa_stream stream) {
+int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* atom_types, const int32_t* atom_order,
+                   int64_t num_nodes, const nqa_gate_block* out_gate, int32_t n_out_gate, const void* gate_h,
+                   int32_t gate_dim, nqa_stream stream) {
   using namespace nqa;
   if (!node_f16()) {
     set_error("nqa_node_fused: needs the two-plane fp16 weight packing (NQA_NODE_F16=0 is set)");
@@ -784,6 +815,10 @@ int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* a
     if (!pt.x || !pt.packed || (pt.n_types > 1 && atom_types == nullptr)) {
       set_error("nqa_node_fused: NULL operand");
       return NQA_ERR_INVALID;
+    }
+    if (pt.n_types > 16) {
+      set_error("nqa_node_fused: at most 16 atom types per typed operand set");
+      return NQA_ERR_UNSUPPORTED;
     }
     int32_t fo[kMaxNodeInstr + 1], mo[kMaxNodeInstr], eo[kMaxNodeInstr + 1];
     const int64_t per_type = node_frag_layout(static_cast<const NodeChunk*>(pt.chunk_table), pt.n_chunks,
@@ -816,6 +851,7 @@ int nqa_node_fused(const nqa_node_part* parts, int32_t n_parts, const int64_t* a
   a.h = static_cast<const float*>(gate_h);
   a.hdim = gate_dim;
   a.types = atom_types;
+  a.perm = atom_order;
   a.N = num_nodes;
   std::memcpy(a.instr, P.instr.data(), sizeof(NFInstr) * P.instr.size());
   const int n_chunks = (int)P.chunks.size();

@@ -442,9 +442,26 @@ def _fill_part(cp, part: FusedPart, out, keep: list):
         cp.n_in_gate = 0
 
 
-def launch_fused(parts: Sequence[FusedPart], types, out_gate: Optional[GateMeta] = None, gate_h=None) -> List[torch.Tensor]:
+_TYPE_ORDER: dict = {}
+
+
+def type_order(types: torch.Tensor) -> torch.Tensor:
+    """A permutation of the atoms that groups them by type (int32, stable), for the ``atom_order`` operand of
+    ``nqa_node_fused``.  ANY permutation gives the same results there (a unit skips the types it does not hold), so the cache
+    -- keyed on the type tensor's memory and version, a few entries -- can at worst cost speed, never correctness."""
+    key = (types.data_ptr(), types._version, types.numel(), str(types.device))
+    hit = _TYPE_ORDER.get(key)
+    if hit is None:
+        if len(_TYPE_ORDER) >= 8:
+            _TYPE_ORDER.clear()
+        hit = _TYPE_ORDER[key] = torch.argsort(types.view(-1), stable=True).to(torch.int32).contiguous()
+    return hit
+
+
+def launch_fused(parts: Sequence[FusedPart], types, out_gate: Optional[GateMeta] = None, gate_h=None,
+                 order: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """``nqa_node_fused``: returns the destination tensors (one per non-accumulating part).  With ``out_gate`` the single
-    destination is the gradient w.r.t. the gate's input rows ``gate_h``."""
+    destination is the gradient w.r.t. the gate's input rows ``gate_h``.  ``order``: optional int32 ``[N]`` atom order."""
     lib = _lib.load()
     x0 = parts[0].x
     N, dev = x0.shape[0], x0.device
@@ -474,8 +491,11 @@ def launch_fused(parts: Sequence[FusedPart], types, out_gate: Optional[GateMeta]
     else:
         og, nog, gh, gdim = None, 0, None, 0
     tp = _ptr(types) if types is not None else ctypes.c_void_p()
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == N and order.is_contiguous() and order.device == dev
     with torch.cuda.device(dev), ktimer.region("node_fused", nbytes, flops):
-        rc = lib.nqa_node_fused(ctypes.cast(cparts, ctypes.c_void_p), len(parts), tp, N, og, nog, gh, gdim, _stream(dev))
+        rc = lib.nqa_node_fused(ctypes.cast(cparts, ctypes.c_void_p), len(parts), tp, _ptr(order), N, og, nog, gh, gdim,
+                                _stream(dev))
     _lib.check(rc, "nqa_node_fused")
     return outs
 
@@ -501,7 +521,10 @@ class _FusedNodeStageFn(torch.autograd.Function):
         parts = [FusedPart(h, wp1, meta1, scale1, in_gate=gate_meta)]
         if wps is not None:
             parts.append(FusedPart(h, wps, metas, 1.0, in_gate=gate_meta))
-        outs = launch_fused(parts, types if wps is not None and wps.shape[0] > 1 else None)
+        typed = wps is not None and wps.shape[0] > 1
+        # typed self-connection: the units walk the atoms grouped by type, so a unit stages one type's weights, not all
+        ctx.order = type_order(types) if (typed and os.environ.get("NQA_NODE_TYPE_ORDER", "") != "0") else None
+        outs = launch_fused(parts, types if typed else None, order=ctx.order)
         ctx.save_for_backward(h, types, wp1, wps)
         ctx.gate_meta, ctx.meta1, ctx.metas, ctx.scale1 = gate_meta, meta1, metas, scale1
         return (outs[0], outs[1]) if wps is not None else (outs[0], None)
@@ -520,10 +543,11 @@ class _FusedNodeStageFn(torch.autograd.Function):
         if wps is not None and gs is not None:
             parts.append(FusedPart(gs.contiguous(), meta_transposed_weights(metas, wps), _transposed(metas), accumulate=True))
         typed = len(parts) > 1 and wps.shape[0] > 1
+        order = ctx.order if typed else None
         if gate_meta is not None:
-            (gh,) = launch_fused(parts, types if typed else None, out_gate=gate_meta, gate_h=h)
+            (gh,) = launch_fused(parts, types if typed else None, out_gate=gate_meta, gate_h=h, order=order)
         else:
-            (gh,) = launch_fused(parts, types if typed else None)
+            (gh,) = launch_fused(parts, types if typed else None, order=order)
         return gh, None, None, None, None, None, None, None
 
 

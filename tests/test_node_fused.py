@@ -327,3 +327,43 @@ def test_model_runs_the_energy_head_and_matches_the_module_chain(device, monkeyp
     torch.testing.assert_close(out["atomic_energy"], ref["atomic_energy"], atol=1e-5, rtol=1e-6)
     torch.testing.assert_close(out["total_energy"], ref["total_energy"], atol=1e-5 * len(pos), rtol=1e-6)
     torch.testing.assert_close(out["forces"], ref["forces"], atol=3e-6 * max(1.0, float(ref["forces"].abs().max())), rtol=0)
+
+
+@pytest.mark.gpu
+def test_atom_order_is_free_and_type_grouping_skips_stages(device, monkeypatch):
+    """``atom_order`` of ``nqa_node_fused``: any permutation gives the results of the natural order (bitwise: the same
+    arithmetic per atom); the default groups the atoms by type, which only changes which typed stages a unit runs."""
+    torch.manual_seed(5)
+    gate, lin1, sc = _layer("64x0e+64x1o+64x2e")
+    gate, lin1, sc = gate.to(device).eval(), lin1.to(device).eval(), sc.to(device).eval()
+    gm = gate._kernel_meta
+    n, n_types = 997, 5
+    h = torch.randn(n, gm.din, device=device)
+    types = torch.randint(0, n_types, (n,), device=device)
+    table = torch.randn(n_types, 8, device=device)
+    wp1 = lin1.eval_weights(device, torch.float32)
+    wps = sc.eval_weights_typed(table, torch.float32)
+
+    def run(order):
+        parts = [nk.FusedPart(h, wp1, lin1._meta, 0.2, in_gate=gm), nk.FusedPart(h, wps, sc._meta, 1.0, in_gate=gm)]
+        return nk.launch_fused(parts, types, order=order)
+
+    ref = run(None)
+    for order in (nk.type_order(types), torch.randperm(n, device=device).to(torch.int32),
+                  torch.arange(n - 1, -1, -1, device=device, dtype=torch.int32)):
+        assert sorted(order.tolist()) == list(range(n))
+        out = run(order.contiguous())
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    srt = types[nk.type_order(types).long()]
+    assert bool((srt[1:] >= srt[:-1]).all())
+    # backward with the output gate, both orders
+    g1, gs = torch.randn(n, gm.dout, device=device), torch.randn(n, gm.din, device=device)
+    t1, ts = nk._transposed(lin1._meta), nk._transposed(sc._meta)
+
+    def run_bwd(order):
+        parts = [nk.FusedPart(g1, nk.meta_transposed_weights(lin1._meta, wp1), t1),
+                 nk.FusedPart(gs, nk.meta_transposed_weights(sc._meta, wps), ts, accumulate=True)]
+        return nk.launch_fused(parts, types, out_gate=gm, gate_h=h, order=order)[0]
+
+    assert torch.equal(run_bwd(nk.type_order(types)), run_bwd(None))
