@@ -155,6 +155,13 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     xo[v] = (idx - xz[v] * RUN4) * 4;
   }
   auto slot_ok = [&](int v) __attribute__((always_inline)) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
+  // the atoms whose rows this lane stages, looked up ONCE per unit (with an atom order the row index is a load: inside the
+  // stage loop it would put a memory round trip in front of every slab request)
+  int zrow_x[XV4], zrow_g[XG4];
+#pragma unroll
+  for (int v = 0; v < XV4; ++v) zrow_x[v] = (int)atom(zbase + min(xz[v], NZT - 1));
+#pragma unroll
+  for (int v = 0; v < XG4; ++v) zrow_g[v] = (int)atom(zbase + min((lane + v * 64) / GQ, NZT - 1));
 
   auto fill = [&](NFStage& st) __attribute__((always_inline)) {
     const NFInstr& in = a.instr[__builtin_amdgcn_readfirstlane(st.q)];  // (scalar index: the tables stay in the kernel-argument segment)
@@ -214,14 +221,14 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
     if (((st.din | st.x_off | kk) & 3) == 0) {
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = atom(zbase + min(xz[v], NZT - 1));
+        const int64_t zg = zrow_x[v];
         const int eo = min(xo[v], kk - 4);
         xr[v] = *reinterpret_cast<const float4*>(xb0 + zg * st.din + eo);
       }
     } else {
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = atom(zbase + min(xz[v], NZT - 1));
+        const int64_t zg = zrow_x[v];
         const float* __restrict__ p = xb0 + zg * st.din;
         xr[v].x = p[min(xo[v] + 0, kk - 1)];
         xr[v].y = p[min(xo[v] + 1, kk - 1)];
@@ -272,7 +279,7 @@ __device__ __forceinline__ void node_fused_unit(const NodeFusedArgs& a, const NF
         for (int v = 0; v < XG4; ++v) {
           const int idx = lane + v * 64;
           const int gz = idx / GQ, go = (idx - gz * GQ) * 4;
-          const int64_t zg = atom(zbase + min(gz, NZT - 1));
+          const int64_t zg = zrow_g[v];
           gr[v] = *reinterpret_cast<const float4*>(gb0 + zg * st.din + min(go, kc - 4));
         }
       }
