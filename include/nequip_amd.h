@@ -348,6 +348,15 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
                     int32_t n_instr, int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out,
                     int64_t num_nodes, double scale, int32_t chunk_width, nqa_stream stream);
+/* ... _ordered: the same launch with an atom order (int32 [N] device pointer, may be NULL; float32 MFMA kernels only): the
+ *   work units walk the atoms in that order and skip the typed stages of atom types none of their atoms has.  ANY permutation
+ *   gives the same results; one that groups the atoms by type makes a typed map (the self-connection: one weight set per
+ *   atom type) one pass per atom instead of one per type. */
+int nqa_node_linear_ordered(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
+                            const int64_t* atom_types, const int32_t* atom_order, const void* chunk_table, int32_t n_chunks,
+                            const void* instr_table, int32_t n_instr, int32_t n_types, int64_t weight_stride,
+                            int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale, int32_t chunk_width,
+                            nqa_stream stream);
 int nqa_gate(int32_t dtype, int32_t backward, const void* input, const void* grad_out, const void* cotangent,
              void* out, const void* col_table, int32_t dim_in, int32_t dim_out, int64_t num_nodes, nqa_stream stream);
 
@@ -374,6 +383,10 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
                            const void* chunk_table, int32_t n_chunks, const void* instr_table, int32_t n_instr,
                            int32_t n_types, int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale,
                            nqa_stream stream);
+int nqa_node_linear_packed_ordered(const void* x, const void* packed, const void* addend, void* out,
+                                   const int64_t* atom_types, const int32_t* atom_order, const void* chunk_table,
+                                   int32_t n_chunks, const void* instr_table, int32_t n_instr, int32_t n_types,
+                                   int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale, nqa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The node side of a layer boundary in one launch per direction.  Between two tensor products the reference runs

@@ -201,6 +201,16 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32]
         + [c_int64, c_double, c_void_p],
     ),
+    "nqa_node_linear_ordered": (
+        c_int32,
+        [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32,
+         c_int64, c_int32, c_int32, c_int64, c_double, c_int32, c_void_p],
+    ),
+    "nqa_node_linear_packed_ordered": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32]
+        + [c_int32, c_int64, c_double, c_void_p],
+    ),
     "nqa_node_fused": (
         c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_void_p],
     ),

@@ -47,6 +47,10 @@ struct NodeLinearArgs {
   const T* __restrict__ addend;  // optional [N, dout]
   T* __restrict__ out;
   const int64_t* __restrict__ types;  // optional [N]
+  // optional [N] (per-wavefront MFMA kernels): the order in which the units walk the atoms -- row r of the launch is atom
+  // perm[r].  Any permutation gives the same results; one that groups the atoms by type lets a unit skip the typed stages of
+  // the types it does not hold (node_fused.h)
+  const int32_t* __restrict__ perm;
   int32_t n_chunks, n_types, din, dout;
   int32_t dbg;  // ablation switches (NQA_NODE_DBG), 0 in production
   int64_t wstride;
@@ -235,16 +239,27 @@ __device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float
   const int cw = min(kNLW, ch.mul_out - ch.c0);
   const int cj0 = min(j, cw - 1), cj1 = min(j + 32, cw - 1);  // clamped weight columns (rows >= cw are never stored)
   const int64_t zbase = g * NZT;
-  const int64_t z = zbase + zl;
-  const bool col_ok = (zlr < NZT) && (z < a.N);
+  auto atom = [&](int64_t r) -> int64_t {  // row of the launch -> atom (clamped rows: loads from valid addresses)
+    const int64_t rc = r < a.N ? r : a.N - 1;
+    return a.perm != nullptr ? (int64_t)a.perm[rc] : rc;
+  };
+  const bool col_ok = (zlr < NZT) && (zbase + zl < a.N);
+  const int64_t z = atom(zbase + zl);
   const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
+  // atom types this unit holds (bit t; types beyond 31 always count as present): stages of absent types are skipped
+  unsigned present = 0xffffffffu;
+  if (a.types != nullptr && a.n_types > 1 && a.n_types <= 32) {
+    present = 0;
+    for (int tt = 0; tt < a.n_types; ++tt) present |= (__any(col_ok && tzj == tt) ? 1u : 0u) << tt;
+  }
 
-  int xz[XV4], xo[XV4];
+  int xz[XV4], xo[XV4], zrow[XV4];
 #pragma unroll
   for (int v = 0; v < XV4; ++v) {
     const int idx = lane + v * 64;
     xz[v] = idx / RUN4;
     xo[v] = (idx - xz[v] * RUN4) * 4;
+    zrow[v] = (int)atom(zbase + min(xz[v], NZT - 1));  // (looked up once per unit, not per stage)
   }
   auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
 
@@ -254,6 +269,15 @@ __device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float
     // falls through to the epilogue with zero accumulators
   }
   NodeInstr ins = q < ch.instr_end ? a.instr[q] : NodeInstr{0, 0, 0, 0};
+  auto settle = [&]() {  // (k0 == 0) on to the next (instruction, type) whose type some atom of this unit has
+    while (q < ch.instr_end && a.n_types > 1) {
+      while (t < a.n_types && t < 32 && ((present >> t) & 1u) == 0u) ++t;
+      if (t < a.n_types) break;
+      t = 0;
+      if (++q < ch.instr_end) ins = a.instr[q];
+    }
+  };
+  settle();
   auto advance = [&]() {
     k0 += kNLK2;
     if (k0 >= ins.mul_in) {
@@ -262,6 +286,7 @@ __device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float
         t = 0;
         if (++q < ch.instr_end) ins = a.instr[q];
       }
+      settle();
     }
     return q < ch.instr_end;
   };
@@ -281,14 +306,14 @@ __device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float
     if (xal_all && ((si.x_off | kk) & 3) == 0) {  // wave-uniform: aligned runs, whole float4s
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int64_t zg = zrow[v];
         const int eo = min(xo[v], kk - 4);
         xreg[v] = *reinterpret_cast<const float4*>(xb0 + zg * a.din + eo);
       }
     } else {  // odd multiplicities / unaligned blocks: dword loads, each clamped on its own
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int64_t zg = zrow[v];
         const float* __restrict__ p = xb0 + zg * a.din;
         xreg[v].x = p[min(xo[v] + 0, kk - 1)];
         xreg[v].y = p[min(xo[v] + 1, kk - 1)];
@@ -383,8 +408,9 @@ __device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float
     const int idx = lane + v * 64;
     const int ez = idx / RUN4E;
     const int eo = (idx - ez * RUN4E) * 4;
-    const int64_t zg = zbase + ez;
+    const int64_t zr = zbase + ez;  // row of the launch
     if (ez >= NZT) continue;
+    const int64_t zg = atom(zr);
     const float* __restrict__ sp = xs + ez * SE + eo;
     const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + eo;
     if (fast) {
@@ -395,7 +421,7 @@ __device__ __forceinline__ void node_linear_wave_unit(const NodeLinearArgs<float
         r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
       }
       *reinterpret_cast<float4*>(a.out + o) = r;
-    } else if (zg < a.N && eo < run) {
+    } else if (zr < a.N && eo < run) {
       float4 r;
       if constexpr (kVecE) {
         r = *reinterpret_cast<const float4*>(sp);
@@ -637,28 +663,53 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
   const int zl = min(zlr, NZT - 1);
   const int cw = min(kNLW, ch.mul_out - ch.c0);
   const int64_t zbase = g * NZT;
-  const int64_t z = zbase + zl;
-  const bool col_ok = (zlr < NZT) && (z < a.N);
+  auto atom = [&](int64_t r) -> int64_t {  // row of the launch -> atom (clamped rows: loads from valid addresses)
+    const int64_t rc = r < a.N ? r : a.N - 1;
+    return a.perm != nullptr ? (int64_t)a.perm[rc] : rc;
+  };
+  const bool col_ok = (zlr < NZT) && (zbase + zl < a.N);
+  const int64_t z = atom(zbase + zl);
   const int tzj = (a.types != nullptr && col_ok) ? (int)a.types[z] : 0;
+  unsigned present = 0xffffffffu;  // atom types this unit holds: stages of absent types are skipped
+  if (a.types != nullptr && a.n_types > 1 && a.n_types <= 32) {
+    present = 0;
+    for (int tt = 0; tt < a.n_types; ++tt) present |= (__any(col_ok && tzj == tt) ? 1u : 0u) << tt;
+  }
   const int nct = (ch.mul_out + 31) / 32;   // column tiles of the whole output block
   const int ct0 = ch.c0 / 32;               // first tile of this chunk (c0 is a multiple of 64)
   const bool two_tiles = cw > 32;           // wave-uniform
 
-  int xz[XV4], xo[XV4];
+  int xz[XV4], xo[XV4], zrow[XV4];
 #pragma unroll
   for (int v = 0; v < XV4; ++v) {
     const int idx = lane + v * 64;
     xz[v] = idx / RUN4;
     xo[v] = (idx - xz[v] * RUN4) * 4;
+    zrow[v] = (int)atom(zbase + min(xz[v], NZT - 1));  // (looked up once per unit, not per stage)
   }
   auto slot_ok = [&](int v) { return (v + 1) * 64 <= NZT * RUN4 || xz[v] < NZT; };
 
   // stage enumeration
+  auto settle = [&](NodeStage st) {  // (st.k0 == 0) on to the next (instruction, type) whose type this unit holds
+    while (st.valid && a.n_types > 1) {
+      while (st.t < a.n_types && st.t < 32 && ((present >> st.t) & 1u) == 0u) ++st.t;
+      if (st.t < a.n_types) break;
+      st.t = 0;
+      if (++st.q < ch.instr_end) {
+        st.mul_in = a.instr[st.q].mul_in;
+        st.x_off = a.instr[st.q].x_off;
+      } else {
+        st.valid = false;
+      }
+    }
+    return st;
+  };
   auto first_stage = [&]() {
     NodeStage st{ch.instr_begin, 0, 0, 0, 0, ch.instr_begin < ch.instr_end};
     if (st.valid) {
       st.mul_in = a.instr[st.q].mul_in;
       st.x_off = a.instr[st.q].x_off;
+      st = settle(st);
     }
     return st;
   };
@@ -676,6 +727,7 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
           st.valid = false;
         }
       }
+      st = settle(st);
     }
     return st;
   };
@@ -692,14 +744,14 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
     if (xal_all && ((st.x_off | kk) & 3) == 0) {
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int64_t zg = zrow[v];
         const int eo = min(xo[v], kk - 4);
         xr[v] = *reinterpret_cast<const float4*>(xb0 + zg * a.din + eo);
       }
     } else {
 #pragma unroll
       for (int v = 0; v < XV4; ++v) {
-        const int64_t zg = min(zbase + min(xz[v], NZT - 1), a.N - 1);
+        const int64_t zg = zrow[v];
         const float* __restrict__ p = xb0 + zg * a.din;
         xr[v].x = p[min(xo[v] + 0, kk - 1)];
         xr[v].y = p[min(xo[v] + 1, kk - 1)];
@@ -981,8 +1033,9 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
     const int idx = lane + v * 64;
     const int ez = idx / RUN4E;
     const int eo = (idx - ez * RUN4E) * 4;
-    const int64_t zg = zbase + ez;
+    const int64_t zr = zbase + ez;  // row of the launch
     if (ez >= NZT) continue;
+    const int64_t zg = atom(zr);
     const float* __restrict__ sp = xs + ez * SE + eo;
     const int64_t o = zg * a.dout + ch.o_off + (int64_t)ch.c0 * D + eo;
     if (fast) {
@@ -993,7 +1046,7 @@ __device__ __forceinline__ void node_linear_wave_bf16_unit(const NodeLinearPacke
         r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
       }
       *reinterpret_cast<float4*>(a.out + o) = r;
-    } else if (zg < a.N && eo < run) {
+    } else if (zr < a.N && eo < run) {
       float4 r;
       if constexpr (kVecE) {
         r = *reinterpret_cast<const float4*>(sp);
@@ -1256,6 +1309,15 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
                     const int64_t* atom_types, const void* chunk_table, int32_t n_chunks, const void* instr_table,
                     int32_t n_instr, int32_t n_types, int64_t weight_stride, int32_t dim_in, int32_t dim_out, int64_t num_nodes,
                     double scale, int32_t chunk_width, nqa_stream stream) {
+  return nqa_node_linear_ordered(dtype, x, weights, addend, out, atom_types, nullptr, chunk_table, n_chunks, instr_table,
+                                 n_instr, n_types, weight_stride, dim_in, dim_out, num_nodes, scale, chunk_width, stream);
+}
+
+int nqa_node_linear_ordered(int32_t dtype, const void* x, const void* weights, const void* addend, void* out,
+                            const int64_t* atom_types, const int32_t* atom_order, const void* chunk_table, int32_t n_chunks,
+                            const void* instr_table, int32_t n_instr, int32_t n_types, int64_t weight_stride,
+                            int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale, int32_t chunk_width,
+                            nqa_stream stream) {
   // 64-channel chunk tables serve both kernels: float32 runs on fp32 MFMA (chunk_width 64) or, on request
   // (chunk_width -64), on the VALU kernel that also serves float64
   const bool use_mfma = dtype == NQA_F32 && chunk_width == 64;
@@ -1276,9 +1338,9 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     // records are self-contained (absolute offsets / instruction ranges)
     for (int32_t c0 = 0; c0 < n_chunks; c0 += kMaxNodeChunks) {
       const int32_t nc = n_chunks - c0 < kMaxNodeChunks ? n_chunks - c0 : kMaxNodeChunks;
-      const int rc = nqa_node_linear(dtype, x, weights, addend, out, atom_types,
-                                     static_cast<const NodeChunk*>(chunk_table) + c0, nc, instr_table, n_instr, n_types,
-                                     weight_stride, dim_in, dim_out, num_nodes, scale, chunk_width, stream);
+      const int rc = nqa_node_linear_ordered(dtype, x, weights, addend, out, atom_types, atom_order,
+                                             static_cast<const NodeChunk*>(chunk_table) + c0, nc, instr_table, n_instr,
+                                             n_types, weight_stride, dim_in, dim_out, num_nodes, scale, chunk_width, stream);
       if (rc != NQA_OK) return rc;
     }
     return NQA_OK;
@@ -1306,6 +1368,7 @@ int nqa_node_linear(int32_t dtype, const void* x, const void* weights, const voi
     a.addend = static_cast<const float*>(addend);
     a.out = static_cast<float*>(out);
     a.types = n_types > 1 ? atom_types : nullptr;
+    a.perm = use_mfma ? atom_order : nullptr;  // (the VALU kernel keeps the natural order)
     std::memcpy(a.chunks, chunk_table, sizeof(NodeChunk) * (size_t)n_chunks);
     if (n_instr > 0) std::memcpy(a.instr, instr_table, sizeof(NodeInstr) * (size_t)n_instr);
     a.n_chunks = n_chunks;
@@ -1498,6 +1561,14 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
                            const void* chunk_table, int32_t n_chunks, const void* instr_table, int32_t n_instr,
                            int32_t n_types, int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale,
                            nqa_stream stream) {
+  return nqa_node_linear_packed_ordered(x, packed, addend, out, atom_types, nullptr, chunk_table, n_chunks, instr_table,
+                                        n_instr, n_types, dim_in, dim_out, num_nodes, scale, stream);
+}
+
+int nqa_node_linear_packed_ordered(const void* x, const void* packed, const void* addend, void* out,
+                                   const int64_t* atom_types, const int32_t* atom_order, const void* chunk_table,
+                                   int32_t n_chunks, const void* instr_table, int32_t n_instr, int32_t n_types,
+                                   int32_t dim_in, int32_t dim_out, int64_t num_nodes, double scale, nqa_stream stream) {
   using namespace nqa;
   if (n_instr < 0 || n_instr > kMaxNodeInstr || num_nodes < 0 || n_chunks < 0 || n_types < 1 || dim_in <= 0 ||
       dim_out <= 0 || (num_nodes > 0 && (!x || !packed || !out || !chunk_table || (n_instr > 0 && !instr_table))) ||
@@ -1526,6 +1597,7 @@ int nqa_node_linear_packed(const void* x, const void* packed, const void* addend
   a.addend = static_cast<const float*>(addend);
   a.out = static_cast<float*>(out);
   a.types = n_types > 1 ? atom_types : nullptr;
+  a.perm = atom_order;
   if (n_instr > 0) std::memcpy(a.instr, instr, sizeof(NodeInstr) * (size_t)n_instr);
   for (int q = 0; q < n_instr; ++q) a.instr[q].pad = exp_off[q];  // (F16: first exponent of the instruction)
   a.n_types = n_types;

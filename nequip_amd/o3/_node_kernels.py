@@ -160,23 +160,30 @@ def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale
     flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
     # (weights that are part of an autograd graph -- training -- change every step: the exact-fp32 kernel reads them as
     # they are, packing them per call would cost a launch per module and direction)
+    # a typed map (one weight set per atom type) walks the atoms grouped by type: a work unit then runs the stages of the
+    # one or two types it holds instead of one masked pass per type (float32 MFMA kernels; any order gives the same result)
+    order = None
+    if (wp.shape[0] > 1 and types is not None and x.dtype == torch.float32
+            and os.environ.get("NQA_NODE_TYPE_ORDER", "") != "0"):
+        order = type_order(types)
     if (x.dtype == torch.float32 and not exact_fp32() and ninstr > 0 and not wp.requires_grad
             and not getattr(wp, "_nqa_volatile", False)):
         wf = packed_weights(wp, meta, which)
         with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
-            rc = lib.nqa_node_linear_packed(
-                _ptr(x), _ptr(wf), _ptr(addend), _ptr(out), _ptr(types), ctypes.cast(ct, ctypes.c_void_p), nchunks,
-                ctypes.cast(it, ctypes.c_void_p), ninstr, wp.shape[0], din, dout, N, float(scale), _stream(x.device),
+            rc = lib.nqa_node_linear_packed_ordered(
+                _ptr(x), _ptr(wf), _ptr(addend), _ptr(out), _ptr(types), _ptr(order),
+                ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p), ninstr, wp.shape[0], din,
+                dout, N, float(scale), _stream(x.device),
             )  # fmt: skip
-        _lib.check(rc, "nqa_node_linear_packed")
+        _lib.check(rc, "nqa_node_linear_packed_ordered")
         return out
     with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
-        rc = lib.nqa_node_linear(
-            _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types),
+        rc = lib.nqa_node_linear_ordered(
+            _dt(x.dtype), _ptr(x), _ptr(wp), _ptr(addend), _ptr(out), _ptr(types), _ptr(order),
             ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p), ninstr,
             wp.shape[0], wp.shape[1], din, dout, N, float(scale), width, _stream(x.device),
         )  # fmt: skip
-    _lib.check(rc, "nqa_node_linear")
+    _lib.check(rc, "nqa_node_linear_ordered")
     return out
 
 

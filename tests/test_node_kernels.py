@@ -220,3 +220,51 @@ def test_node_linear_constant_weight_modes_over_a_wide_dynamic_range(device, mon
         print(label, "max error / magnitude sum:", errs)
         assert all(e < 1e-6 for e in errs.values()), (label, errs)
         assert errs["f16"] < 3 * max(errs["bf16"], errs["fp32"]) + 2e-7, (label, errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16", "fp32"])
+def test_typed_node_linear_atom_order_is_a_pure_schedule(device, monkeypatch, mode):
+    """``nqa_node_linear_ordered`` / ``nqa_node_linear_packed_ordered``: the atom order only decides which atoms share a
+    work unit (and which typed stages that unit can skip) -- natural order, grouped by type, or a random permutation give
+    the same output bit for bit, including a type that no atom has and N not a multiple of the unit."""
+    import ctypes
+
+    from nequip_amd import _lib
+    from nequip_amd.o3._node_kernels import NodeLinearMeta, _launch_linear, _ptr, _stream, packed_weights
+    from nequip_amd.o3.irreps import Irreps
+
+    monkeypatch.setenv("NQA_NODE_EXACT_FP32", "1" if mode == "fp32" else "0")
+    monkeypatch.setenv("NQA_NODE_F16", "1")
+    torch.manual_seed(5)
+    i_in, i_out = Irreps("64x0e+40x1o+24x2e"), Irreps("96x0e+64x1o+16x2e")
+    meta = NodeLinearMeta(i_in, i_out, [(0, 0), (1, 1), (2, 2)])
+    N, T = 1237, 6
+    x = torch.randn(N, i_in.dim, device=device)
+    wp = torch.randn(T, meta.wstride, device=device)
+    types = torch.randint(0, T - 1, (N,), device=device)  # (type T-1 is absent)
+    types[:70] = 3                                         # (a run of units holding one type only)
+
+    monkeypatch.setenv("NQA_NODE_TYPE_ORDER", "0")
+    natural = _launch_linear(x, wp, None, types, meta, "fwd", 0.5)
+    monkeypatch.setenv("NQA_NODE_TYPE_ORDER", "1")
+    grouped = _launch_linear(x, wp, None, types, meta, "fwd", 0.5)
+    assert torch.equal(natural, grouped)
+
+    lib = _lib.load()
+    ct, nchunks, it, ninstr = meta.host_tables("fwd")
+    perm = torch.randperm(N, device=device).to(torch.int32)
+    out = torch.empty_like(natural)
+    if mode == "fp32":
+        rc = lib.nqa_node_linear_ordered(_lib.NQA_F32, _ptr(x), _ptr(wp), None, _ptr(out), _ptr(types), _ptr(perm),
+                                         ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p),
+                                         ninstr, T, wp.shape[1], meta.din, meta.dout, N, 0.5, 64, _stream(x.device))
+    else:
+        wf = packed_weights(wp, meta, "fwd")
+        rc = lib.nqa_node_linear_packed_ordered(_ptr(x), _ptr(wf), None, _ptr(out), _ptr(types), _ptr(perm),
+                                                ctypes.cast(ct, ctypes.c_void_p), nchunks,
+                                                ctypes.cast(it, ctypes.c_void_p), ninstr, T, meta.din, meta.dout, N, 0.5,
+                                                _stream(x.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(natural, out)
