@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes
 import os
 import struct
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -122,17 +123,17 @@ def packed_weights(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.
     """``wp [T, wstride]`` split into 16-bit planes in MFMA-fragment order (``nqa_node_weights_pack``: two fp16 planes of
     power-of-two scaled K blocks by default, three bf16 planes with ``NQA_NODE_F16=0``).  Constant
     weights (eval mode: the modules keep ``wp`` alive across steps) are packed once per version of the tensor; a ``wp``
-    that is part of an autograd graph (training: rebuilt from the parameter every step) is packed per call."""
+    that is part of an autograd graph (training: rebuilt from the parameter every step) is packed once per step."""
     lib = _lib.load()
     ct, nchunks, it, ninstr = meta.host_tables(which)
     key = (id(meta), which, os.environ.get("NQA_NODE_F16", ""))  # (the layout depends on the split the library uses)
-    cache = None
-    if not wp.requires_grad:
-        cache = wp.__dict__.setdefault("_nqa_packed", {}) if hasattr(wp, "__dict__") else None
-        if cache is not None:
-            hit = cache.get(key)
-            if hit is not None and hit[0] == wp._version:
-                return hit[1]
+    # the cache rides on the tensor object: a constant lives as long as its module keeps it; a graph tensor (training) lives
+    # for one step -- autograd hands the same object back from ctx.saved_tensors -- and is used twice per direction in it
+    cache = wp.__dict__.setdefault("_nqa_packed", {}) if hasattr(wp, "__dict__") else None
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == wp._version:
+            return hit[1]
     T = wp.shape[0]
     nbytes = lib.nqa_node_weights_pack_bytes(ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p),
                                              ninstr, T)
@@ -150,6 +151,12 @@ def packed_weights(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.
     return out
 
 
+def train_packed() -> bool:
+    """Opt-in (NQA_NODE_TRAIN_PACKED=1): pack the weights of a training step too.  Measured on train256: the packed kernel
+    is no faster than the exact one at 8192 atoms (0.95 vs 0.94 ms per step) and the 18 pack launches cost 0.25 ms."""
+    return os.environ.get("NQA_NODE_TRAIN_PACKED", "") == "1"
+
+
 def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale: float):
     lib = _lib.load()
     width = 64  # 64-channel chunks: float32 on the MFMA kernels, float64 on the VALU kernel
@@ -159,15 +166,15 @@ def _launch_linear(x, wp, addend, types, meta: NodeLinearMeta, which: str, scale
     out = torch.empty((N, dout), dtype=x.dtype, device=x.device)
     flops = 2.0 * N * sum(c[1] * min(64, c[2] - c[3]) * sum(meta_i[1] for meta_i in (meta.fwd if which == "fwd" else meta.bwd)[1][c[4]:c[5]]) for c in (meta.fwd if which == "fwd" else meta.bwd)[0])
     # (weights that are part of an autograd graph -- training -- change every step: the exact-fp32 kernel reads them as
-    # they are, packing them per call would cost a launch per module and direction)
+    # they are; see train_packed())
     # a typed map (one weight set per atom type) walks the atoms grouped by type: a work unit then runs the stages of the
     # one or two types it holds instead of one masked pass per type (float32 MFMA kernels; any order gives the same result)
     order = None
     if (wp.shape[0] > 1 and types is not None and x.dtype == torch.float32
             and os.environ.get("NQA_NODE_TYPE_ORDER", "") != "0"):
         order = type_order(types)
-    if (x.dtype == torch.float32 and not exact_fp32() and ninstr > 0 and not wp.requires_grad
-            and not getattr(wp, "_nqa_volatile", False)):
+    if (x.dtype == torch.float32 and not exact_fp32() and ninstr > 0
+            and (train_packed() or not (wp.requires_grad or getattr(wp, "_nqa_volatile", False)))):
         wf = packed_weights(wp, meta, which)
         with torch.cuda.device(x.device), ktimer.region("node_linear", x.element_size() * N * (din + dout), flops):
             rc = lib.nqa_node_linear_packed_ordered(
@@ -220,6 +227,8 @@ _TRANSPOSED_CACHE = {}
 
 def _transposed(meta: NodeLinearMeta) -> NodeLinearMeta:
     """The adjoint map as a NodeLinearMeta of its own (so that double backward closes on the same kernel)."""
+    if getattr(meta, "_adjoint_of", None) is not None:
+        return meta._adjoint_of
     key = id(meta)
     if key not in _TRANSPOSED_CACHE:
         mt = NodeLinearMeta(meta.irreps_out, meta.irreps_in, [(o, i) for i, o in meta.instructions])
@@ -230,10 +239,21 @@ def _transposed(meta: NodeLinearMeta) -> NodeLinearMeta:
 
 def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Tensor:
     if wp.requires_grad:
+        # one transposed copy per step: the force pass (create_graph) makes it, the loss backward finds it on the step's
+        # weight tensor; the adjoint of the adjoint is the tensor it was made from (same meta, see _transposed)
+        src = getattr(wp, "_nqa_adjoint_src", None)
+        if src is not None and src[0] is meta:
+            orig = src[1]()  # (weak: no reference cycle between the two copies)
+            if orig is not None:
+                return orig
+        hit = getattr(wp, "_nqa_step_transposed", None)
+        if hit is not None and hit[0] is meta and (hit[1].requires_grad or not torch.is_grad_enabled()):
+            return hit[1]
         wt = meta.transpose_weights(wp)
-        # inside a backward pass that builds no graph this copy does not require grad although it changes every step:
-        # tell _launch_linear not to pack it (one prepass launch per module and step otherwise)
+        # inside a backward pass that builds no graph this copy does not require grad although it changes every step
         wt._nqa_volatile = True
+        wt._nqa_adjoint_src = (_transposed(meta), weakref.ref(wp))
+        wp._nqa_step_transposed = (meta, wt)
         return wt
     # constant weights (eval mode): the modules keep `wp` alive across steps, so the transposed copy rides on it
     cached = getattr(wp, "_nqa_transposed", None)
