@@ -23,6 +23,29 @@
  *   node_linear(Tensor x, Tensor wp, Tensor? addend, Tensor? types, str key, float scale, bool transposed) -> Tensor
  *   gate(Tensor x, str key) -> Tensor
  *   gate_bwd(Tensor x, Tensor g, str key) -> Tensor
+ * and the fused forms an exported energy / forces graph is made of since round 4 (one op per convolution edge side, per layer
+ * boundary, for the readout and for the force / virial tail; nequip_amd/nn/_radial_tp_ops.py, o3/_node_ops.py,
+ * nn/_energy_head.py, nn/_force_ops.py):
+ *   radial_tp_fwd(Tensor emb, Tensor x, Tensor edge_attr, Tensor w0, Tensor w1, float alpha0, float alpha1,
+ *                 Tensor edge_dst, Tensor edge_src, Tensor? edge_shift, str plan) -> (Tensor, Tensor)
+ *       radial MLP + tensor-product scatter; pairs the edge list when every edge has one reverse partner (decided here,
+ *       on the host, once per topology entry) and then evaluates the MLP once per pair; second result = the [E / 2, W]
+ *       weight rows, flat, kept for the backward (a placeholder when the list does not pair up)
+ *   radial_tp_bwd(Tensor grad_out, Tensor emb, Tensor x, Tensor edge_attr, Tensor w_rows, Tensor w0, Tensor w1,
+ *                 float alpha0, float alpha1, Tensor edge_dst, Tensor edge_src, Tensor? edge_shift, str plan,
+ *                 bool need_emb, bool need_x, bool need_y) -> (Tensor, Tensor, Tensor)
+ *   node_stage_fwd(Tensor h, Tensor types, Tensor wp1, Tensor wps, str gate_key, str lin_key, str sc_key, float scale)
+ *                  -> (Tensor, Tensor)        x1 = scale * linear_1(Gate(h)), sc = self_connection(Gate(h), types)
+ *   node_stage_bwd(Tensor g_x1, Tensor g_sc, Tensor h, Tensor types, Tensor wp1, Tensor wps, str gate_key, str lin_key,
+ *                  str sc_key, float scale) -> Tensor
+ *   energy_head_fwd(Tensor h, Tensor w, Tensor? scales, Tensor? shifts, Tensor types, int act, float cst) -> Tensor
+ *   energy_head_bwd(Tensor g_e, Tensor h, Tensor w, Tensor? scales, Tensor types, int act, float cst) -> Tensor
+ *   force_virial(Tensor g_vec, Tensor edge_vec, Tensor edge_index, Tensor? batch, Tensor? cell, SymInt num_nodes,
+ *                SymInt num_frames) -> (Tensor, Tensor, Tensor)      forces, virial, stress from dE/d(edge vectors)
+ * Derived weight images (packed fp16-split fragments, transposed copies, the radial MLP's split second layer) are built
+ * once per CONSTANT weight tensor: the cache is keyed on the identity of the tensor's storage, which an AOTInductor
+ * package's constant buffers keep from call to call (NQA_OP_CONSTANT_CACHE=0 switches it off; a weight buffer rewritten
+ * in place outside torch needs a new package or that switch).
  * `plan` / `key` are the canonical texts of the module constructor arguments (nequip_amd/nn/_tp_scatter_ops.py::plan_key,
  * nequip_amd/o3/_node_ops.py::linear_key / gate_key) that an exported graph carries as string constants.
  *

@@ -7,7 +7,7 @@ the loader imports it before the package loader runs (``nequip/utils/aoti_metada
 
 def register_ops() -> None:
     """Idempotent: import the modules that define the dispatcher ops."""
-    from .nn import _edge_vector_ops, _mlp_ops, _tp_scatter_ops  # noqa: F401
+    from .nn import _edge_vector_ops, _energy_head, _force_ops, _mlp_ops, _radial_tp_ops, _tp_scatter_ops  # noqa: F401
     from .nn.embedding import _edge_ops  # noqa: F401
     from .o3 import _node_ops  # noqa: F401
 

@@ -22,8 +22,11 @@
 #include <c10/util/intrusive_ptr.h>
 #include <torch/library.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <atomic>
@@ -126,6 +129,49 @@ std::vector<int32_t> irreps_offsets(const std::vector<Ir>& v) {
 std::mutex& registry_mutex() {
   static std::mutex m;
   return m;
+}
+
+// ---- derived constants of weight tensors, keyed on the identity of the weight's storage (nequip_amd/utils/constcache.py) -----
+// An AOTInductor package hands its constant buffers to these ops at every call: packed / transposed / split images of a
+// weight are built once per (storage -- held by the entry, so its address cannot be recycled under it --, data pointer,
+// version counter, shape, tag).  A weight tensor that is recomputed per call never hits and only costs a slot of the
+// bounded list.  NQA_OP_CONSTANT_CACHE=0 switches the cache off.
+struct ConstEntry {
+  const void* storage;
+  const void* data;
+  uint32_t version;
+  int64_t rows, cols;
+  std::string tag;
+  c10::Storage keep;
+  Tensor value;
+};
+
+std::pair<Tensor, bool> const_cached(const Tensor& t, const std::string& tag, const std::function<Tensor()>& build) {
+  static std::vector<ConstEntry> entries;  // most recent last; guarded by registry_mutex()
+  static const bool enabled = [] {
+    const char* v = std::getenv("NQA_OP_CONSTANT_CACHE");
+    return !(v != nullptr && v[0] == '0');
+  }();
+  if (!enabled) return {build(), false};
+  const void* st = t.storage().unsafeGetStorageImpl();
+  const int64_t rows = t.dim() > 0 ? t.size(0) : 1, cols = t.numel();
+  {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    for (size_t i = entries.size(); i-- > 0;) {
+      ConstEntry& e = entries[i];
+      if (e.storage == st && e.data == t.data_ptr() && e.version == t._version() && e.rows == rows && e.cols == cols &&
+          e.tag == tag) {
+        Tensor hit = e.value;
+        if (i + 1 != entries.size()) std::rotate(entries.begin() + (long)i, entries.begin() + (long)i + 1, entries.end());
+        return {hit, true};
+      }
+    }
+  }
+  Tensor value = build();  // (outside the lock: builders use the registry themselves)
+  std::lock_guard<std::mutex> lock(registry_mutex());
+  entries.push_back(ConstEntry{st, t.data_ptr(), t._version(), rows, cols, tag, t.storage(), value});
+  if (entries.size() > 512) entries.erase(entries.begin());
+  return {value, false};
 }
 
 // ---- tensor-product plans: text -> nqa_plan + per-device table image ----------------------------------------------------
@@ -247,6 +293,16 @@ int64_t index_checksum(const Tensor& dst, const Tensor& src) {
 struct Csr {
   Tensor rowptr, edge_id, other;
 };
+// nequip_amd/nn/_topology.py::EdgePairing: weight rows of a paired list (rows[e] = p for the representative edge of pair p,
+// p + P for its reverse), the representative edges, the rows in the slot order of the two CSRs, and the owner lists of the
+// pair-centric backward (build_owner_csr)
+struct Pairing {
+  Tensor rows, rep;
+  int64_t P = 0;
+  Tensor slots_dst, slots_src;
+  Tensor owner[7];
+  bool has_owner = false;
+};
 
 struct Topology {
   c10::weak_intrusive_ptr<c10::StorageImpl> dst_ref, src_ref;
@@ -258,6 +314,9 @@ struct Topology {
   Tensor dst, src;  // contiguous int64
   Csr by_dst, by_src;
   bool has_dst = false, has_src = false;
+  bool pairing_done = false;           // reverse-edge pairing (radial_tp_*): verdict read once per entry
+  const void* pairing_shift = nullptr;
+  std::shared_ptr<struct Pairing> pairing;
   std::mutex build;  // the CSRs are built on first use, outside the registry lock
   Topology(const Tensor& d, const Tensor& s)
       : dst_ref(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(d.storage().unsafeGetStorageImpl())),
@@ -356,6 +415,84 @@ const Csr& by_src(Topology& t) {
 }
 
 const int32_t* i32(const Tensor& t) { return static_cast<const int32_t*>(t.data_ptr()); }
+
+// EdgeTopology.pairing (nequip_amd/nn/_topology.py): nullptr when some edge has no unique reverse partner.  One host
+// synchronisation per topology entry to read the verdict.
+std::shared_ptr<Pairing> pairing_of(Topology& t, const OptTensor& shift) {
+  std::lock_guard<std::mutex> lock(t.build);
+  const void* sp = ptr(shift);
+  if (t.pairing_done && t.pairing_shift == sp) return t.pairing;
+  t.pairing_done = true;
+  t.pairing_shift = sp;
+  t.pairing.reset();
+  const int64_t E = t.num_edges;
+  if (E == 0 || (E & 1) != 0 || env_on("NQA_NO_PAIRED")) return nullptr;
+  Tensor sh;
+  int32_t sdt = NQA_F64;
+  if (sp != nullptr) {
+    sh = *shift;
+    if (sh.scalar_type() != at::kFloat && sh.scalar_type() != at::kDouble) sh = sh.to(at::kDouble);
+    sh = sh.contiguous();
+    sdt = sh.scalar_type() == at::kFloat ? NQA_F32 : NQA_F64;
+  }
+  const auto o32 = t.dst.options().dtype(at::kInt);
+  auto p = std::make_shared<Pairing>();
+  p->rows = at::empty({E}, o32);
+  p->rep = at::empty({E / 2}, t.dst.options());
+  Tensor ok = at::zeros({1}, o32);
+  const int64_t ws_bytes = nqa_edge_pairs_workspace_bytes(E);
+  TORCH_CHECK(ws_bytes >= 0, "nequip_amd: nqa_edge_pairs_workspace_bytes failed");
+  Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, t.dst.options().dtype(at::kByte));
+  NQA_CALL(nqa_edge_pairs(static_cast<const int64_t*>(t.dst.data_ptr()), static_cast<const int64_t*>(t.src.data_ptr()),
+                          ptr(sh), sdt, E, t.num_nodes, ws.data_ptr(), ws_bytes, static_cast<int32_t*>(p->rows.data_ptr()),
+                          static_cast<int64_t*>(p->rep.data_ptr()), static_cast<int32_t*>(ok.data_ptr()), stream_of(t.dst)),
+           "nqa_edge_pairs");
+  if (ok.item<int32_t>() != 1) return nullptr;
+  p->P = E / 2;
+  t.pairing = p;
+  return p;
+}
+
+const Tensor& slots_dst(Topology& t, Pairing& p) {
+  const Csr& c = by_dst(t);
+  std::lock_guard<std::mutex> lock(t.build);
+  if (!p.slots_dst.defined()) p.slots_dst = p.rows.index_select(0, c.edge_id.slice(0, 0, t.num_edges).to(at::kLong)).contiguous();
+  return p.slots_dst;
+}
+
+const Tensor& slots_src(Topology& t, Pairing& p) {
+  const Csr& c = by_src(t);
+  std::lock_guard<std::mutex> lock(t.build);
+  if (!p.slots_src.defined()) p.slots_src = p.rows.index_select(0, c.edge_id.slice(0, 0, t.num_edges).to(at::kLong)).contiguous();
+  return p.slots_src;
+}
+
+// build_owner_csr (nequip_amd/nn/_topology.py): owner of the pair {i <- j, j <- i} is i when (i < j) xor (i + j odd), a self
+// image pair belongs to i; slots grouped by owner (within an owner by the other node) and, separately, by the other node.
+void owner_lists(Topology& t, Pairing& p) {
+  std::lock_guard<std::mutex> lock(t.build);
+  if (p.has_owner) return;
+  const int64_t P = p.P, N = t.num_nodes;
+  const Tensor order = at::argsort(p.rows.to(at::kLong), /*stable=*/true, 0, false);
+  const Tensor ea = order.slice(0, 0, P), eb = order.slice(0, P, 2 * P);
+  const Tensor i = t.dst.index_select(0, ea), j = t.src.index_select(0, ea);
+  const Tensor own_i = i.eq(j).logical_or(i.lt(j).logical_xor((i + j).bitwise_and(1).eq(1)));
+  const Tensor owner = at::where(own_i, i, j), other = at::where(own_i, j, i);
+  const Tensor e_in = at::where(own_i, ea, eb), e_out = at::where(own_i, eb, ea);
+  const Tensor perm = at::argsort(owner * N + other, /*stable=*/true, 0, false);
+  const Tensor owner_s = owner.index_select(0, perm), other_s = other.index_select(0, perm);
+  const Tensor nodes = at::arange(N + 1, t.dst.options());
+  auto c32 = [](const Tensor& v) { return v.to(at::kInt).contiguous(); };
+  const Tensor perm2 = at::argsort(other_s, /*stable=*/true, 0, false);
+  p.owner[0] = c32(at::searchsorted(owner_s, nodes));
+  p.owner[1] = c32(other_s);
+  p.owner[2] = c32(perm);
+  p.owner[3] = c32(e_in.index_select(0, perm));
+  p.owner[4] = c32(e_out.index_select(0, perm));
+  p.owner[5] = c32(at::searchsorted(other_s.index_select(0, perm2), nodes));
+  p.owner[6] = c32(perm2);
+  p.has_owner = true;
+}
 
 // ---- tp_scatter ------------------------------------------------------------------------------------------------------
 void check_tp_operands(const Plan& P, const Tensor* x, const Tensor& y, const Tensor& w, int64_t N, int64_t E) {
@@ -556,6 +693,16 @@ Tensor edge_embed_bwd(const Tensor& edge_vec, const Tensor& bessel_weights, cons
 // ---- radial MLP --------------------------------------------------------------------------------------------------------
 int32_t mlp_mode() { return env_on("NQA_MLP_EXACT_FP32") ? NQA_MLP_FP32 : NQA_MLP_BF16X6; }
 
+// (image, ready): the workspace of nqa_radial_mlp_fwd / _bwd for one constant `w1` -- ready once a launch has filled it
+// (the prepass folds alpha1 into the image; a launch over zero rows returns before it: no entry is made for one)
+std::pair<Tensor, bool> mlp_image(const Tensor& w1, double alpha1, int32_t mode, int backward, int64_t ws_bytes, int64_t rows) {
+  auto fresh = [&] { return at::empty({std::max<int64_t>(ws_bytes, 1)}, w1.options().dtype(at::kByte)); };
+  if (rows == 0) return {fresh(), false};
+  char a[40];
+  std::snprintf(a, sizeof(a), "%.17g", alpha1);
+  return const_cached(w1, "mlp_image:" + std::to_string(mode) + ":" + std::to_string(backward) + ":" + a, fresh);
+}
+
 void check_mlp(const Tensor& emb, const Tensor& w0, const Tensor& w1, const char* op) {
   require_gpu(emb, op);
   TORCH_CHECK(emb.scalar_type() == at::kFloat && w0.scalar_type() == at::kFloat && w1.scalar_type() == at::kFloat,
@@ -578,9 +725,10 @@ Tensor radial_mlp_fwd(const Tensor& emb_, const Tensor& w0_, const Tensor& w1_, 
   Tensor out = at::empty({E, W}, emb.options());
   const int64_t ws_bytes = nqa_radial_mlp_workspace_bytes(mode, 0, H, W);
   TORCH_CHECK(ws_bytes >= 0, "nequip_amd::radial_mlp_fwd: workspace query failed");
-  Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, emb.options().dtype(at::kByte));
+  // the split / re-laid-out second-layer weights: built by the kernel's prepass on the first call with a constant `w1`
+  const auto ws = mlp_image(w1, alpha1, mode, 0, ws_bytes, E);
   NQA_CALL(nqa_radial_mlp_fwd(NQA_F32, mode, emb.data_ptr(), w0.data_ptr(), alpha0, w1.data_ptr(), alpha1, nb, H, W, E,
-                              out.data_ptr(), ws.data_ptr(), ws_bytes, 0, stream_of(emb)),
+                              out.data_ptr(), ws.first.data_ptr(), ws_bytes, ws.second ? 1 : 0, stream_of(emb)),
            "nqa_radial_mlp_fwd");
   return out;
 }
@@ -600,11 +748,245 @@ Tensor radial_mlp_bwd(const Tensor& emb_, const Tensor& w0_, const Tensor& w1_, 
   Tensor g_emb = at::empty_like(emb);
   const int64_t ws_bytes = nqa_radial_mlp_workspace_bytes(mode, 1, H, W);
   TORCH_CHECK(ws_bytes >= 0, "nequip_amd::radial_mlp_bwd: workspace query failed");
-  Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, emb.options().dtype(at::kByte));
+  const auto ws = mlp_image(w1, alpha1, mode, 1, ws_bytes, E);
   NQA_CALL(nqa_radial_mlp_bwd(NQA_F32, mode, emb.data_ptr(), w0.data_ptr(), alpha0, w1.data_ptr(), alpha1, g.data_ptr(), nb,
-                              H, W, E, g_emb.data_ptr(), ws.data_ptr(), ws_bytes, 0, stream_of(emb)),
+                              H, W, E, g_emb.data_ptr(), ws.first.data_ptr(), ws_bytes, ws.second ? 1 : 0, stream_of(emb)),
            "nqa_radial_mlp_bwd");
   return g_emb;
+}
+
+// gradient w.r.t. the embedding rows of the pairs from the two halves of the weight gradient (nqa_radial_mlp_bwd_paired)
+Tensor radial_mlp_bwd_halves(const Tensor& emb, const Tensor& w0, const Tensor& w1, const Tensor& g1, const Tensor& g2,
+                             double alpha0, double alpha1) {
+  const int64_t P = emb.size(0);
+  const int32_t nb = (int32_t)emb.size(1), H = (int32_t)w1.size(0), W = (int32_t)w1.size(1);
+  int32_t mode = mlp_mode();
+  if (mode == NQA_MLP_BF16X6 && !(std::getenv("NQA_MLP_BWD_F16") && std::getenv("NQA_MLP_BWD_F16")[0] == '0'))
+    mode = NQA_MLP_F16X3;
+  Tensor g_emb = at::empty_like(emb);
+  const int64_t ws_bytes = nqa_radial_mlp_workspace_bytes(mode, 1, H, W);
+  TORCH_CHECK(ws_bytes >= 0, "nequip_amd::radial_tp_bwd: workspace query failed");
+  const auto ws = mlp_image(w1, alpha1, mode, 1, ws_bytes, P);
+  NQA_CALL(nqa_radial_mlp_bwd_paired(NQA_F32, mode, emb.data_ptr(), w0.data_ptr(), alpha0, w1.data_ptr(), alpha1,
+                                     g1.data_ptr(), g2.data_ptr(), nb, H, W, P, g_emb.data_ptr(), ws.first.data_ptr(),
+                                     ws_bytes, ws.second ? 1 : 0, stream_of(emb)),
+           "nqa_radial_mlp_bwd_paired");
+  return g_emb;
+}
+
+// ---- radial_tp: radial MLP + tensor-product scatter of one convolution, pairing decided here (nn/_radial_tp_ops.py) -----
+bool plan_has_spec(Plan& P) { return nqa_tp_bwd_fused_workspace_bytes(P.handle, NQA_F32, 0) >= 0; }
+
+bool pair_backward_pays(const Tensor& g) {  // nequip_amd/nn/_paired_radial.py::_pair_backward_pays
+  if (env_on("NQA_NO_PAIR_BWD")) return false;
+  const char* lim = std::getenv("NQA_PAIR_BWD_MAX_MB");
+  if (lim == nullptr || lim[0] == '\0') return true;
+  return (double)g.numel() * (double)g.element_size() <= std::atof(lim) * (double)(1 << 20);
+}
+
+Tensor pair_rows(const Tensor& emb, Pairing& p) {
+  Tensor out = at::empty({p.P, emb.size(1)}, emb.options());
+  NQA_CALL(nqa_pair_gather(emb.data_ptr(), static_cast<const int64_t*>(p.rep.data_ptr()), p.P, (int32_t)emb.size(1),
+                           out.data_ptr(), stream_of(emb)),
+           "nqa_pair_gather");
+  return out;
+}
+
+std::shared_ptr<Pairing> radial_tp_pairing(Plan& P, Topology& t, const OptTensor& shift) {
+  if (!plan_has_spec(P)) return nullptr;
+  return pairing_of(t, shift);
+}
+
+void check_radial_tp(Plan& P, const Tensor& emb, const Tensor& x, const Tensor& y, const Tensor& w0, const Tensor& w1,
+                     int64_t E, const char* op) {
+  check_mlp(emb, w0, w1, op);
+  TORCH_CHECK(x.scalar_type() == at::kFloat && y.scalar_type() == at::kFloat, "nequip_amd::", op, ": float32 only");
+  TORCH_CHECK(emb.size(0) == E, "nequip_amd::", op, ": one embedding row per edge");
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == P.dim_in1, "nequip_amd::", op, ": x must be [N, ", P.dim_in1, "]");
+  TORCH_CHECK(y.dim() == 2 && y.size(0) == E && y.size(1) == P.dim_in2, "nequip_amd::", op, ": edge_attr must be [E, ", P.dim_in2, "]");
+  TORCH_CHECK(w1.size(1) == P.weight_numel, "nequip_amd::", op, ": w1 must be [H, ", P.weight_numel, "]");
+}
+
+std::tuple<Tensor, Tensor> radial_tp_fwd(const Tensor& emb_, const Tensor& x_, const Tensor& y_, const Tensor& w0_,
+                                         const Tensor& w1_, double alpha0, double alpha1, const Tensor& edge_dst,
+                                         const Tensor& edge_src, const OptTensor& edge_shift, std::string plan) {
+  require_gpu(x_, "radial_tp_fwd");
+  c10::DeviceGuard guard(x_.device());
+  Plan& P = plan_of(plan);
+  const Tensor emb = emb_.contiguous(), x = x_.contiguous(), y = y_.contiguous(), w0 = w0_.contiguous(), w1 = w1_.contiguous();
+  const int64_t N = x.size(0), E = edge_dst.numel();
+  check_radial_tp(P, emb, x, y, w0, w1, E, "radial_tp_fwd");
+  auto topo = topology_of(edge_dst, edge_src, N);
+  auto pairing = radial_tp_pairing(P, *topo, edge_shift);
+  const Csr& c = by_dst(*topo);
+  Tensor out = P.out_needs_zero ? at::zeros({N, P.dim_out}, x.options()) : at::empty({N, P.dim_out}, x.options());
+  Tensor image = plan_image(P, x.device());
+  if (pairing) {
+    const Tensor w_rows = radial_mlp_fwd(pair_rows(emb, *pairing), w0, w1, alpha0, alpha1);
+    const Tensor& slots = slots_dst(*topo, *pairing);
+    NQA_CALL(nqa_tp_scatter_fwd_paired(P.handle, image.data_ptr(), NQA_F32, x.data_ptr(), y.data_ptr(), w_rows.data_ptr(),
+                                       i32(c.rowptr), i32(c.edge_id), i32(c.other), out.data_ptr(), N, E, i32(slots),
+                                       pairing->P, stream_of(x)),
+             "nqa_tp_scatter_fwd_paired");
+    return std::make_tuple(out, w_rows.view({-1}));
+  }
+  const Tensor w = radial_mlp_fwd(emb, w0, w1, alpha0, alpha1);
+  NQA_CALL(nqa_tp_scatter_fwd(P.handle, image.data_ptr(), NQA_F32, x.data_ptr(), y.data_ptr(), w.data_ptr(), i32(c.rowptr),
+                              i32(c.edge_id), i32(c.other), out.data_ptr(), N, E, stream_of(x)),
+           "nqa_tp_scatter_fwd");
+  return std::make_tuple(out, at::empty({(E / 2) * P.weight_numel}, x.options()));
+}
+
+std::tuple<Tensor, Tensor, Tensor> radial_tp_bwd(const Tensor& g_, const Tensor& emb_, const Tensor& x_, const Tensor& y_,
+                                                 const Tensor& w_rows_, const Tensor& w0_, const Tensor& w1_, double alpha0,
+                                                 double alpha1, const Tensor& edge_dst, const Tensor& edge_src,
+                                                 const OptTensor& edge_shift, std::string plan, bool need_emb, bool need_x,
+                                                 bool need_y) {
+  require_gpu(x_, "radial_tp_bwd");
+  c10::DeviceGuard guard(x_.device());
+  Plan& P = plan_of(plan);
+  const Tensor g = g_.contiguous(), emb = emb_.contiguous(), x = x_.contiguous(), y = y_.contiguous();
+  const Tensor w0 = w0_.contiguous(), w1 = w1_.contiguous();
+  const int64_t N = x.size(0), E = edge_dst.numel(), W = P.weight_numel;
+  check_radial_tp(P, emb, x, y, w0, w1, E, "radial_tp_bwd");
+  TORCH_CHECK(g.dim() == 2 && g.size(0) == N && g.size(1) == P.dim_out && g.scalar_type() == at::kFloat,
+              "nequip_amd::radial_tp_bwd: grad_out must be float32 [", N, ", ", P.dim_out, "]");
+  auto topo = topology_of(edge_dst, edge_src, N);
+  auto pairing = radial_tp_pairing(P, *topo, edge_shift);
+  const Tensor empty = at::empty({0}, x.options());
+  if (!pairing) {  // the per-edge kernels; the weight rows were not kept (w_rows is a placeholder): one more MLP forward
+    const Tensor w = radial_mlp_fwd(emb, w0, w1, alpha0, alpha1);
+    auto r = tp_scatter_bwd(g, x, y, w, edge_dst, edge_src, plan, need_x, need_y, need_emb);
+    Tensor g_emb = need_emb ? radial_mlp_bwd(emb, w0, w1, std::get<2>(r), alpha0, alpha1) : empty;
+    return std::make_tuple(g_emb, std::get<0>(r), std::get<1>(r));
+  }
+  Pairing& pr = *pairing;
+  const int64_t Pn = pr.P;
+  TORCH_CHECK(w_rows_.numel() == Pn * W, "nequip_amd::radial_tp_bwd: w_rows is not the forward's [E / 2, W] rows");
+  const Tensor w_rows = w_rows_.contiguous().view({Pn, W});
+  Tensor image = plan_image(P, x.device());
+  const auto bytes = x.options().dtype(at::kByte);
+  Tensor gx = empty, gy = empty, G;
+  bool folded = false, done = false;
+  // the choices of _PairedRadialTPFn.backward (nequip_amd/nn/_paired_radial.py)
+  auto run_pairs = [&](bool with_gx) -> bool {
+    const int64_t ws_bytes = nqa_tp_bwd_pairs_workspace_bytes(P.handle, NQA_F32, E);
+    if (ws_bytes < 0) return false;
+    owner_lists(*topo, pr);
+    if (with_gx) gx = at::empty({N, P.dim_in1}, x.options());
+    G = at::empty({Pn, W}, x.options());
+    gy = at::empty({E, P.dim_in2}, x.options());
+    Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, bytes);
+    NQA_CALL(nqa_tp_scatter_bwd_pairs(P.handle, image.data_ptr(), NQA_F32, x.data_ptr(), y.data_ptr(), w_rows.data_ptr(),
+                                      g.data_ptr(), i32(pr.owner[0]), i32(pr.owner[1]), i32(pr.owner[2]), i32(pr.owner[3]),
+                                      i32(pr.owner[4]), i32(pr.owner[5]), i32(pr.owner[6]), G.data_ptr(), gy.data_ptr(),
+                                      with_gx ? gx.data_ptr() : nullptr, ws.data_ptr(), ws_bytes, N, E, stream_of(x)),
+             "nqa_tp_scatter_bwd_pairs");
+    return true;
+  };
+  if (need_emb && need_x && need_y && P.prefer_fused_bwd && !env_on("NQA_NO_FUSED_BWD")) {
+    if (pair_backward_pays(g) && run_pairs(true)) {
+      folded = done = true;
+    } else if (P.fused_rows_ok) {
+      const int64_t ws_bytes = nqa_tp_bwd_fused_workspace_bytes(P.handle, NQA_F32, E);
+      if (ws_bytes >= 0) {
+        const Csr& cd = by_dst(*topo);
+        const Csr& cs = by_src(*topo);
+        const Tensor& slots = slots_dst(*topo, pr);
+        gx = at::empty({N, P.dim_in1}, x.options());
+        G = at::empty({2 * Pn, W}, x.options());
+        gy = at::empty({E, P.dim_in2}, x.options());
+        Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, bytes);
+        NQA_CALL(nqa_tp_scatter_bwd_fused_paired(P.handle, image.data_ptr(), NQA_F32, x.data_ptr(), y.data_ptr(),
+                                                 w_rows.data_ptr(), g.data_ptr(), i32(cd.rowptr), i32(cd.edge_id),
+                                                 i32(cd.other), i32(cs.rowptr), i32(cs.edge_id), G.data_ptr(), gy.data_ptr(),
+                                                 gx.data_ptr(), ws.data_ptr(), ws_bytes, N, E, i32(slots), Pn, stream_of(x)),
+                 "nqa_tp_scatter_bwd_fused_paired");
+        done = true;
+      }
+    }
+  }
+  if (!done) {
+    if (need_x) {
+      const Csr& cs = by_src(*topo);
+      const Tensor& slots = slots_src(*topo, pr);
+      gx = at::empty({N, P.dim_in1}, x.options());
+      NQA_CALL(nqa_tp_scatter_bwd_x_paired(P.handle, image.data_ptr(), NQA_F32, y.data_ptr(), w_rows.data_ptr(), g.data_ptr(),
+                                           i32(cs.rowptr), i32(cs.edge_id), i32(cs.other), gx.data_ptr(), N, E, i32(slots),
+                                           Pn, stream_of(x)),
+               "nqa_tp_scatter_bwd_x_paired");
+    }
+    Tensor gx_keep = gx;
+    if (need_emb && need_y && pair_backward_pays(g) && run_pairs(false)) {
+      folded = true;
+      gx = gx_keep;
+    } else if (need_emb || need_y) {
+      const Csr& cd = by_dst(*topo);
+      const Tensor& slots = slots_dst(*topo, pr);
+      if (need_emb) G = at::empty({2 * Pn, W}, x.options());
+      if (need_y) gy = at::empty({E, P.dim_in2}, x.options());
+      int64_t ws_bytes = 0;
+      Tensor ws;
+      if (need_y) {
+        ws_bytes = nqa_tp_bwd_edge_workspace_bytes(P.handle, NQA_F32, E);
+        TORCH_CHECK(ws_bytes >= 0, "nequip_amd: nqa_tp_bwd_edge_workspace_bytes failed");
+        ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, bytes);
+      }
+      NQA_CALL(nqa_tp_scatter_bwd_edge_paired(P.handle, image.data_ptr(), NQA_F32, x.data_ptr(), y.data_ptr(),
+                                              w_rows.data_ptr(), g.data_ptr(), i32(cd.rowptr), i32(cd.edge_id), i32(cd.other),
+                                              need_emb ? G.data_ptr() : nullptr, need_y ? gy.data_ptr() : nullptr,
+                                              need_y ? ws.data_ptr() : nullptr, ws_bytes, N, E, i32(slots), Pn, stream_of(x)),
+               "nqa_tp_scatter_bwd_edge_paired");
+    }
+  }
+  Tensor g_emb = empty;
+  if (need_emb) {
+    const Tensor emb_half = pair_rows(emb, pr);
+    const Tensor g_half = folded ? radial_mlp_bwd(emb_half, w0, w1, G, alpha0, alpha1)
+                                 : radial_mlp_bwd_halves(emb_half, w0, w1, G.slice(0, 0, Pn), G.slice(0, Pn, 2 * Pn), alpha0,
+                                                         alpha1);
+    g_emb = at::empty_like(emb);
+    NQA_CALL(nqa_pair_expand(g_half.data_ptr(), i32(pr.rows), E, Pn, (int32_t)emb.size(1), g_emb.data_ptr(), stream_of(emb)),
+             "nqa_pair_expand");
+  }
+  if (!need_x) gx = empty;
+  if (!need_y) gy = empty;
+  return std::make_tuple(g_emb, gx, gy);
+}
+
+// ---- force / virial tail (nequip_amd/nn/_force_ops.py) ------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor> force_virial(const Tensor& g_vec, const Tensor& edge_vec, const Tensor& edge_index,
+                                                const OptTensor& batch, const OptTensor& cell, int64_t num_nodes,
+                                                int64_t num_frames) {
+  require_gpu(g_vec, "force_virial");
+  c10::DeviceGuard guard(g_vec.device());
+  TORCH_CHECK(edge_index.scalar_type() == at::kLong && edge_index.dim() == 2 && edge_index.size(0) == 2,
+              "nequip_amd::force_virial: edge_index must be int64 [2, E]");
+  const Tensor g = as_f64(g_vec), ev = as_f64(edge_vec);
+  TORCH_CHECK(g.sizes() == ev.sizes() && g.dim() == 2 && g.size(1) == 3 && g.size(0) == edge_index.size(1),
+              "nequip_amd::force_virial: g_vec / edge_vec must be [E, 3]");
+  auto topo = topology_of(edge_index.select(0, 0), edge_index.select(0, 1), num_nodes);
+  const Csr& cd = by_dst(*topo);
+  const Csr& cs = by_src(*topo);
+  const auto f64 = g.options().dtype(at::kDouble);
+  Tensor forces = at::empty({num_nodes, 3}, f64), part = at::empty({num_nodes, 9}, f64);
+  Tensor virial = at::empty({num_frames, 3, 3}, f64);
+  const bool has_cell = cell.has_value() && cell->defined();
+  Tensor stress = has_cell ? at::empty({num_frames, 3, 3}, f64) : at::empty({0}, f64);
+  Tensor cell_c;
+  if (has_cell) cell_c = as_f64(cell->reshape({-1, 3, 3}).expand({num_frames, 3, 3}));
+  const OptTensor batch_c = as_i64(batch);
+  // part[n] = sum_{e: centre(e) = n} edge_vec_e (x) g_e; sign -1: forces = -dE/dpos
+  NQA_CALL(nqa_edge_vectors_bwd(static_cast<const double*>(g.data_ptr()), static_cast<const double*>(ev.data_ptr()),
+                                i32(cd.rowptr), i32(cd.edge_id), i32(cs.rowptr), i32(cs.edge_id), num_nodes, -1.0,
+                                static_cast<double*>(forces.data_ptr()), static_cast<double*>(part.data_ptr()), stream_of(g)),
+           "nqa_edge_vectors_bwd");
+  NQA_CALL(nqa_virial_finalize(static_cast<const double*>(part.data_ptr()), static_cast<const int64_t*>(ptr(batch_c)),
+                               static_cast<const double*>(ptr(cell_c)), num_nodes, num_frames,
+                               static_cast<double*>(virial.data_ptr()), has_cell ? static_cast<double*>(stress.data_ptr()) : nullptr,
+                               stream_of(g)),
+           "nqa_virial_finalize");
+  return std::make_tuple(forces, virial, stress);
 }
 
 // ---- node_linear -------------------------------------------------------------------------------------------------------
@@ -708,6 +1090,29 @@ Tensor transpose_perm(LinearMeta& fwd, const at::Device& device) {
   return d;
 }
 
+// the adjoint map's packed weights from the forward map's, once per constant (nequip_amd/o3/_node_kernels.py::
+// meta_transposed_weights)
+Tensor transposed_weights(const Tensor& wp, const std::string& key) {
+  return const_cached(wp, "node_transposed:" + key, [&] {
+           return wp.index_select(1, transpose_perm(linear_meta(key, false), wp.device())).contiguous();
+         }).first;
+}
+
+// fp16-split fragment image of packed weights [T, wstride] for the tables of M (nqa_node_weights_pack), once per constant
+Tensor packed_weights(const Tensor& wp, LinearMeta& M, const std::string& full_key) {
+  const bool f16 = !(std::getenv("NQA_NODE_F16") && std::getenv("NQA_NODE_F16")[0] == '0');
+  return const_cached(wp, std::string("node_packed:") + (f16 ? "h:" : "b:") + full_key, [&] {
+           const int32_t T = (int32_t)wp.size(0);
+           const int64_t nbytes = nqa_node_weights_pack_bytes(M.chunks.data(), M.n_chunks, M.instr.data(), M.n_instr, T);
+           TORCH_CHECK(nbytes >= 0, "nequip_amd: inconsistent node_linear tables");
+           Tensor wf = at::empty({std::max<int64_t>(nbytes, 16)}, wp.options().dtype(at::kByte));
+           NQA_CALL(nqa_node_weights_pack(wp.data_ptr(), M.chunks.data(), M.n_chunks, M.instr.data(), M.n_instr, T, wp.size(1),
+                                          wf.data_ptr(), stream_of(wp)),
+                    "nqa_node_weights_pack");
+           return wf;
+         }).first;
+}
+
 Tensor node_linear(const Tensor& x_, const Tensor& wp_, const OptTensor& addend_, const OptTensor& types_, std::string key,
                    double scale, bool transposed) {
   require_gpu(x_, "node_linear");
@@ -716,7 +1121,7 @@ Tensor node_linear(const Tensor& x_, const Tensor& wp_, const OptTensor& addend_
   Tensor wp = wp_.contiguous();
   TORCH_CHECK(wp.dim() == 2 && wp.scalar_type() == x.scalar_type(), "nequip_amd::node_linear: weights must be [T, wstride] in the dtype of x");
   LinearMeta& M = linear_meta(key, transposed);
-  if (transposed) wp = wp.index_select(1, transpose_perm(linear_meta(key, false), x.device())).contiguous();
+  if (transposed) wp = transposed_weights(wp, key);
   TORCH_CHECK(x.dim() == 2 && x.size(1) == M.din, "nequip_amd::node_linear: x must be [N, ", M.din, "]");
   TORCH_CHECK(wp.size(1) == M.wstride, "nequip_amd::node_linear: packed weights must be [T, ", M.wstride, "]");
   OptTensor addend, types;
@@ -734,12 +1139,7 @@ Tensor node_linear(const Tensor& x_, const Tensor& wp_, const OptTensor& addend_
   Tensor out = at::empty({N, M.dout}, x.options());
   const bool packed = x.scalar_type() == at::kFloat && !env_on("NQA_NODE_EXACT_FP32") && M.n_instr > 0;
   if (packed) {
-    const int64_t nbytes = nqa_node_weights_pack_bytes(M.chunks.data(), M.n_chunks, M.instr.data(), M.n_instr, (int32_t)T);
-    TORCH_CHECK(nbytes >= 0, "nequip_amd::node_linear: inconsistent tables");
-    Tensor wf = at::empty({std::max<int64_t>(nbytes, 16)}, x.options().dtype(at::kByte));
-    NQA_CALL(nqa_node_weights_pack(wp.data_ptr(), M.chunks.data(), M.n_chunks, M.instr.data(), M.n_instr, (int32_t)T,
-                                   wp.size(1), wf.data_ptr(), stream_of(x)),
-             "nqa_node_weights_pack");
+    const Tensor wf = packed_weights(wp, M, (transposed ? "T|" : "N|") + key);
     NQA_CALL(nqa_node_linear_packed(x.data_ptr(), wf.data_ptr(), ptr(addend), out.data_ptr(),
                                     static_cast<const int64_t*>(ptr(types)), M.chunks.data(), M.n_chunks, M.instr.data(),
                                     M.n_instr, (int32_t)T, (int32_t)M.din, (int32_t)M.dout, N, scale, stream_of(x)),
@@ -876,6 +1276,209 @@ Tensor gate_bwd(const Tensor& x, const Tensor& g, std::string key) {
   return launch_gate(x.contiguous(), g.contiguous(), gate_meta(key), 1, "gate_bwd");
 }
 
+// ---- node_stage: Gate + linear_1 + typed self-connection of a layer boundary, one launch per direction (nqa_node_fused;
+// nequip_amd/o3/_node_ops.py::node_stage, _node_kernels.py::_FusedNodeStageFn) ------------------------------------------------
+struct GateBlocks {
+  std::vector<nqa_gate_block> blocks;
+  int64_t din = 0, dout = 0;
+};
+
+// GateMeta.blocks: (out_off, d, mul, val_off, gate_off, act, cst) per output block -- activated scalars, then gated irreps
+GateBlocks& gate_blocks(const std::string& key) {
+  static std::map<std::string, std::unique_ptr<GateBlocks>> metas;
+  std::lock_guard<std::mutex> lock(registry_mutex());
+  auto it = metas.find(key);
+  if (it != metas.end()) return *it->second;
+  const auto parts = split(key, '|');
+  TORCH_CHECK(parts.size() == 5, "nequip_amd: malformed gate key");
+  const auto scalars = parse_irreps(parts[0]), gates = parse_irreps(parts[2]), gated = parse_irreps(parts[4]);
+  const auto act_s = parse_acts(parts[1]), act_g = parse_acts(parts[3]);
+  TORCH_CHECK(act_s.size() >= scalars.size() && act_g.size() >= gated.size(), "nequip_amd::node_stage: one activation per irrep");
+  auto m = std::make_unique<GateBlocks>();
+  const int64_t ns = irreps_dim(scalars), ng = irreps_dim(gates);
+  m->din = ns + ng + irreps_dim(gated);
+  m->dout = ns + irreps_dim(gated);
+  int32_t off = 0;
+  for (size_t i = 0; i < scalars.size(); ++i) {
+    if (scalars[i].mul > 0) m->blocks.push_back(nqa_gate_block{off, 1, scalars[i].mul, off, -1, act_s[i].first, act_s[i].second});
+    off += scalars[i].mul;
+  }
+  int32_t b_in = (int32_t)(ns + ng), b_out = (int32_t)ns, b_gate = (int32_t)ns;
+  for (size_t i = 0; i < gated.size(); ++i) {
+    const Ir& ir = gated[i];
+    if (ir.mul > 0) m->blocks.push_back(nqa_gate_block{b_out, ir.d(), ir.mul, b_in, b_gate, act_g[i].first, act_g[i].second});
+    b_in += ir.mul * ir.d();
+    b_out += ir.mul * ir.d();
+    b_gate += ir.mul;
+  }
+  GateBlocks& ref = *m;
+  metas.emplace(key, std::move(m));
+  return ref;
+}
+
+// a permutation that groups the atoms by type (int32): ANY permutation gives the same results in nqa_node_fused, so the
+// one-entry memo below -- keyed on the type tensor's memory -- can at worst cost speed
+Tensor type_order(const Tensor& types) {
+  static std::mutex mu;
+  static const void* last_ptr = nullptr;
+  static int64_t last_n = -1;
+  static uint32_t last_version = 0;
+  static Tensor last;
+  std::lock_guard<std::mutex> lock(mu);
+  if (last.defined() && last_ptr == types.data_ptr() && last_n == types.numel() && last_version == types._version() &&
+      last.device() == types.device())
+    return last;
+  last = at::argsort(types.view({-1}), /*stable=*/true, 0, false).to(at::kInt).contiguous();
+  last_ptr = types.data_ptr();
+  last_n = types.numel();
+  last_version = types._version();
+  return last;
+}
+
+void fill_part(nqa_node_part& p, const Tensor& x, const Tensor& packed, LinearMeta& M, int64_t n_types, void* out, double scale,
+               int32_t accumulate, GateBlocks* in_gate) {
+  std::memset(&p, 0, sizeof(p));
+  p.x = x.data_ptr();
+  p.packed = packed.data_ptr();
+  p.chunk_table = M.chunks.data();
+  p.instr_table = M.instr.data();
+  p.n_chunks = M.n_chunks;
+  p.n_instr = M.n_instr;
+  p.n_types = (int32_t)n_types;
+  p.dim_in = (int32_t)M.din;
+  p.out = out;
+  p.addend = nullptr;
+  p.dim_out = (int32_t)M.dout;
+  p.accumulate = accumulate;
+  p.scale = scale;
+  p.in_gate = in_gate != nullptr ? in_gate->blocks.data() : nullptr;
+  p.n_in_gate = in_gate != nullptr ? (int32_t)in_gate->blocks.size() : 0;
+}
+
+struct StageOperands {
+  Tensor h, types, wp1, wps, order;
+  bool typed = false;
+};
+
+StageOperands stage_operands(const Tensor& h_, const Tensor& types_, const Tensor& wp1_, const Tensor& wps_, GateBlocks& G,
+                             LinearMeta& M1, LinearMeta& MS, const char* op) {
+  require_gpu(h_, op);
+  StageOperands o;
+  o.h = h_.contiguous();
+  o.wp1 = wp1_.contiguous();
+  o.wps = wps_.contiguous();
+  TORCH_CHECK(o.h.scalar_type() == at::kFloat && o.wp1.scalar_type() == at::kFloat && o.wps.scalar_type() == at::kFloat,
+              "nequip_amd::", op, ": float32 only");
+  TORCH_CHECK(o.h.dim() == 2 && o.h.size(1) == G.din, "nequip_amd::", op, ": h must be [N, ", G.din, "] (pre-gate rows)");
+  TORCH_CHECK(M1.din == G.dout && MS.din == G.dout, "nequip_amd::", op, ": linear_1 / self-connection do not take the gate's output");
+  TORCH_CHECK(o.wp1.dim() == 2 && o.wp1.size(0) == 1 && o.wp1.size(1) == M1.wstride, "nequip_amd::", op, ": wp1 must be [1, ",
+              M1.wstride, "]");
+  TORCH_CHECK(o.wps.dim() == 2 && o.wps.size(1) == MS.wstride, "nequip_amd::", op, ": wps must be [T, ", MS.wstride, "]");
+  TORCH_CHECK(!env_on("NQA_NODE_EXACT_FP32") && !(std::getenv("NQA_NODE_F16") && std::getenv("NQA_NODE_F16")[0] == '0'),
+              "nequip_amd::", op, ": the fused node stage needs the default fp16-split packing");
+  o.types = (types_.scalar_type() == at::kLong ? types_ : types_.to(at::kLong)).contiguous();
+  TORCH_CHECK(o.types.numel() == o.h.size(0), "nequip_amd::", op, ": one atom type per row");
+  o.typed = o.wps.size(0) > 1;
+  const char* ord = std::getenv("NQA_NODE_TYPE_ORDER");
+  if (o.typed && !(ord != nullptr && ord[0] == '0')) o.order = type_order(o.types);
+  return o;
+}
+
+std::tuple<Tensor, Tensor> node_stage_fwd(const Tensor& h_, const Tensor& types_, const Tensor& wp1_, const Tensor& wps_,
+                                          std::string gate_key, std::string lin_key, std::string sc_key, double scale) {
+  c10::DeviceGuard guard(h_.device());
+  GateBlocks& G = gate_blocks(gate_key);
+  LinearMeta &M1 = linear_meta(lin_key, false), &MS = linear_meta(sc_key, false);
+  StageOperands o = stage_operands(h_, types_, wp1_, wps_, G, M1, MS, "node_stage_fwd");
+  const int64_t N = o.h.size(0);
+  Tensor x1 = at::empty({N, M1.dout}, o.h.options()), sc = at::empty({N, MS.dout}, o.h.options());
+  const Tensor p1 = packed_weights(o.wp1, M1, "N|" + lin_key), ps = packed_weights(o.wps, MS, "N|" + sc_key);
+  nqa_node_part parts[2];
+  fill_part(parts[0], o.h, p1, M1, 1, x1.data_ptr(), scale, 0, &G);
+  fill_part(parts[1], o.h, ps, MS, o.wps.size(0), sc.data_ptr(), 1.0, 0, &G);
+  NQA_CALL(nqa_node_fused(parts, 2, o.typed ? static_cast<const int64_t*>(o.types.data_ptr()) : nullptr,
+                          o.order.defined() ? i32(o.order) : nullptr, N, nullptr, 0, nullptr, 0, stream_of(o.h)),
+           "nqa_node_fused");
+  return std::make_tuple(x1, sc);
+}
+
+Tensor node_stage_bwd(const Tensor& g_x1, const Tensor& g_sc, const Tensor& h_, const Tensor& types_, const Tensor& wp1_,
+                      const Tensor& wps_, std::string gate_key, std::string lin_key, std::string sc_key, double scale) {
+  c10::DeviceGuard guard(h_.device());
+  GateBlocks& G = gate_blocks(gate_key);
+  LinearMeta &M1 = linear_meta(lin_key, false), &MS = linear_meta(sc_key, false);
+  LinearMeta &T1 = linear_meta(lin_key, true), &TS = linear_meta(sc_key, true);
+  StageOperands o = stage_operands(h_, types_, wp1_, wps_, G, M1, MS, "node_stage_bwd");
+  const int64_t N = o.h.size(0);
+  const Tensor g1 = g_x1.contiguous(), gs = g_sc.contiguous();
+  TORCH_CHECK(g1.scalar_type() == at::kFloat && g1.dim() == 2 && g1.size(0) == N && g1.size(1) == M1.dout &&
+                  gs.scalar_type() == at::kFloat && gs.dim() == 2 && gs.size(0) == N && gs.size(1) == MS.dout,
+              "nequip_amd::node_stage_bwd: gradients must be float32 [N, ", M1.dout, "] and [N, ", MS.dout, "]");
+  // transposed weights; linear_1's scale is folded into them (both operand sets accumulate into one tile)
+  Tensor w1t = transposed_weights(o.wp1, lin_key);
+  if (scale != 1.0) {
+    char a[40];
+    std::snprintf(a, sizeof(a), "%.17g", scale);
+    w1t = const_cached(w1t, std::string("node_scaled:") + a, [&] { return (w1t * scale).contiguous(); }).first;
+  }
+  const Tensor wst = transposed_weights(o.wps, sc_key);
+  const Tensor p1 = packed_weights(w1t, T1, "T|" + lin_key), ps = packed_weights(wst, TS, "T|" + sc_key);
+  Tensor gh = at::empty({N, G.din}, o.h.options());
+  nqa_node_part parts[2];
+  fill_part(parts[0], g1, p1, T1, 1, gh.data_ptr(), 1.0, 0, nullptr);
+  fill_part(parts[1], gs, ps, TS, o.wps.size(0), nullptr, 1.0, 1, nullptr);
+  NQA_CALL(nqa_node_fused(parts, 2, o.typed ? static_cast<const int64_t*>(o.types.data_ptr()) : nullptr,
+                          o.order.defined() ? i32(o.order) : nullptr, N, G.blocks.data(), (int32_t)G.blocks.size(),
+                          o.h.data_ptr(), (int32_t)G.din, stream_of(o.h)),
+           "nqa_node_fused");
+  return gh;
+}
+
+// ---- energy head (nequip_amd/nn/_energy_head.py) -----------------------------------------------------------------------------
+void check_head(const Tensor& h, const Tensor& w, const OptTensor& scales, const Tensor& types, const char* op) {
+  require_gpu(h, op);
+  TORCH_CHECK(h.scalar_type() == at::kFloat && w.scalar_type() == at::kFloat && h.dim() == 2 && w.dim() == 1 &&
+                  w.size(0) == h.size(1) && h.size(1) % 4 == 0,
+              "nequip_amd::", op, ": h [N, D] and w [D] float32, D a multiple of 4");
+  TORCH_CHECK(types.numel() == h.size(0), "nequip_amd::", op, ": one atom type per row");
+  if (scales.has_value() && scales->defined())
+    TORCH_CHECK(scales->scalar_type() == at::kDouble, "nequip_amd::", op, ": scales / shifts are float64");
+}
+
+Tensor energy_head_fwd(const Tensor& h_, const Tensor& w_, const OptTensor& scales, const OptTensor& shifts,
+                       const Tensor& types_, int64_t act, double cst) {
+  check_head(h_, w_, scales, types_, "energy_head_fwd");
+  c10::DeviceGuard guard(h_.device());
+  const Tensor h = h_.contiguous(), w = w_.contiguous();
+  const Tensor types = (types_.scalar_type() == at::kLong ? types_ : types_.to(at::kLong)).contiguous();
+  const OptTensor sc = as_f64(scales), sh = as_f64(shifts);
+  const int64_t N = h.size(0);
+  Tensor e = at::empty({N, 1}, h.options().dtype(at::kDouble));
+  NQA_CALL(nqa_energy_head(0, h.data_ptr(), w.data_ptr(), ptr(sc), sc.has_value() ? (int32_t)sc->numel() : 0, ptr(sh),
+                           sh.has_value() ? (int32_t)sh->numel() : 0, static_cast<const int64_t*>(types.data_ptr()), nullptr,
+                           e.data_ptr(), (int32_t)h.size(1), (int32_t)act, cst, N, stream_of(h)),
+           "nqa_energy_head");
+  return e;
+}
+
+Tensor energy_head_bwd(const Tensor& g_e, const Tensor& h_, const Tensor& w_, const OptTensor& scales, const Tensor& types_,
+                       int64_t act, double cst) {
+  check_head(h_, w_, scales, types_, "energy_head_bwd");
+  c10::DeviceGuard guard(h_.device());
+  const Tensor h = h_.contiguous(), w = w_.contiguous();
+  const Tensor types = (types_.scalar_type() == at::kLong ? types_ : types_.to(at::kLong)).contiguous();
+  const OptTensor sc = as_f64(scales);
+  const int64_t N = h.size(0);
+  const Tensor g = as_f64(g_e).view({-1});
+  TORCH_CHECK(g.numel() == N, "nequip_amd::energy_head_bwd: one energy gradient per atom");
+  Tensor gh = at::empty_like(h);
+  NQA_CALL(nqa_energy_head(1, h.data_ptr(), w.data_ptr(), ptr(sc), sc.has_value() ? (int32_t)sc->numel() : 0, nullptr, 0,
+                           static_cast<const int64_t*>(types.data_ptr()), g.data_ptr(), gh.data_ptr(), (int32_t)h.size(1),
+                           (int32_t)act, cst, N, stream_of(h)),
+           "nqa_energy_head");
+  return gh;
+}
+
 const char* const kEdgeCfg = "int lmax, bool want_sh, bool want_emb, int nb, float rmax_recip, float p, float factor, bool f32";
 
 bool already_registered() {
@@ -903,6 +1506,20 @@ TORCH_LIBRARY_FRAGMENT(nequip_amd, m) {
   m.def("radial_mlp_fwd(Tensor emb, Tensor w0, Tensor w1, float alpha0, float alpha1) -> Tensor");
   m.def("radial_mlp_bwd(Tensor emb, Tensor w0, Tensor w1, Tensor g, float alpha0, float alpha1) -> Tensor");
   m.def("node_linear(Tensor x, Tensor wp, Tensor? addend, Tensor? types, str key, float scale, bool transposed) -> Tensor");
+  m.def("radial_tp_fwd(Tensor emb, Tensor x, Tensor edge_attr, Tensor w0, Tensor w1, float alpha0, float alpha1, "
+        "Tensor edge_dst, Tensor edge_src, Tensor? edge_shift, str plan) -> (Tensor, Tensor)");
+  m.def("radial_tp_bwd(Tensor grad_out, Tensor emb, Tensor x, Tensor edge_attr, Tensor w_rows, Tensor w0, Tensor w1, "
+        "float alpha0, float alpha1, Tensor edge_dst, Tensor edge_src, Tensor? edge_shift, str plan, bool need_emb, "
+        "bool need_x, bool need_y) -> (Tensor, Tensor, Tensor)");
+  m.def("force_virial(Tensor g_vec, Tensor edge_vec, Tensor edge_index, Tensor? batch, Tensor? cell, SymInt num_nodes, "
+        "SymInt num_frames) -> (Tensor, Tensor, Tensor)");
+  m.def("node_stage_fwd(Tensor h, Tensor types, Tensor wp1, Tensor wps, str gate_key, str lin_key, str sc_key, "
+        "float scale) -> (Tensor, Tensor)");
+  m.def("node_stage_bwd(Tensor g_x1, Tensor g_sc, Tensor h, Tensor types, Tensor wp1, Tensor wps, str gate_key, "
+        "str lin_key, str sc_key, float scale) -> Tensor");
+  m.def("energy_head_fwd(Tensor h, Tensor w, Tensor? scales, Tensor? shifts, Tensor types, int act, float cst) "
+        "-> Tensor");
+  m.def("energy_head_bwd(Tensor g_e, Tensor h, Tensor w, Tensor? scales, Tensor types, int act, float cst) -> Tensor");
   m.def("gate(Tensor x, str key) -> Tensor");
   m.def("gate_bwd(Tensor x, Tensor g, str key) -> Tensor");
   m.impl("tp_scatter_fwd", c10::DispatchKey::CUDA, TORCH_FN(tp_scatter_fwd));
@@ -914,6 +1531,13 @@ TORCH_LIBRARY_FRAGMENT(nequip_amd, m) {
   m.impl("radial_mlp_fwd", c10::DispatchKey::CUDA, TORCH_FN(radial_mlp_fwd));
   m.impl("radial_mlp_bwd", c10::DispatchKey::CUDA, TORCH_FN(radial_mlp_bwd));
   m.impl("node_linear", c10::DispatchKey::CUDA, TORCH_FN(node_linear));
+  m.impl("radial_tp_fwd", c10::DispatchKey::CUDA, TORCH_FN(radial_tp_fwd));
+  m.impl("radial_tp_bwd", c10::DispatchKey::CUDA, TORCH_FN(radial_tp_bwd));
+  m.impl("force_virial", c10::DispatchKey::CUDA, TORCH_FN(force_virial));
+  m.impl("node_stage_fwd", c10::DispatchKey::CUDA, TORCH_FN(node_stage_fwd));
+  m.impl("node_stage_bwd", c10::DispatchKey::CUDA, TORCH_FN(node_stage_bwd));
+  m.impl("energy_head_fwd", c10::DispatchKey::CUDA, TORCH_FN(energy_head_fwd));
+  m.impl("energy_head_bwd", c10::DispatchKey::CUDA, TORCH_FN(energy_head_bwd));
   m.impl("gate", c10::DispatchKey::CUDA, TORCH_FN(gate));
   m.impl("gate_bwd", c10::DispatchKey::CUDA, TORCH_FN(gate_bwd));
 }

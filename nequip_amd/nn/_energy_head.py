@@ -62,3 +62,62 @@ def energy_head(h, w, scales, shifts, types, act: int, cst: float) -> torch.Tens
     """``[N, 1]`` float64 per-atom energies ``shift[t] + scale[t] * double(sum_c w[c] cst act(h[:, c]))``; the gradient
     w.r.t. ``h`` is one launch (constant weights: eval mode)."""
     return _EnergyHeadFn.apply(h, w, scales, shifts, types, act, cst)
+
+
+# ---- the same two launches as dispatcher ops (a tracer keeps them: utils/tracing.py) ----------------------------------------
+_NS = "nequip_amd"
+_lib_def = torch.library.Library(_NS, "FRAGMENT")
+_lib_def.define("energy_head_fwd(Tensor h, Tensor w, Tensor? scales, Tensor? shifts, Tensor types, int act, float cst) "
+                "-> Tensor")
+_lib_def.define("energy_head_bwd(Tensor g_e, Tensor h, Tensor w, Tensor? scales, Tensor types, int act, float cst) -> Tensor")
+
+
+def _fwd_cuda(h, w, scales, shifts, types, act, cst):
+    h = h.contiguous()
+    e = torch.empty((h.shape[0], 1), dtype=torch.float64, device=h.device)
+    _launch(0, h, w.contiguous(), scales, shifts, types.contiguous(), None, e, int(act), float(cst))
+    return e
+
+
+def _bwd_cuda(g_e, h, w, scales, types, act, cst):
+    h = h.contiguous()
+    g = g_e.to(torch.float64).contiguous().view(-1)
+    gh = torch.empty_like(h)
+    _launch(1, h, w.contiguous(), scales, None, types.contiguous(), g, gh, int(act), float(cst))
+    return gh
+
+
+_lib_def.impl("energy_head_fwd", _fwd_cuda, "CUDA")
+_lib_def.impl("energy_head_bwd", _bwd_cuda, "CUDA")
+
+
+@torch.library.register_fake(f"{_NS}::energy_head_fwd")
+def _fwd_fake(h, w, scales, shifts, types, act, cst):
+    torch._check(h.dim() == 2 and w.dim() == 1 and w.shape[0] == h.shape[1], lambda: "h [N, D], w [D]")
+    return h.new_empty((h.shape[0], 1), dtype=torch.float64)
+
+
+@torch.library.register_fake(f"{_NS}::energy_head_bwd")
+def _bwd_fake(g_e, h, w, scales, types, act, cst):
+    return torch.empty_like(h)
+
+
+def _op_setup(ctx, inputs, output):
+    h, w, scales, shifts, types, act, cst = inputs
+    ctx.save_for_backward(h, w, scales, types)
+    ctx.act, ctx.cst = act, cst
+
+
+def _op_backward(ctx, g):
+    h, w, scales, types = ctx.saved_tensors
+    gh = None
+    if ctx.needs_input_grad[0]:
+        gh = torch.ops.nequip_amd.energy_head_bwd(g, h, w, scales, types, ctx.act, ctx.cst)
+    return gh, None, None, None, None, None, None
+
+
+torch.library.register_autograd(f"{_NS}::energy_head_fwd", _op_backward, setup_context=_op_setup)
+
+
+def energy_head_op(h, w, scales, shifts, types, act: int, cst: float) -> torch.Tensor:
+    return torch.ops.nequip_amd.energy_head_fwd(h, w, scales, shifts, types, int(act), float(cst))

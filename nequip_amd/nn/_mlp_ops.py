@@ -18,33 +18,32 @@ _lib_def.define("radial_mlp_bwd(Tensor emb, Tensor w0, Tensor w1, Tensor g, floa
 _lib_def.define("radial_mlp_bwd_bwd(Tensor emb, Tensor w0, Tensor w1, Tensor g, Tensor c, float alpha0, float alpha1, "
                 "bool need_emb, bool need_g) -> (Tensor, Tensor)")
 
-def _cache_for(w1: torch.Tensor):
-    """A fresh image cache per call: the op sees the weights as plain tensors (no parameter identity to key a cache on --
-    addresses are re-used across models), so the split / re-laid-out second-layer weights are rebuilt by the ~7 us prepass
-    kernel each time; the eager modules keep theirs per parameter version."""
+def _cache_for(w1: torch.Tensor, alpha1: float = 1.0):
+    """The split / re-laid-out images of the second-layer weights, once per constant: the op sees the weights as plain
+    tensors, so the cache is keyed on the identity of their storage (``utils/constcache.py``) -- a compiled graph's constant
+    buffer hits at every call, a weight tensor that is recomputed per call runs the ~7 us prepass kernel each time."""
+    from ..utils import constcache
     from .mlp import _WeightImages
 
-    c = _WeightImages()
-    c.validate(w1)
-    return c
+    return constcache.get(w1, ("radial_mlp_images", float(alpha1)), _WeightImages)  # (the prepass folds alpha1 in)
 
 
 def _fwd_cuda(emb, w0, w1, alpha0, alpha1):
     from . import mlp as m
 
-    return m._launch_fwd(emb.contiguous(), w0, w1, alpha0, alpha1, m.radial_mlp_mode(), _cache_for(w1))
+    return m._launch_fwd(emb.contiguous(), w0, w1, alpha0, alpha1, m.radial_mlp_mode(), _cache_for(w1, alpha1))
 
 
 def _bwd_cuda(emb, w0, w1, g, alpha0, alpha1):
     from . import mlp as m
 
-    return m._launch_bwd(emb.contiguous(), w0, w1, alpha0, alpha1, g.contiguous(), m.radial_mlp_mode(), _cache_for(w1))
+    return m._launch_bwd(emb.contiguous(), w0, w1, alpha0, alpha1, g.contiguous(), m.radial_mlp_mode(), _cache_for(w1, alpha1))
 
 
 def _bwd_bwd_cuda(emb, w0, w1, g, c, alpha0, alpha1, need_emb, need_g):
     from . import mlp as m
 
-    mode, cache = m.radial_mlp_mode(), _cache_for(w1)
+    mode, cache = m.radial_mlp_mode(), _cache_for(w1, alpha1)
     emb, g, c = emb.contiguous(), g.contiguous(), c.contiguous()
     g_emb2 = emb.new_empty(0)
     gg = emb.new_empty(0)

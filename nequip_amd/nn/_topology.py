@@ -141,7 +141,7 @@ def build_owner_csr(edge_dst: torch.Tensor, edge_src: torch.Tensor, rows: torch.
     own_i = (i == j) | ((i < j) ^ (((i + j) & 1) == 1))
     owner, other = torch.where(own_i, i, j), torch.where(own_i, j, i)
     e_in, e_out = torch.where(own_i, ea, eb), torch.where(own_i, eb, ea)  # dst = owner / dst = other
-    perm = torch.argsort(owner * N + other)
+    perm = torch.argsort(owner * N + other, stable=True)  # (stable: several periodic images of one neighbour tie)
     owner_s, other_s = owner.index_select(0, perm), other.index_select(0, perm)
     nodes = torch.arange(N + 1, dtype=torch.int64, device=dev)
     owner_rowptr = torch.searchsorted(owner_s, nodes).to(torch.int32)
@@ -197,8 +197,8 @@ class _TopologyCache:
     """Reuse of the CSRs / pairing of an edge list: across the layers of one forward, and across forwards for as long as
     the caller keeps handing in the SAME index tensor (static neighbour list: benchmark loops, MD between list rebuilds).
 
-    An entry is keyed on the identity of the index storage -- the very tensor object must still be alive (weak
-    reference, so a recycled ``id`` cannot alias), with the same version counter, data pointer, size and strides.  What
+    An entry is keyed on the identity of the index storage (which the entry keeps alive, so a recycled address cannot
+    alias), with the same version counter, data pointer, size and strides.  What
     this cannot see is a caller that rewrites the index memory behind PyTorch's back (a DLPack / Kokkos view refilled
     by LAMMPS, ``.data`` writes, raw-pointer kernels): the version counter does not move and a stale CSR would give
     silently wrong forces.  Three guards:
@@ -212,8 +212,7 @@ class _TopologyCache:
 
     A few entries are kept (least recently used first out), so alternating graphs do not rebuild on every call.
 
-    Memory: an entry holds views of the caller's int64 index tensors (which keeps their storage alive: the weak references
-    above guard against recycled ``id`` values, they do not free an entry early), both int32 CSRs and the pairing / owner
+    Memory: an entry holds the storage of the caller's int64 index tensors, both int32 CSRs and the pairing / owner
     lists -- about 100 bytes per directed edge, i.e. ~0.4 GB per cached graph at the 100 000-atom Cu box.  A driver that
     builds a new neighbour list every step (MD) therefore keeps the last ``MAX_ENTRIES`` graphs resident;
     ``NQA_TOPOLOGY_CACHE_ENTRIES=1`` (or ``topology_cache.MAX_ENTRIES = 1``) bounds that to the current graph."""
@@ -264,9 +263,14 @@ class _TopologyCache:
             self._scope = None
 
     def get(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int) -> EdgeTopology:
+        # identity of the STORAGE behind the two index tensors (the rule of csrc/torch_ops/nequip_amd_torch.cpp): every
+        # `edge_index[0]` / `edge_index[1]` view of one input tensor maps to the same entry, whoever made the view -- the
+        # model, an FX graph, or the AOTInductor runtime, whose views are new Python objects at every op call.  An entry
+        # holds the two storages, so their addresses cannot be recycled under it.
         bd, bs = self._base(edge_dst), self._base(edge_src)
+        sd, ss = edge_dst.untyped_storage(), edge_src.untyped_storage()
         key = (
-            id(bd), id(bs), bd._version, bs._version, edge_dst.data_ptr(), edge_src.data_ptr(),
+            sd._cdata, ss._cdata, edge_dst._version, edge_src._version, edge_dst.data_ptr(), edge_src.data_ptr(),
             edge_dst.numel(), edge_dst.stride(0), edge_src.stride(0), int(num_nodes), str(edge_dst.device),
         )  # fmt: skip
         if self._scope is not None:  # untrusted caller: per-evaluation sharing only
@@ -276,7 +280,7 @@ class _TopologyCache:
             return topo
         verify = os.environ.get("NQA_TOPOLOGY_VERIFY", "") not in ("", "0")
         for i, (k, refs, topo, csum) in enumerate(self._entries):
-            if k == key and refs[0]() is bd and refs[1]() is bs:
+            if k == key:
                 if verify:
                     now = self._checksum(edge_dst, edge_src)
                     if csum is None:
@@ -290,9 +294,7 @@ class _TopologyCache:
                     self._entries.append(self._entries.pop(i))
                 return topo
         topo = EdgeTopology(edge_dst, edge_src, num_nodes, rowptr_dst=self._rowptr_hint(bd, edge_dst, num_nodes))
-        self._entries = [e for e in self._entries if e[1][0]() is not None and e[1][1]() is not None]
-        self._entries.append((key, (weakref.ref(bd), weakref.ref(bs)), topo,
-                              self._checksum(edge_dst, edge_src) if verify else None))
+        self._entries.append((key, (sd, ss), topo, self._checksum(edge_dst, edge_src) if verify else None))
         while len(self._entries) > self.MAX_ENTRIES:
             self._entries.pop(0)
         return topo

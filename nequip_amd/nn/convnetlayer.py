@@ -2,6 +2,8 @@
 
 from typing import Any, Callable, Dict, Optional
 
+import os
+
 import torch
 
 from ..data import AtomicDataDict
@@ -85,7 +87,9 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
         if not self.defer_gate or self.resnet or not isinstance(self.equivariant_nonlin, Gate):
             return False
         meta = self.equivariant_nonlin._kernel_meta
-        if meta is None or not h.is_cuda or h.dtype != torch.float32 or self.training or traceable():
+        if meta is None or not h.is_cuda or h.dtype != torch.float32 or self.training:
+            return False
+        if traceable() and os.environ.get("NQA_TRACE_NO_NODE_FUSION", "") not in ("", "0"):
             return False
         return _node_kernels.fusion_enabled() and meta.fusable()
 
@@ -93,7 +97,8 @@ class ConvNetLayer(GraphModuleMixin, torch.nn.Module):
         old_x = data[AtomicDataDict.NODE_FEATURES_KEY]
         data = self.conv(data)
         if self._gate_deferred(data[AtomicDataDict.NODE_FEATURES_KEY]):
-            data["_nqa_pregate"] = (data[AtomicDataDict.NODE_FEATURES_KEY], self.equivariant_nonlin._kernel_meta)
+            data["_nqa_pregate"] = (data[AtomicDataDict.NODE_FEATURES_KEY], self.equivariant_nonlin._kernel_meta,
+                                    self.equivariant_nonlin._op_key)
             return data
         data[AtomicDataDict.NODE_FEATURES_KEY] = self.equivariant_nonlin(data[AtomicDataDict.NODE_FEATURES_KEY])
         if self.resnet:

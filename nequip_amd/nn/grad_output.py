@@ -2,6 +2,8 @@
 (mirror of ``nequip/nn/grad_output.py:107-298``; symmetric-displacement trick for the virial,
 ``create_graph=self.training`` so that force-matching training can differentiate again)."""
 
+import os
+
 import torch
 
 from ..data import AtomicDataDict
@@ -43,7 +45,8 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
             num_batch = 1
         pos = data[K.POSITIONS_KEY]
         has_cell = K.CELL_KEY in data
-        if not self.training and pos.is_cuda and pos.dtype == torch.float64 and not traceable():
+        if (not self.training and pos.is_cuda and pos.dtype == torch.float64
+                and (not traceable() or os.environ.get("NQA_TRACE_REFERENCE_TAIL", "") in ("", "0"))):
             return self._forward_inference(data, pos, batch, num_batch, has_cell)
         if has_cell:
             orig_cell = data[K.CELL_KEY]
@@ -127,14 +130,30 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         cell = data[K.CELL_KEY].view(-1, 3, 3).expand(num_batch, 3, 3) if has_cell else None
         shift = data[K.EDGE_CELL_SHIFT_KEY].contiguous() if has_cell else None
         ebatch = batch.contiguous() if (has_cell and batch is not None) else None
+        tracing = traceable()
         with torch.no_grad():
-            edge_vec = _EdgeVectorsFn.apply(pos.detach(), cell, edge_index, shift, ebatch)
+            if tracing:  # the same kernels as dispatcher ops (nn/_edge_vector_ops.py, nn/_force_ops.py)
+                from ._edge_vector_ops import edge_vectors as _edge_vectors_op
+
+                edge_vec = _edge_vectors_op(pos.detach(), cell, edge_index, shift, ebatch)
+            else:
+                edge_vec = _EdgeVectorsFn.apply(pos.detach(), cell, edge_index, shift, ebatch)
         edge_vec.requires_grad_(True)
         data[K.EDGE_VECTORS_KEY] = edge_vec
         data = self.func(data)
         with inputs_only_backward():
             g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].to(torch.float64).contiguous()
         num_nodes = pos.shape[0]
+        if tracing:
+            from ._force_ops import force_virial
+
+            forces, virial, stress = force_virial(g, edge_vec.detach(), edge_index, batch, cell, num_nodes, num_batch)
+            data[K.FORCE_KEY] = forces
+            if has_cell:
+                data[K.STRESS_KEY] = stress
+            data[K.VIRIAL_KEY] = virial
+            data[K.EDGE_VECTORS_KEY] = edge_vec.detach()
+            return data
         topo = topology_cache.get(edge_index[0], edge_index[1], num_nodes)
         rp_d, eid_d, _ = topo.by_dst
         rp_s, eid_s, _ = topo.by_src

@@ -16,7 +16,7 @@ from ..o3 import _node_kernels
 from ..o3.irreps import Irreps
 from ..o3.modules import FullyConnectedTensorProduct, Linear
 from ..utils.wgrad import differentiable_parameters
-from . import _paired_radial, _segmented
+from . import _paired_radial, _radial_tp_ops, _segmented
 from ._ghost_exchange import NoOpGhostExchangeModule
 from ._graph_mixin import GraphModuleMixin
 from ._topology import topology_cache
@@ -110,11 +110,11 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         )
         self.is_first_layer = is_first_layer
 
-    def _fused_node_stage(self, data, h: torch.Tensor, gate_meta, num_local_nodes: int):
+    def _fused_node_stage(self, data, h: torch.Tensor, gate_meta, num_local_nodes: int, gate_key: str = ""):
         """``(x1, sc)`` of this block from the previous layer's pre-gate rows in one launch, or None when the conditions of
         the fused kernel do not hold (then the caller applies the gate and takes the separate launches)."""
         norm = self.avg_num_neighbors_norm
-        if (self.sc is None or not h.is_cuda or h.dtype != torch.float32 or traceable() or self.training
+        if (self.sc is None or not h.is_cuda or h.dtype != torch.float32 or self.training
                 or not _node_kernels.fusion_enabled() or not norm.norm_shortcut or norm.norm_key in data
                 or self.sc._meta is None or self.linear_1.weight_numel == 0
                 or differentiable_parameters(self.training, self.sc.weight)
@@ -124,6 +124,11 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         if table is None or table.shape[0] > 16:
             return None
         types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: h.shape[0]].contiguous()
+        if traceable():  # the same launch as a dispatcher-op pair (o3/_node_ops.py::node_stage)
+            from ..o3 import _node_ops
+
+            return _node_ops.node_stage(h, types, self.linear_1.traced_weights(), self.sc.traced_weights_typed(table),
+                                        gate_key, self.linear_1._op_key, self.sc._op_key, float(norm.norm_scalar))
         wp1 = self.linear_1.eval_weights(h.device, h.dtype)
         wps = self.sc.eval_weights_typed(table, h.dtype)
         return _node_kernels.fused_node_stage(h, types, gate_meta, wp1, self.linear_1._meta, float(norm.norm_scalar), wps,
@@ -192,9 +197,9 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         fused = None
         if pregate is not None:
             gate_meta = pregate[1]
-            fused = self._fused_node_stage(data, x, gate_meta, num_local_nodes)
+            fused = self._fused_node_stage(data, x, gate_meta, num_local_nodes, pregate[2])
             if fused is None:
-                x = _node_kernels.gate(x, gate_meta)
+                x = _node_kernels.apply_deferred_gate(pregate)
 
         sc = None
         sc_stream = None
@@ -224,7 +229,7 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
         norm = self.avg_num_neighbors_norm
         if fused is not None:
             x = x1
-        elif norm.norm_shortcut and x.is_cuda and not traceable() and norm.norm_key not in data:
+        elif norm.norm_shortcut and x.is_cuda and norm.norm_key not in data:
             # one avg_num_neighbors for all types: 1/sqrt(avg) rides on the linear_1 launch (no separate N x D pass)
             x = self.linear_1(x, scale=norm.norm_scalar)
         else:
@@ -264,7 +269,13 @@ class InteractionBlock(GraphModuleMixin, torch.nn.Module):
             # interaction -- evaluate it once per pair (nn/_paired_radial.py); None if the list does not pair up
             topo = topology_cache.get(edge_index[0], edge_index[1], x.size(0))
             pairing = topo.pairing(data.get(AtomicDataDict.EDGE_CELL_SHIFT_KEY))
-        if pairing is not None:
+        if (pairing is None and traceable() and self.paired_radial_ok and AtomicDataDict.POSITIONS_KEY in data
+                and _radial_tp_ops.usable(self.edge_mlp, self.tp_scatter, x, emb)):
+            # while a tracer follows the model: radial MLP + tensor product as ONE dispatcher-op pair whose implementation
+            # takes the pairing decision at run time (nn/_radial_tp_ops.py)
+            x = _radial_tp_ops.radial_tp(self.edge_mlp, self.tp_scatter, emb, x, data[AtomicDataDict.EDGE_ATTRS_KEY],
+                                         edge_index[0], edge_index[1], data.get(AtomicDataDict.EDGE_CELL_SHIFT_KEY))
+        elif pairing is not None:
             # the representative rows of the embedding are the same for every layer: gathered once per evaluation
             emb_half = data.get("_nqa_edge_embedding_pairs")
             if emb_half is None or emb_half.shape[0] != pairing.num_pairs:

@@ -58,7 +58,11 @@ class _WeightImages:
         if key != self.key:
             self.key, self.images = key, {}
 
-    def get(self, w1: torch.Tensor, mode: int, backward: int, nbytes: int):
+    def get(self, w1: torch.Tensor, mode: int, backward: int, nbytes: int, rows: int = 1):
+        """(workspace, filled?).  ``rows``: the rows of the launch -- one over zero rows returns before the prepass, so it
+        gets a scratch buffer and leaves no image behind that a later call would take for a filled one."""
+        if rows == 0:
+            return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=w1.device), False
         hit = (mode, backward) in self.images
         if not hit:
             self.images[(mode, backward)] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=w1.device)
@@ -76,7 +80,7 @@ def _launch_fwd(emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _We
     flops = 2.0 * E * (nb * H + H * W)
     mode = forward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
-    ws, ready = cache.get(w1, mode, 0, ws_bytes)
+    ws, ready = cache.get(w1, mode, 0, ws_bytes, E)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (nb + W), flops):
         rc = lib.nqa_radial_mlp_fwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, nb, H, W, E,
                                     _ptr(out), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
@@ -95,7 +99,7 @@ def _launch_bwd(emb, w0, w1, alpha0: float, alpha1: float, g_w, mode: int, cache
     flops = 2.0 * E * (nb * H * 2 + H * W)
     mode = backward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
-    ws, ready = cache.get(w1, mode, 1, ws_bytes)
+    ws, ready = cache.get(w1, mode, 1, ws_bytes, E)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
         rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, _ptr(g_w), nb, H,
                                     W, E, _ptr(g_emb), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
@@ -119,7 +123,7 @@ def _launch_bwd_train(emb, w0, w1, alpha0: float, alpha1: float, g_w, cot, mode:
     flops = 2.0 * E * (nb * H * (3 if cot is None else 5) + H * W)
     mode = backward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
-    ws, ready = cache.get(w1, mode, 1, ws_bytes)
+    ws, ready = cache.get(w1, mode, 1, ws_bytes, E)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd_train", 4.0 * E * (3 * nb + W + H), flops):
         rc = lib.nqa_radial_mlp_bwd_train(_lib.NQA_F32, mode, _ptr(emb), _ptr(cot), _ptr(w0), alpha0, _ptr(w1), alpha1,
                                           _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(hid), _ptr(parts), _ptr(ws),
@@ -137,7 +141,7 @@ def _launch_fwd_tangent(emb, cot, w0, w1, alpha0: float, alpha1: float, mode: in
     H, W = w1.shape
     out = torch.empty((E, W), dtype=emb.dtype, device=emb.device)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 0, H, W)
-    ws, ready = cache.get(w1, mode, 0, ws_bytes)
+    ws, ready = cache.get(w1, mode, 0, ws_bytes, E)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_fwd", 4.0 * E * (2 * nb + W), 2.0 * E * (2 * nb * H + H * W)):
         rc = lib.nqa_radial_mlp_fwd_tangent(_lib.NQA_F32, mode, _ptr(emb), _ptr(cot), _ptr(w0), alpha0, _ptr(w1),
                                             alpha1, nb, H, W, E, _ptr(out), _ptr(ws), ws_bytes, int(ready),
@@ -158,7 +162,7 @@ def _launch_bwd_paired(emb, w0, w1, alpha0: float, alpha1: float, g_a, g_b, mode
     flops = 2.0 * E * (nb * H * 2 + H * W)
     mode = backward_mode(mode)
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
-    ws, ready = cache.get(w1, mode, 1, ws_bytes)
+    ws, ready = cache.get(w1, mode, 1, ws_bytes, E)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + 2 * W), flops):
         rc = lib.nqa_radial_mlp_bwd_paired(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, _ptr(g_a),
                                            _ptr(g_b), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes, int(ready),
@@ -496,7 +500,7 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
         tail = self.__dict__.get("_scale_shift")
         fn = self.mlp_module
         if (tail is None or fn.num_layers != 1 or fn.has_bias or fn.dims[-1] != 1 or not h.is_cuda or h.dtype != torch.float32
-                or self.training or traceable() or h.shape[1] % 4 != 0 or len(gate_meta.blocks) != 1
+                or self.training or h.shape[1] % 4 != 0 or len(gate_meta.blocks) != 1
                 or gate_meta.blocks[0][4] >= 0 or os.environ.get("NQA_NO_ENERGY_HEAD", "") not in ("", "0")
                 or differentiable_parameters(self.training, fn.mlp[0].weight)):
             return None
@@ -504,6 +508,14 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
         if ss.field != self.out_field or ss.out_field != self.out_field:
             return None
         lin = fn.mlp[0]
+        types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: h.shape[0]].contiguous()
+        _, _, _, _, _, act, cst = gate_meta.blocks[0]
+        if traceable():  # the same launch as a dispatcher-op pair (nn/_energy_head.py)
+            from ._energy_head import energy_head_op
+
+            w = (lin.weight.detach().view(-1) * lin.alpha_value).to(torch.float32)
+            return energy_head_op(h, w, ss.scales.view(-1) if ss.has_scales else None,
+                                  ss.shifts.view(-1) if ss.has_shifts else None, types, act, cst)
         if torch.is_grad_enabled() and lin.weight.requires_grad and not h.requires_grad:
             # nothing upstream asks for a gradient but the readout weight does (an energy-only backward in eval mode): the
             # module chain, whose `mm` gives that gradient -- the fused head treats the weight as a constant
@@ -513,8 +525,6 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
         if cached is None or cached[0] != key:
             cached = (key, (lin.weight.detach().view(-1) * lin.alpha_value).to(torch.float32).contiguous())
             self.__dict__["_head_w"] = cached
-        types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: h.shape[0]].contiguous()
-        _, _, _, _, _, act, cst = gate_meta.blocks[0]
         from ._energy_head import energy_head
 
         return energy_head(h, cached[1], ss.scales.view(-1) if ss.has_scales else None,
@@ -523,7 +533,7 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         pregate = data.pop("_nqa_pregate", None)
         if pregate is not None:  # the last convolution layer left its Gate to this module (ConvNetLayer.defer_gate)
-            h, gate_meta = pregate
+            h, gate_meta = pregate[0], pregate[1]
             e = self._energy_head(data, h, gate_meta)
             if e is not None:
                 data[self.out_field] = e
@@ -531,6 +541,6 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
                 return data
             from ..o3 import _node_kernels
 
-            data[self.field] = _node_kernels.gate(h, gate_meta)
+            data[self.field] = _node_kernels.apply_deferred_gate(pregate)
         data[self.out_field] = self.mlp_module(data[self.field])
         return data

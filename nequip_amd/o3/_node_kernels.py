@@ -19,6 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from .. import _lib
+from ..utils import constcache as _constcache
 from ..utils import ktimer
 from ..utils import wgrad as _wgrad
 from .irreps import Irreps
@@ -123,17 +124,19 @@ def packed_weights(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.
     """``wp [T, wstride]`` split into 16-bit planes in MFMA-fragment order (``nqa_node_weights_pack``: two fp16 planes of
     power-of-two scaled K blocks by default, three bf16 planes with ``NQA_NODE_F16=0``).  Constant
     weights (eval mode: the modules keep ``wp`` alive across steps) are packed once per version of the tensor; a ``wp``
-    that is part of an autograd graph (training: rebuilt from the parameter every step) is packed once per step."""
+    that is part of an autograd graph (training: rebuilt from the parameter every step) is packed per call."""
+    key = ("node_packed", id(meta), which, os.environ.get("NQA_NODE_F16", ""))  # (the layout depends on the split in use)
+    # constants (eval mode: the module keeps `wp`; a compiled graph: a constant buffer) are packed once per version of the
+    # tensor -- the cache is keyed on the storage (utils/constcache.py); a graph tensor of a training step lives for that
+    # step only and is packed per call when NQA_NODE_TRAIN_PACKED=1 asks for it at all
+    if wp.requires_grad or getattr(wp, "_nqa_volatile", False):
+        return _pack(wp, meta, which)
+    return _constcache.get(wp, key, lambda: _pack(wp, meta, which))
+
+
+def _pack(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.Tensor:
     lib = _lib.load()
     ct, nchunks, it, ninstr = meta.host_tables(which)
-    key = (id(meta), which, os.environ.get("NQA_NODE_F16", ""))  # (the layout depends on the split the library uses)
-    # the cache rides on the tensor object: a constant lives as long as its module keeps it; a graph tensor (training) lives
-    # for one step -- autograd hands the same object back from ctx.saved_tensors -- and is used twice per direction in it
-    cache = wp.__dict__.setdefault("_nqa_packed", {}) if hasattr(wp, "__dict__") else None
-    if cache is not None:
-        hit = cache.get(key)
-        if hit is not None and hit[0] == wp._version:
-            return hit[1]
     T = wp.shape[0]
     nbytes = lib.nqa_node_weights_pack_bytes(ctypes.cast(ct, ctypes.c_void_p), nchunks, ctypes.cast(it, ctypes.c_void_p),
                                              ninstr, T)
@@ -146,8 +149,6 @@ def packed_weights(wp: torch.Tensor, meta: NodeLinearMeta, which: str) -> torch.
                                        ctypes.cast(it, ctypes.c_void_p), ninstr, T, w.shape[1], _ptr(out),
                                        _stream(wp.device))
     _lib.check(rc, "nqa_node_weights_pack")
-    if cache is not None:
-        cache[key] = (wp._version, out)
     return out
 
 
@@ -255,12 +256,8 @@ def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Ten
         wt._nqa_adjoint_src = (_transposed(meta), weakref.ref(wp))
         wp._nqa_step_transposed = (meta, wt)
         return wt
-    # constant weights (eval mode): the modules keep `wp` alive across steps, so the transposed copy rides on it
-    cached = getattr(wp, "_nqa_transposed", None)
-    if cached is None or cached[0] != wp._version:
-        cached = (wp._version, meta.transpose_weights(wp))
-        wp._nqa_transposed = cached
-    return cached[1]
+    # constant weights (eval mode / a compiled graph's constant): one transposed copy per version of the tensor
+    return _constcache.get(wp, ("node_transposed", id(meta)), lambda: meta.transpose_weights(wp).contiguous())
 
 
 def _weight_grad(x, g, types, meta: NodeLinearMeta, T: int):
@@ -428,6 +425,19 @@ def gate(x, meta: GateMeta):
     return _GateFn.apply(x, meta)
 
 
+def apply_deferred_gate(pregate):
+    """The gate a ``ConvNetLayer`` left to its consumer (``data["_nqa_pregate"] = (h, meta, op key)``), for a consumer whose
+    fused form does not apply: the gate kernel, as a dispatcher op while a tracer follows the model."""
+    from ..utils.tracing import traceable
+
+    h, meta, key = pregate
+    if traceable():
+        from . import _node_ops
+
+        return _node_ops.gate_op(h, key)
+    return gate(h, meta)
+
+
 # ---- fused node stage (nqa_node_fused): Gate folded into its consumers / into the producers of its gradient -------------
 def fusion_enabled() -> bool:
     """The fused node stage needs the default fp16-split packing; ``NQA_NO_NODE_FUSION=1`` keeps the separate launches."""
@@ -531,11 +541,7 @@ def _scaled(wp: torch.Tensor, scale: float) -> torch.Tensor:
     """``wp * scale`` as a constant riding on ``wp`` (eval mode: folded once per weight version)."""
     if scale == 1.0:
         return wp
-    cached = getattr(wp, "_nqa_scaled", None)
-    if cached is None or cached[0] != (wp._version, scale):
-        cached = ((wp._version, scale), (wp * scale).contiguous())
-        wp._nqa_scaled = cached
-    return cached[1]
+    return _constcache.get(wp, ("node_scaled", float(scale)), lambda: (wp * scale).contiguous())
 
 
 class _FusedNodeStageFn(torch.autograd.Function):

@@ -25,6 +25,12 @@ _lib_def.define("node_linear(Tensor x, Tensor wp, Tensor? addend, Tensor? types,
 _lib_def.define("gate(Tensor x, str key) -> Tensor")
 _lib_def.define("gate_bwd(Tensor x, Tensor g, str key) -> Tensor")
 _lib_def.define("gate_bwd_bwd(Tensor x, Tensor g, Tensor c, str key, bool need_x, bool need_g) -> (Tensor, Tensor)")
+# Gate + linear_1 + typed self-connection of a layer boundary as one launch per direction (`nqa_node_fused`, inference:
+# constant weights, first order).  h: the previous layer's PRE-gate rows; x1 = scale * linear_1(Gate(h)); sc = sc(Gate(h), types)
+_lib_def.define("node_stage_fwd(Tensor h, Tensor types, Tensor wp1, Tensor wps, str gate_key, str lin_key, str sc_key, "
+                "float scale) -> (Tensor, Tensor)")
+_lib_def.define("node_stage_bwd(Tensor g_x1, Tensor g_sc, Tensor h, Tensor types, Tensor wp1, Tensor wps, str gate_key, "
+                "str lin_key, str sc_key, float scale) -> Tensor")
 
 _LINEAR: Dict[str, object] = {}
 _GATE: Dict[str, object] = {}
@@ -112,6 +118,40 @@ def _gate_bwd_bwd_cuda(x, g, c, key, need_x, need_g):
     return gx, gg
 
 
+def _stage_order(types, wps):
+    import os
+
+    from ._node_kernels import type_order
+
+    typed = wps.shape[0] > 1
+    return typed, (type_order(types) if (typed and os.environ.get("NQA_NODE_TYPE_ORDER", "") != "0") else None)
+
+
+def _node_stage_fwd_cuda(h, types, wp1, wps, gate_key, lin_key, sc_key, scale):
+    from ._node_kernels import FusedPart, launch_fused
+
+    gm, m1, ms = _gate_meta(gate_key), _linear_meta(lin_key), _linear_meta(sc_key)
+    h, types = h.contiguous(), types.contiguous()
+    typed, order = _stage_order(types, wps)
+    parts = [FusedPart(h, wp1.contiguous(), m1, scale, in_gate=gm), FusedPart(h, wps.contiguous(), ms, 1.0, in_gate=gm)]
+    x1, sc = launch_fused(parts, types if typed else None, order=order)
+    return x1, sc
+
+
+def _node_stage_bwd_cuda(g_x1, g_sc, h, types, wp1, wps, gate_key, lin_key, sc_key, scale):
+    from ._node_kernels import FusedPart, _scaled, _transposed, launch_fused, meta_transposed_weights
+
+    gm, m1, ms = _gate_meta(gate_key), _linear_meta(lin_key), _linear_meta(sc_key)
+    h, types = h.contiguous(), types.contiguous()
+    typed, order = _stage_order(types, wps)
+    parts = [FusedPart(g_x1.contiguous(), _scaled(meta_transposed_weights(m1, wp1.contiguous()), scale), _transposed(m1)),
+             FusedPart(g_sc.contiguous(), meta_transposed_weights(ms, wps.contiguous()), _transposed(ms), accumulate=True)]
+    (gh,) = launch_fused(parts, types if typed else None, out_gate=gm, gate_h=h, order=order)
+    return gh
+
+
+_lib_def.impl("node_stage_fwd", _node_stage_fwd_cuda, "CUDA")
+_lib_def.impl("node_stage_bwd", _node_stage_bwd_cuda, "CUDA")
 _lib_def.impl("node_linear", _node_linear_cuda, "CUDA")
 _lib_def.impl("gate", _gate_cuda, "CUDA")
 _lib_def.impl("gate_bwd", _gate_bwd_cuda, "CUDA")
@@ -145,7 +185,44 @@ def _gate_bwd_bwd_fake(x, g, c, key, need_x, need_g):
     return (torch.empty_like(x) if need_x else x.new_empty(0), torch.empty_like(g) if need_g else x.new_empty(0))
 
 
+@torch.library.register_fake(f"{_NS}::node_stage_fwd")
+def _node_stage_fwd_fake(h, types, wp1, wps, gate_key, lin_key, sc_key, scale):
+    din, dgated = gate_dims(gate_key)
+    l_in, l_out = linear_dims(lin_key)
+    s_in, s_out = linear_dims(sc_key)
+    torch._check(h.dim() == 2 and h.shape[1] == din, lambda: f"h must be [N, {din}] (pre-gate rows)")
+    torch._check(l_in == dgated and s_in == dgated, lambda: "linear_1 / self-connection do not take the gate's output")
+    return h.new_empty((h.shape[0], l_out)), h.new_empty((h.shape[0], s_out))
+
+
+@torch.library.register_fake(f"{_NS}::node_stage_bwd")
+def _node_stage_bwd_fake(g_x1, g_sc, h, types, wp1, wps, gate_key, lin_key, sc_key, scale):
+    return torch.empty_like(h)
+
+
 # ---- autograd --------------------------------------------------------------------------------------------------------
+def _ns_setup(ctx, inputs, output):
+    h, types, wp1, wps, gate_key, lin_key, sc_key, scale = inputs
+    ctx.save_for_backward(h, types, wp1, wps)
+    ctx.keys, ctx.scale = (gate_key, lin_key, sc_key), scale
+    ctx.dims = (output[0].shape[1], output[1].shape[1])
+
+
+def _ns_backward(ctx, g1, gs):
+    h, types, wp1, wps = ctx.saved_tensors
+    if not ctx.needs_input_grad[0]:
+        return (None,) * 8
+    if g1 is None:
+        g1 = h.new_zeros((h.shape[0], ctx.dims[0]))
+    if gs is None:
+        gs = h.new_zeros((h.shape[0], ctx.dims[1]))
+    gh = torch.ops.nequip_amd.node_stage_bwd(g1, gs, h, types, wp1, wps, *ctx.keys, ctx.scale)
+    return (gh,) + (None,) * 7
+
+
+torch.library.register_autograd(f"{_NS}::node_stage_fwd", _ns_backward, setup_context=_ns_setup)
+
+
 def _nl_setup(ctx, inputs, output):
     x, wp, addend, types, key, scale, transposed = inputs
     ctx.save_for_backward(wp, types)
@@ -201,3 +278,7 @@ def node_linear_op(x, wp, key: str, addend: Optional[torch.Tensor] = None, types
 
 def gate_op(x, key: str) -> torch.Tensor:
     return torch.ops.nequip_amd.gate(x, key)
+
+
+def node_stage(h, types, wp1, wps, gate_key: str, lin_key: str, sc_key: str, scale: float):
+    return torch.ops.nequip_amd.node_stage_fwd(h, types, wp1, wps, gate_key, lin_key, sc_key, float(scale))

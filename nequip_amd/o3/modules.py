@@ -73,12 +73,15 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
         if (traceable() and x.is_cuda and x.dtype == torch.float32 and self.weight_numel > 0
                 and not differentiable_parameters(self.training, self.weight)):
             # while tracing, constant weights: the fused kernel as a dispatcher op (o3/_node_ops.py)
-            wp = (self.weight.detach() * self._scale_vec).unsqueeze(0)
-            return _node_ops.node_linear_op(x, wp, self._op_key, addend=addend, scale=scale)
+            return _node_ops.node_linear_op(x, self.traced_weights(), self._op_key, addend=addend, scale=scale)
         out = self._forward_reference(x)
         if scale != 1.0:
             out = out * scale
         return out if addend is None else out + addend
+
+    def traced_weights(self) -> torch.Tensor:
+        """``eval_weights`` as graph operations on the (possibly fake) parameter, for the dispatcher-op forms."""
+        return (self.weight.detach() * self._scale_vec).unsqueeze(0)
 
     def eval_weights(self, device, dtype) -> torch.Tensor:
         """Packed, path-normalised weights ``[1, wstride]`` as constants (eval mode): built once per parameter version
@@ -206,6 +209,17 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             outs[io] = r if outs[io] is None else outs[io] + r
         return self._assemble(outs, x)
 
+    def traced_weights_typed(self, table: torch.Tensor) -> torch.Tensor:
+        """``eval_weights_typed`` as graph operations, for the dispatcher-op forms (per-instruction einsums on slices of the
+        flat weight: no cached index tensors -- a real constant tensor is not allowed next to fake weights while make_fx
+        traces symbolically)."""
+        tb = table.detach()
+        parts = []
+        for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
+            W = self.weight.detach()[sl].view(shape)
+            parts.append((torch.einsum("tv,uvw->tuw", tb[:, self._s2[i2]], W) * self._scale[io]).reshape(tb.shape[0], -1))
+        return torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+
     def eval_weights_typed(self, table: torch.Tensor, dtype) -> torch.Tensor:
         """Per-type pre-contracted weights ``W_t[u, w] = sum_v table[t, v] W[u, v, w]`` as constants, ``[T, wstride]``."""
         key = (id(self.weight), self.weight.data_ptr(), self.weight._version, table._version, table.data_ptr(),
@@ -235,15 +249,8 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
             return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)
         if (traceable() and x.is_cuda and x.dtype == torch.float32 and self._meta is not None
                 and not differentiable_parameters(self.training, self.weight)):
-            # (per-instruction einsums on slices of the flat weight: no cached index tensors -- a real constant tensor is
-            # not allowed next to fake weights while make_fx traces symbolically)
-            tb = table.detach()
-            parts = []
-            for (i1, i2, io), (sl, shape) in zip(self.instructions, self._wslices):
-                W = self.weight.detach()[sl].view(shape)
-                parts.append((torch.einsum("tv,uvw->tuw", tb[:, self._s2[i2]], W) * self._scale[io]).reshape(tb.shape[0], -1))
-            wp = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
-            return _node_ops.node_linear_op(x, wp, self._op_key, types=types.view(-1).contiguous())
+            return _node_ops.node_linear_op(x, self.traced_weights_typed(table), self._op_key,
+                                            types=types.view(-1).contiguous())
         Z = x.shape[0]
         T = table.shape[0]
         onehot = torch.nn.functional.one_hot(types.view(-1), T).to(x.dtype)  # [Z, T]

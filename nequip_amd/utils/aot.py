@@ -93,9 +93,10 @@ def _field_dims(field: str, batch_map) -> Optional[Dict[int, object]]:
 def aot_export_model(model: torch.nn.Module, data: AtomicDataDict.Type, output_path: str,
                      input_fields: Sequence[str] = tuple(ASE_INPUTS), output_fields: Sequence[str] = tuple(ASE_OUTPUTS),
                      batch_map: Optional[dict] = None, metadata: Optional[dict] = None,
-                     inductor_configs: Optional[dict] = None) -> str:
+                     inductor_configs: Optional[dict] = None, fold_constants: bool = True) -> str:
     """Trace, export and package ``model`` (eval mode, on the GPU) for the example ``data``; returns ``output_path``.
-    ``batch_map``: ``{"graph" | "node" | "edge": torch.export.Dim}`` (defaults: one frame, dynamic nodes / edges)."""
+    ``batch_map``: ``{"graph" | "node" | "edge": torch.export.Dim}`` (defaults: one frame, dynamic nodes / edges).
+    ``fold_constants``: evaluate the weight-only part of the graph now (``utils/tracing.py::fold_constants``)."""
     if not str(output_path).endswith(".nequip.pt2"):
         raise ValueError("AOTInductor packages are named `<name>.nequip.pt2` (nequip/scripts/compile.py:97-104)")
     model = model.eval()
@@ -103,7 +104,7 @@ def aot_export_model(model: torch.nn.Module, data: AtomicDataDict.Type, output_p
     device = inputs[AtomicDataDict.POSITIONS_KEY].device
     if device.type != "cuda":
         raise RuntimeError("aot_export_model: the kernels are GPU-only, the example data must live on the device")
-    gm, params, buffers = trace_model(model, inputs, tracing_mode="symbolic")
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="symbolic", fold=fold_constants)
     for nd in list(gm.graph.nodes):  # unused lifted constants trip torch.export's lift_constants_pass
         if nd.op == "get_attr" and len(nd.users) == 0:
             gm.graph.erase_node(nd)

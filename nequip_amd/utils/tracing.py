@@ -41,10 +41,10 @@ def traceable_forms(enabled: bool = True):
             _forced -= 1
 
 
-def trace_model(model: torch.nn.Module, example_inputs, tracing_mode: str = "symbolic"):
+def trace_model(model: torch.nn.Module, example_inputs, tracing_mode: str = "symbolic", fold: bool = False):
     """``make_fx`` graph of ``model(dict(inputs))`` with the weights as graph inputs, the way the reference's compile path
     does it (``nequip/nn/compile.py:150-191``).  Returns ``(graph_module, params, buffers)``; call the graph as
-    ``graph_module(params, buffers, inputs)`` -- it returns the model's output dict."""
+    ``graph_module(params, buffers, inputs)`` -- it returns the model's output dict.  ``fold``: see ``fold_constants``."""
     from torch.fx.experimental.proxy_tensor import make_fx
 
     params, buffers = dict(model.named_parameters()), dict(model.named_buffers())
@@ -54,4 +54,64 @@ def trace_model(model: torch.nn.Module, example_inputs, tracing_mode: str = "sym
 
     with traceable_forms():
         gm = make_fx(f, tracing_mode=tracing_mode)(params, buffers, example_inputs)
+    if fold:
+        fold_constants(gm, params, buffers)
     return gm, params, buffers
+
+
+def fold_constants(gm: torch.fx.GraphModule, params, buffers) -> int:
+    """Deployment-time freezing of a ``trace_model`` graph: every node that depends on the weights alone -- the path
+    normalisation folded into ``o3.Linear`` weights, the per-type contraction of the self-connection weights, the scaled
+    readout weight, dtype casts of the scale / shift tables: two dozen small kernels per evaluation otherwise -- is evaluated
+    ONCE, here, on the current parameter values, and enters the graph as a constant buffer (``_folded_<k>``).  The graph keeps
+    its signature (the weight inputs stay, mostly unused); it is then a snapshot of the weights it was folded with, which is
+    what an exported package is anyway.  Constant buffers are also what lets the dispatcher ops keep their packed /
+    transposed / split weight images across calls (``utils/constcache.py``).  Returns the number of buffers created."""
+    import torch.utils._pytree as pytree
+
+    leaves = pytree.tree_leaves((params, buffers))
+    placeholders = [n for n in gm.graph.nodes if n.op == "placeholder"]
+    assert len(placeholders) >= len(leaves), "not a trace_model graph (weights first)"
+    env = {n: v.detach() for n, v in zip(placeholders, leaves)}
+    const_inputs = set(env)
+
+    def known(a) -> bool:
+        ok = True
+
+        def visit(x):
+            nonlocal ok
+            if isinstance(x, torch.fx.Node) and x not in env:
+                ok = False
+            return x
+
+        torch.fx.node.map_arg(a, visit)
+        return ok
+
+    with torch.no_grad():
+        for n in gm.graph.nodes:
+            if n.op != "call_function" or not known(n.args) or not known(n.kwargs):
+                continue
+            if not any(isinstance(a, torch.fx.Node) for a in pytree.tree_leaves((n.args, n.kwargs))):
+                continue  # (factory calls: nothing to gain, and their sizes may be symbolic)
+            args = torch.fx.node.map_arg(n.args, lambda x: env[x])
+            kwargs = torch.fx.node.map_arg(n.kwargs, lambda x: env[x])
+            env[n] = n.target(*args, **kwargs)
+    first = next(n for n in gm.graph.nodes if n.op != "placeholder")
+    made = 0
+    for n, val in list(env.items()):
+        if n in const_inputs or not isinstance(val, torch.Tensor):
+            continue
+        outside = [u for u in n.users if u not in env]
+        if not outside:
+            continue
+        name = f"_folded_{made}"
+        made += 1
+        gm.register_buffer(name, val.contiguous().clone())
+        with gm.graph.inserting_before(first):
+            const = gm.graph.get_attr(name)
+        const.meta = dict(n.meta)
+        for u in outside:
+            u.replace_input_with(n, const)
+    gm.graph.eliminate_dead_code()
+    gm.recompile()
+    return made

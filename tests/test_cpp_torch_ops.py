@@ -22,7 +22,8 @@ LIB = os.path.join(ROOT, "nequip_amd", "csrc", "libnequip_amd_torch.so")
 RUNNER = os.path.join(ROOT, "nequip_amd", "csrc", "nequip_amd_aoti_run")
 
 OPS = ["tp_scatter_fwd", "tp_scatter_bwd", "edge_vectors", "edge_vectors_adj", "edge_embed_fwd", "edge_embed_bwd",
-       "radial_mlp_fwd", "radial_mlp_bwd", "node_linear", "gate", "gate_bwd"]
+       "radial_mlp_fwd", "radial_mlp_bwd", "node_linear", "gate", "gate_bwd", "radial_tp_fwd", "radial_tp_bwd",
+       "node_stage_fwd", "node_stage_bwd", "energy_head_fwd", "energy_head_bwd", "force_virial"]
 
 
 @pytest.fixture(scope="module")
@@ -250,10 +251,44 @@ def test_cpp_ops_reproduce_the_python_ops_bitwise(device, tmp_path, cpp):
         run("node_linear", x, torch.randn(1, ws), None, None, key, 1.0, False)
         run("node_linear", x, torch.randn(2, ws), torch.randn(N, Irreps(s_out).dim), t, key, 0.7, False)
         run("node_linear", torch.randn(N, Irreps(s_out).dim), torch.randn(2, ws), None, t, key, 0.7, True)
-    gk = gate_key(Irreps("64x0e"), [("silu", 1.679)], Irreps("128x0e"), [("silu", 1.679)], Irreps("64x1o+64x2e"))
+    gk = gate_key(Irreps("64x0e"), [("silu", 1.679)], Irreps("64x0e+64x0e"), [("silu", 1.679), ("silu", 1.679)],
+                  Irreps("64x1o+64x2e"))
     xg = torch.randn(N, 64 + 128 + 64 * 8)
     run("gate", xg, gk)
     run("gate_bwd", xg, torch.randn(N, 64 + 64 * 8), gk)
+    # the fused forms of an exported graph: radial MLP + tensor product (paired: the box's list is symmetric; unpaired: the
+    # same list with one edge dropped), layer boundary, readout, force / virial tail
+    f_in, f_out = "64x0e+64x1o+64x2e", "192x0e+64x1o+64x2e"
+    sh = Irreps.spherical_harmonics(2)
+    mid, instr = otp.build_instructions(f_in, str(sh), f_out)
+    mid_ir = Irreps(oir.to_str(mid))
+    key = plan_key(Irreps(f_in), sh, mid_ir, instr)
+    wn = sum(Irreps(f_in)[i[0]].mul for i in instr)
+    w1t = torch.randn(128, wn)
+    x, y, g = torch.randn(N, Irreps(f_in).dim), torch.randn(E, sh.dim), torch.randn(N, mid_ir.dim)
+    lengths = vec.cpu().norm(dim=1, keepdim=True).float()
+    emb_sym = torch.cat([torch.sin(lengths * k) for k in range(1, 9)], dim=1) * 0.5  # (a function of the edge length)
+    shift32 = data["edge_cell_shift"].float()
+    out, rows = run("radial_tp_fwd", emb_sym, x, y, w0, w1t, 0.35, 0.125, ei[0].cpu(), ei[1].cpu(), shift32, key)
+    assert rows.numel() == (E // 2) * wn
+    for need in ((True, True, True), (True, False, True), (False, True, False)):
+        run("radial_tp_bwd", g, emb_sym, x, y, rows.cpu(), w0, w1t, 0.35, 0.125, ei[0].cpu(), ei[1].cpu(), shift32, key, *need)
+    eo = ei[:, :-1].cpu().contiguous()  # an odd number of edges: no pairing
+    out_o, rows_o = run("radial_tp_fwd", emb_sym[:-1], x, y[:-1], w0, w1t, 0.35, 0.125, eo[0], eo[1], shift32[:-1], key)
+    run("radial_tp_bwd", g, emb_sym[:-1], x, y[:-1], rows_o.cpu(), w0, w1t, 0.35, 0.125, eo[0], eo[1], shift32[:-1], key,
+        True, True, True)
+    lk = linear_key(Irreps("64x0e+64x1o+64x2e"), Irreps("64x0e+64x1o+64x2e"), [(0, 0), (1, 1), (2, 2)])
+    sk = linear_key(Irreps("64x0e+64x1o+64x2e"), Irreps("192x0e+64x1o+64x2e"), [(0, 0), (1, 1), (2, 2)])
+    wp1, wps = torch.randn(1, 3 * 64 * 64) * 0.1, torch.randn(2, 64 * 192 + 2 * 64 * 64) * 0.1
+    x1, sc = run("node_stage_fwd", xg, t, wp1, wps, gk, lk, sk, 0.23)
+    run("node_stage_bwd", torch.randn_like(x1.cpu()), torch.randn_like(sc.cpu()), xg, t, wp1, wps, gk, lk, sk, 0.23)
+    hh, wr = torch.randn(N, 64), torch.randn(64)
+    scales, shifts = torch.tensor([1.5, 0.5], dtype=torch.float64), torch.tensor([-1.0, 2.0], dtype=torch.float64)
+    run("energy_head_fwd", hh, wr, scales, shifts, t, 1, 1.679)
+    run("energy_head_fwd", hh, wr, None, None, t, 1, 1.679)
+    run("energy_head_bwd", torch.randn(N, 1, dtype=torch.float64), hh, wr, scales, t, 1, 1.679)
+    run("force_virial", torch.randn(E, 3, dtype=torch.float64), vec.cpu(), ei.cpu(), None, celld, N, 1)
+    run("force_virial", torch.randn(E, 3, dtype=torch.float64), vec.cpu(), ei.cpu(), None, None, N, 1)
     path = tmp_path / "ops.pt"
     torch.save(rec, path)
     r = subprocess.run([sys.executable, "-c", _OP_REPLAY, LIB, str(path)], capture_output=True, text=True, timeout=900,

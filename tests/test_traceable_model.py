@@ -80,6 +80,96 @@ def test_whole_model_traces_symbolically_on_cpu():
     assert not isinstance(shift.shape[0], int), "the number of edges must be symbolic"
 
 
+def test_fold_constants_leaves_no_weight_only_computation_in_the_graph():
+    """`fold_constants` (deployment-time freezing, utils/tracing.py): afterwards no call node depends on weight inputs /
+    folded buffers alone, the graph got smaller, and the folded buffers are what the graph computed from the weights
+    (checked on one of them: the path-normalised o3.Linear weights)."""
+    from nequip_amd.utils.tracing import fold_constants, trace_model
+
+    model, inputs = _model_and_data(torch.device("cpu"))
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="symbolic")
+    before = sum(1 for n in gm.graph.nodes if n.op == "call_function")
+    n_weights = len(params) + len(buffers)
+    made = fold_constants(gm, params, buffers)
+    after = sum(1 for n in gm.graph.nodes if n.op == "call_function")
+    assert made > 0 and after < before, (made, before, after)
+    const = {n for i, n in enumerate(n for n in gm.graph.nodes if n.op == "placeholder") if i < n_weights}
+    const |= {n for n in gm.graph.nodes if n.op == "get_attr"}
+    for n in gm.graph.nodes:
+        if n.op == "call_function":
+            ins = n.all_input_nodes
+            assert not ins or any(i not in const for i in ins), f"{n.format_node()} depends on constants alone"
+    lin = [m for m in model.modules() if type(m).__name__ == "Linear" and getattr(m, "weight_numel", 0) > 0][0]
+    want = lin.weight.detach() * lin._scale_vec
+    folded = [b for name, b in gm.named_buffers() if name.startswith("_folded_") and b.numel() == want.numel()]
+    assert any(torch.equal(b.reshape(-1), want) for b in folded)
+
+
+def test_constant_cache_is_keyed_on_storage_identity_and_version():
+    """utils/constcache.py: views / new wrapper objects of one storage hit, a clone or an in-place write misses."""
+    from nequip_amd.utils import constcache
+
+    constcache.clear()
+    calls = []
+    w = torch.arange(12.0).view(3, 4)
+
+    def build():
+        calls.append(1)
+        return len(calls)
+
+    assert constcache.get(w, "t", build) == 1
+    assert constcache.get(w.view(3, 4), "t", build) == 1          # another tensor object over the same memory
+    assert constcache.get(w.detach(), "t", build) == 1
+    assert constcache.get(w, "other tag", build) == 2
+    assert constcache.get(w.clone(), "t", build) == 3             # same values, another storage
+    assert constcache.get(w[1:], "t", build) == 4                 # same storage, another data pointer / shape
+    w.add_(1.0)                                                   # PyTorch sees the write: version counter
+    assert constcache.get(w, "t", build) == 5
+    constcache.clear()
+    assert constcache.get(w, "t", build) == 6
+
+
+def test_energy_graph_of_the_benchmark_shape_on_fake_gpu_tensors():
+    """No GPU needed: fake CUDA tensors take the GPU branches of every module, so the FORWARD graph of a cfg-3-shaped model
+    (64 features, radial MLP 8-128-W) is checked here -- the edge side of every convolution is ONE op (`radial_tp_fwd`: the
+    pairing decision lives behind the dispatcher), every layer boundary ONE (`node_stage_fwd`: Gate + linear_1 +
+    self-connection), the readout ONE (`energy_head_fwd`), and no separate gate / radial-MLP / tensor-product op is left.
+    (The backward half needs the autograd engine, which needs the device: GPU test below.)"""
+    from collections import Counter
+
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from torch.fx.experimental.proxy_tensor import make_fx
+
+    pos, types, cell, names = syn.water_box(n_side=2, seed=5)
+    data = syn.make_data(pos, types, 4.0, cell)
+    model = NequIPGNNModel(seed=3, model_dtype="float32", r_max=4.0, type_names=names, num_layers=3, l_max=2, parity=False,
+                           num_features=64, radial_mlp_depth=1, radial_mlp_width=128, avg_num_neighbors=20.0,
+                           per_type_energy_scales=1.0, per_type_energy_shifts=0.0).eval()
+    energy = model.model.func  # (the energy model inside ForceStressOutput)
+    mode = FakeTensorMode()
+
+    def fake(t):
+        with mode:
+            return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device="cuda")
+
+    params = {k: fake(v) for k, v in energy.named_parameters()}
+    buffers = {k: fake(v) for k, v in energy.named_buffers()}
+    inputs = {k: fake(data[k]) for k in FIELDS}
+
+    def f(params, buffers, inputs):
+        return torch.func.functional_call(energy, (params, buffers), (dict(inputs),))["total_energy"]
+
+    with mode, traceable_forms():
+        gm = make_fx(f, tracing_mode="real")(params, buffers, inputs)
+    ours = Counter(str(n.target).split(".")[1] for n in gm.graph.nodes
+                   if n.op == "call_function" and str(n.target).startswith("nequip_amd."))
+    assert ours["radial_tp_fwd"] == 3 and ours["node_stage_fwd"] == 2 and ours["energy_head_fwd"] == 1, ours
+    assert not ({"gate", "radial_mlp_fwd", "tp_scatter_fwd"} & set(ours)), ours
+    out = [n for n in gm.graph.nodes if n.op == "output"][0].args[0]
+    out = out[0] if isinstance(out, (list, tuple)) else out
+    assert tuple(out.meta["val"].shape) == (1, 1) and out.meta["val"].dtype == torch.float64
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("parity,l_max", [(False, 2), (True, 1)])
 def test_traced_graph_reproduces_the_eager_model(device, parity, l_max):
@@ -173,6 +263,69 @@ def test_traced_benchmark_shaped_model_keeps_the_fused_kernels(device):
     appears as a dispatcher op in the graph, and the graph reproduces the eager model (energy, forces, virial)."""
     from nequip_amd.utils.tracing import trace_model
 
+    pos, types, cell, names = syn.water_box(n_side=3, seed=2)
+    data = syn.make_data(pos, types, 4.5, cell)
+    model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
+                           avg_num_neighbors=float(data["edge_index"].shape[1] / data["pos"].shape[0]),
+                           per_type_energy_scales=1.0, per_type_energy_shifts=0.0).to(device).eval()
+    data = AtomicDataDict.to_device(data, device)
+    inputs = {k: data[k] for k in FIELDS}
+    ref = model(dict(inputs))
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="real")
+    ours = {str(n.target) for n in gm.graph.nodes if n.op == "call_function" and str(n.target).startswith("nequip_amd.")}
+    for op in ("radial_tp_fwd", "radial_tp_bwd", "edge_embed_fwd", "edge_embed_bwd", "node_linear", "node_stage_fwd",
+               "node_stage_bwd", "energy_head_fwd", "energy_head_bwd", "edge_vectors", "force_virial"):
+        assert f"nequip_amd.{op}.default" in ours, (op, ours)
+    assert not any(f"nequip_amd.{op}.default" in ours for op in ("gate", "radial_mlp_fwd", "tp_scatter_fwd")), ours
+    out = gm(params, buffers, inputs)
+    for k in ("total_energy", "forces", "virial", "stress"):
+        torch.testing.assert_close(out[k], ref[k], rtol=1e-5, atol=3e-5 * max(1.0, float(ref[k].abs().max())))
+
+
+@pytest.mark.gpu
+def test_folded_graph_reproduces_the_eager_model_and_keeps_its_weight_images(device):
+    """`trace_model(fold=True)`: the weight-only part of the graph is evaluated once; what is left reproduces the eager model
+    on the box it was traced on and on another one (dynamic sizes), and the dispatcher ops find their packed / transposed /
+    split weight images again at the second call (utils/constcache.py: no new entries)."""
+    from nequip_amd.utils import constcache
+    from nequip_amd.utils.tracing import trace_model
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=2)
+    data = syn.make_data(pos, types, 4.5, cell)
+    model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
+                           parity=False, num_features=64, radial_mlp_depth=1, radial_mlp_width=128,
+                           avg_num_neighbors=float(data["edge_index"].shape[1] / data["pos"].shape[0]),
+                           per_type_energy_scales=1.0, per_type_energy_shifts=0.0).to(device).eval()
+    data = AtomicDataDict.to_device(data, device)
+    inputs = {k: data[k] for k in FIELDS}
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="symbolic", fold=True)
+    folded = [n for n, _ in gm.named_buffers() if n.startswith("_folded_")]
+    assert len(folded) >= 8, folded
+    aten_math = [str(n.target) for n in gm.graph.nodes if n.op == "call_function"
+                 and str(n.target) in ("aten.bmm.default", "aten.mm.default", "aten.embedding.default")]
+    assert aten_math == ["aten.embedding.default"], aten_math  # (the type embedding depends on the input, nothing else is left)
+    pos2, types2, cell2, _ = syn.water_box(n_side=4, seed=7)
+    d2 = AtomicDataDict.to_device(syn.make_data(pos2, types2, 4.5, cell2), device)
+    for k, inp in enumerate((inputs, {f: d2[f] for f in FIELDS}, inputs)):
+        ref = model(dict(inp))
+        if k == 1:
+            held = len(constcache._entries)
+        out = gm(params, buffers, inp)
+        for f in ("total_energy", "forces", "virial", "stress"):
+            torch.testing.assert_close(out[f], ref[f], rtol=1e-5, atol=3e-5 * max(1.0, float(ref[f].abs().max())))
+    assert len(constcache._entries) == held, "the ops rebuilt a weight image for a constant they had seen"
+
+
+@pytest.mark.gpu
+def test_traced_graph_with_the_round_3_op_set(device, monkeypatch):
+    """The separate-op forms stay selectable (and are what a graph that differentiates twice, or a deep radial MLP, gets):
+    per-edge radial MLP + tensor-product ops, gate ops, the reference's strain formulation of the virial."""
+    from nequip_amd.utils.tracing import trace_model
+
+    monkeypatch.setenv("NQA_NO_RADIAL_TP_OP", "1")
+    monkeypatch.setenv("NQA_TRACE_NO_NODE_FUSION", "1")
+    monkeypatch.setenv("NQA_TRACE_REFERENCE_TAIL", "1")
     pos, types, cell, names = syn.water_box(n_side=3, seed=2)
     data = syn.make_data(pos, types, 4.5, cell)
     model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.5, type_names=names, num_layers=3, l_max=2,
