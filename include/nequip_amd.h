@@ -477,6 +477,19 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
  *   for representative edges and 0 for the reverse ones (every row written).  width = 32-bit words per row. */
 int nqa_pair_gather(const void* rows_in, const int64_t* rep_edge, int64_t num_pairs, int32_t width, void* rows_out,
                     nqa_stream stream);
+/* nqa_pair_owner_lists: the pair lists of nqa_tp_scatter_bwd_pairs (below) from a pairing (weight_rows, rep_edge of
+ *   nqa_edge_pairs with *ok == 1) and the dst-CSR of the same edge list (nqa_csr_build: rowptr, edge_id, src_sorted).  Every
+ *   directed edge is the owner-side or the other-side edge of its pair -- owner of {i <- j, j <- i}: i when (i < j) xor
+ *   (i + j odd), a self-image pair through its representative edge -- so both lists of a node are subsequences of its CSR
+ *   row: two counting passes, two prefix sums, two fill passes, no sort, no synchronisation.  Slots keep the CSR order.
+ *   Outputs (int32, device): owner_rowptr [N + 1], pair_other / pair_row / pair_edge_in / pair_edge_out [P] by slot,
+ *   other_rowptr [N + 1], other_slot [P] (the slots grouped by their other node). */
+int64_t nqa_pair_owner_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+int nqa_pair_owner_lists(const int32_t* weight_rows, const int64_t* rep_edge, const int32_t* rowptr_dst,
+                         const int32_t* edge_id_dst, const int32_t* src_sorted, int64_t num_edges, int64_t num_nodes,
+                         void* workspace, int64_t workspace_bytes, int32_t* owner_rowptr, int32_t* pair_other,
+                         int32_t* pair_row, int32_t* pair_edge_in, int32_t* pair_edge_out, int32_t* other_rowptr,
+                         int32_t* other_slot, nqa_stream stream);
 int nqa_pair_expand(const void* pair_rows, const int32_t* weight_rows, int64_t num_edges, int64_t num_pairs,
                     int32_t width, void* edge_rows, nqa_stream stream);
 int nqa_tp_scatter_fwd_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,

@@ -103,6 +103,12 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
          c_void_p],
     ),
+    "nqa_pair_owner_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "nqa_pair_owner_lists": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "nqa_pair_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "nqa_pair_expand": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nqa_tp_scatter_fwd_paired": (

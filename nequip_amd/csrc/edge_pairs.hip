@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <cstdint>
 #include <string>
@@ -128,6 +129,91 @@ __global__ __launch_bounds__(256) void pair_expand_kernel(const uint32_t* __rest
   out[i] = r < P ? g[(int64_t)r * width + c] : 0u;
 }
 
+// ---- owner lists of the pair-centric backward, from the pairing and the dst-CSR (no sort) ----------------------------------
+// Every directed edge e (dst = n) is either the owner-side edge of its pair (`edge_in`: n owns the pair) or the other-side
+// edge (`edge_out`: n is the pair's other node).  Owner of {i <- j, j <- i}: i when (i < j) xor (i + j odd); a self-image pair
+// (i == j) is owned through its representative edge.  So both lists of a node are subsequences of its CSR row.
+__device__ __forceinline__ bool ep_is_in(int i, int j, int32_t row, int32_t P) {
+  return i != j ? ((i < j) != (((i + j) & 1) == 1)) : row < P;
+}
+
+__global__ __launch_bounds__(256) void pair_reverse_edge_kernel(const int32_t* __restrict__ rows, int64_t E, int32_t P,
+                                                                int32_t* __restrict__ rev_edge) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int32_t r = rows[e];
+  if (r >= P) rev_edge[r - P] = (int32_t)e;
+}
+
+__global__ __launch_bounds__(256) void pair_owner_count_kernel(const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ edge_id,
+                                                               const int32_t* __restrict__ src_sorted,
+                                                               const int32_t* __restrict__ rows, int64_t N, int32_t P,
+                                                               int32_t* __restrict__ cnt_own, int32_t* __restrict__ cnt_oth) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  int own = 0, oth = 0;
+  if (n < N) {
+    for (int32_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+      const bool in = ep_is_in((int)n, src_sorted[k], rows[edge_id[k]], P);
+      own += in ? 1 : 0;
+      oth += in ? 0 : 1;
+    }
+  }
+  cnt_own[n] = own;  // (entry N = 0: the exclusive scan over N + 1 entries ends in the total)
+  cnt_oth[n] = oth;
+}
+
+__global__ __launch_bounds__(256) void pair_owner_fill_kernel(const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ edge_id,
+                                                              const int32_t* __restrict__ src_sorted,
+                                                              const int32_t* __restrict__ rows,
+                                                              const int64_t* __restrict__ rep_edge,
+                                                              const int32_t* __restrict__ rev_edge, int64_t N, int32_t P,
+                                                              const int32_t* __restrict__ owner_rowptr,
+                                                              int32_t* __restrict__ pair_other, int32_t* __restrict__ pair_row,
+                                                              int32_t* __restrict__ edge_in, int32_t* __restrict__ edge_out,
+                                                              int32_t* __restrict__ slot_of_pair) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int32_t s = owner_rowptr[n];
+  for (int32_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+    const int32_t e = edge_id[k], j = src_sorted[k], r = rows[e];
+    if (!ep_is_in((int)n, j, r, P)) continue;
+    const int32_t p = r < P ? r : r - P;
+    pair_other[s] = j;
+    pair_row[s] = p;
+    edge_in[s] = e;
+    edge_out[s] = r < P ? rev_edge[p] : (int32_t)rep_edge[p];
+    slot_of_pair[p] = s;
+    ++s;
+  }
+}
+
+__global__ __launch_bounds__(256) void pair_other_fill_kernel(const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ edge_id,
+                                                              const int32_t* __restrict__ src_sorted,
+                                                              const int32_t* __restrict__ rows, int64_t N, int32_t P,
+                                                              const int32_t* __restrict__ other_rowptr,
+                                                              const int32_t* __restrict__ slot_of_pair,
+                                                              int32_t* __restrict__ other_slot) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int32_t t = other_rowptr[n];
+  for (int32_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
+    const int32_t r = rows[edge_id[k]];
+    if (ep_is_in((int)n, src_sorted[k], r, P)) continue;
+    other_slot[t++] = slot_of_pair[r < P ? r : r - P];
+  }
+}
+
+static size_t ep_scan_bytes(int64_t N) {
+  size_t bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(N + 1),
+                                rocprim::plus<int32_t>(), (hipStream_t)0);
+  return bytes;
+}
+
 static size_t ep_cub_bytes(int64_t E) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
@@ -202,6 +288,73 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_edge_pairs: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int64_t nqa_pair_owner_workspace_bytes(int64_t num_edges, int64_t num_nodes) {
+  if (num_edges < 0 || num_nodes < 0 || num_edges > 2147483647LL || num_nodes > 2147483646LL) return -1;
+  const int64_t P = num_edges / 2 > 0 ? num_edges / 2 : 1;
+  return 2 * ep_align256(P * 4) + 2 * ep_align256((num_nodes + 1) * 4) + ep_align256((int64_t)ep_scan_bytes(num_nodes));
+}
+
+int nqa_pair_owner_lists(const int32_t* weight_rows, const int64_t* rep_edge, const int32_t* rowptr_dst,
+                         const int32_t* edge_id_dst, const int32_t* src_sorted, int64_t num_edges, int64_t num_nodes,
+                         void* workspace, int64_t workspace_bytes, int32_t* owner_rowptr, int32_t* pair_other,
+                         int32_t* pair_row, int32_t* pair_edge_in, int32_t* pair_edge_out, int32_t* other_rowptr,
+                         int32_t* other_slot, nqa_stream stream) {
+  if (num_edges < 0 || num_nodes < 0 || (num_edges % 2) != 0 || !owner_rowptr || !other_rowptr ||
+      (num_edges > 0 && (!weight_rows || !rep_edge || !rowptr_dst || !edge_id_dst || !src_sorted || !pair_other || !pair_row ||
+                         !pair_edge_in || !pair_edge_out || !other_slot))) {
+    set_error("nqa_pair_owner_lists: invalid argument (a paired list has an even number of edges)");
+    return NQA_ERR_INVALID;
+  }
+  const int64_t need = nqa_pair_owner_workspace_bytes(num_edges, num_nodes);
+  if (need < 0) {
+    set_error("nqa_pair_owner_lists: sizes beyond the int32 index range");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (!workspace || workspace_bytes < need) {
+    set_error("nqa_pair_owner_lists: workspace missing or too small");
+    return NQA_ERR_WORKSPACE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t E = num_edges, N = num_nodes;
+  const int32_t P = (int32_t)(E / 2);
+  char* p = static_cast<char*>(workspace);
+  int32_t* rev_edge = reinterpret_cast<int32_t*>(p);
+  p += ep_align256((P > 0 ? P : 1) * 4LL);
+  int32_t* slot_of_pair = reinterpret_cast<int32_t*>(p);
+  p += ep_align256((P > 0 ? P : 1) * 4LL);
+  int32_t* cnt_own = reinterpret_cast<int32_t*>(p);
+  p += ep_align256((N + 1) * 4);
+  int32_t* cnt_oth = reinterpret_cast<int32_t*>(p);
+  p += ep_align256((N + 1) * 4);
+  size_t scan_bytes = ep_scan_bytes(N);
+  const unsigned gn = (unsigned)((N + 1 + 255) / 256);
+  if (E > 0)
+    hipLaunchKernelGGL(pair_reverse_edge_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, weight_rows, E, P,
+                       rev_edge);
+  hipLaunchKernelGGL(pair_owner_count_kernel, dim3(gn), dim3(256), 0, s, rowptr_dst, edge_id_dst, src_sorted, weight_rows, N,
+                     P, cnt_own, cnt_oth);
+  if (rocprim::exclusive_scan(p, scan_bytes, cnt_own, owner_rowptr, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(),
+                              s) != hipSuccess ||
+      rocprim::exclusive_scan(p, scan_bytes, cnt_oth, other_rowptr, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(),
+                              s) != hipSuccess) {
+    set_error("nqa_pair_owner_lists: prefix sum failed");
+    return NQA_ERR_LAUNCH;
+  }
+  if (N > 0 && E > 0) {
+    hipLaunchKernelGGL(pair_owner_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowptr_dst, edge_id_dst,
+                       src_sorted, weight_rows, rep_edge, rev_edge, N, P, owner_rowptr, pair_other, pair_row, pair_edge_in,
+                       pair_edge_out, slot_of_pair);
+    hipLaunchKernelGGL(pair_other_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowptr_dst, edge_id_dst,
+                       src_sorted, weight_rows, N, P, other_rowptr, slot_of_pair, other_slot);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_pair_owner_lists: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

@@ -467,30 +467,25 @@ const Tensor& slots_src(Topology& t, Pairing& p) {
   return p.slots_src;
 }
 
-// build_owner_csr (nequip_amd/nn/_topology.py): owner of the pair {i <- j, j <- i} is i when (i < j) xor (i + j odd), a self
-// image pair belongs to i; slots grouped by owner (within an owner by the other node) and, separately, by the other node.
+// nequip_amd/nn/_topology.py::owner_lists: the pair lists of the pair-centric backward from the pairing and the dst-CSR
+// (nqa_pair_owner_lists: no sort, no synchronisation)
 void owner_lists(Topology& t, Pairing& p) {
+  const Csr& c = by_dst(t);
   std::lock_guard<std::mutex> lock(t.build);
   if (p.has_owner) return;
-  const int64_t P = p.P, N = t.num_nodes;
-  const Tensor order = at::argsort(p.rows.to(at::kLong), /*stable=*/true, 0, false);
-  const Tensor ea = order.slice(0, 0, P), eb = order.slice(0, P, 2 * P);
-  const Tensor i = t.dst.index_select(0, ea), j = t.src.index_select(0, ea);
-  const Tensor own_i = i.eq(j).logical_or(i.lt(j).logical_xor((i + j).bitwise_and(1).eq(1)));
-  const Tensor owner = at::where(own_i, i, j), other = at::where(own_i, j, i);
-  const Tensor e_in = at::where(own_i, ea, eb), e_out = at::where(own_i, eb, ea);
-  const Tensor perm = at::argsort(owner * N + other, /*stable=*/true, 0, false);
-  const Tensor owner_s = owner.index_select(0, perm), other_s = other.index_select(0, perm);
-  const Tensor nodes = at::arange(N + 1, t.dst.options());
-  auto c32 = [](const Tensor& v) { return v.to(at::kInt).contiguous(); };
-  const Tensor perm2 = at::argsort(other_s, /*stable=*/true, 0, false);
-  p.owner[0] = c32(at::searchsorted(owner_s, nodes));
-  p.owner[1] = c32(other_s);
-  p.owner[2] = c32(perm);
-  p.owner[3] = c32(e_in.index_select(0, perm));
-  p.owner[4] = c32(e_out.index_select(0, perm));
-  p.owner[5] = c32(at::searchsorted(other_s.index_select(0, perm2), nodes));
-  p.owner[6] = c32(perm2);
+  const int64_t P = p.P, N = t.num_nodes, E = t.num_edges;
+  const auto o32 = t.dst.options().dtype(at::kInt);
+  p.owner[0] = at::empty({N + 1}, o32);
+  p.owner[5] = at::empty({N + 1}, o32);
+  for (int k : {1, 2, 3, 4, 6}) p.owner[k] = at::empty({std::max<int64_t>(P, 1)}, o32);
+  const int64_t ws_bytes = nqa_pair_owner_workspace_bytes(E, N);
+  TORCH_CHECK(ws_bytes >= 0, "nequip_amd: edge list exceeds the int32 index range supported by the kernels");
+  Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, t.dst.options().dtype(at::kByte));
+  auto w = [](Tensor& v) { return static_cast<int32_t*>(v.data_ptr()); };
+  NQA_CALL(nqa_pair_owner_lists(i32(p.rows), static_cast<const int64_t*>(p.rep.data_ptr()), i32(c.rowptr), i32(c.edge_id),
+                                i32(c.other), E, N, ws.data_ptr(), ws_bytes, w(p.owner[0]), w(p.owner[1]), w(p.owner[2]),
+                                w(p.owner[3]), w(p.owner[4]), w(p.owner[5]), w(p.owner[6]), stream_of(t.dst)),
+           "nqa_pair_owner_lists");
   p.has_owner = true;
 }
 
@@ -1335,8 +1330,10 @@ Tensor type_order(const Tensor& types) {
   return last;
 }
 
-void fill_part(nqa_node_part& p, const Tensor& x, const Tensor& packed, LinearMeta& M, int64_t n_types, void* out, double scale,
-               int32_t accumulate, GateBlocks* in_gate) {
+// (dim_out: the row length of `out` -- the map's output, or the gate's input rows when the launch ends in the gate's backward;
+// 0 for an operand set that accumulates into the first one's tile)
+void fill_part(nqa_node_part& p, const Tensor& x, const Tensor& packed, LinearMeta& M, int64_t n_types, void* out,
+               int64_t dim_out, double scale, int32_t accumulate, GateBlocks* in_gate) {
   std::memset(&p, 0, sizeof(p));
   p.x = x.data_ptr();
   p.packed = packed.data_ptr();
@@ -1345,10 +1342,10 @@ void fill_part(nqa_node_part& p, const Tensor& x, const Tensor& packed, LinearMe
   p.n_chunks = M.n_chunks;
   p.n_instr = M.n_instr;
   p.n_types = (int32_t)n_types;
-  p.dim_in = (int32_t)M.din;
+  p.dim_in = (int32_t)x.size(1);  // (the row length of x: with an input gate, the PRE-gate rows)
   p.out = out;
   p.addend = nullptr;
-  p.dim_out = (int32_t)M.dout;
+  p.dim_out = (int32_t)dim_out;
   p.accumulate = accumulate;
   p.scale = scale;
   p.in_gate = in_gate != nullptr ? in_gate->blocks.data() : nullptr;
@@ -1394,8 +1391,8 @@ std::tuple<Tensor, Tensor> node_stage_fwd(const Tensor& h_, const Tensor& types_
   Tensor x1 = at::empty({N, M1.dout}, o.h.options()), sc = at::empty({N, MS.dout}, o.h.options());
   const Tensor p1 = packed_weights(o.wp1, M1, "N|" + lin_key), ps = packed_weights(o.wps, MS, "N|" + sc_key);
   nqa_node_part parts[2];
-  fill_part(parts[0], o.h, p1, M1, 1, x1.data_ptr(), scale, 0, &G);
-  fill_part(parts[1], o.h, ps, MS, o.wps.size(0), sc.data_ptr(), 1.0, 0, &G);
+  fill_part(parts[0], o.h, p1, M1, 1, x1.data_ptr(), M1.dout, scale, 0, &G);
+  fill_part(parts[1], o.h, ps, MS, o.wps.size(0), sc.data_ptr(), MS.dout, 1.0, 0, &G);
   NQA_CALL(nqa_node_fused(parts, 2, o.typed ? static_cast<const int64_t*>(o.types.data_ptr()) : nullptr,
                           o.order.defined() ? i32(o.order) : nullptr, N, nullptr, 0, nullptr, 0, stream_of(o.h)),
            "nqa_node_fused");
@@ -1425,8 +1422,8 @@ Tensor node_stage_bwd(const Tensor& g_x1, const Tensor& g_sc, const Tensor& h_, 
   const Tensor p1 = packed_weights(w1t, T1, "T|" + lin_key), ps = packed_weights(wst, TS, "T|" + sc_key);
   Tensor gh = at::empty({N, G.din}, o.h.options());
   nqa_node_part parts[2];
-  fill_part(parts[0], g1, p1, T1, 1, gh.data_ptr(), 1.0, 0, nullptr);
-  fill_part(parts[1], gs, ps, TS, o.wps.size(0), nullptr, 1.0, 1, nullptr);
+  fill_part(parts[0], g1, p1, T1, 1, gh.data_ptr(), G.din, 1.0, 0, nullptr);
+  fill_part(parts[1], gs, ps, TS, o.wps.size(0), nullptr, 0, 1.0, 1, nullptr);
   NQA_CALL(nqa_node_fused(parts, 2, o.typed ? static_cast<const int64_t*>(o.types.data_ptr()) : nullptr,
                           o.order.defined() ? i32(o.order) : nullptr, N, G.blocks.data(), (int32_t)G.blocks.size(),
                           o.h.data_ptr(), (int32_t)G.din, stream_of(o.h)),

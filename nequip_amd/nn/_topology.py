@@ -126,6 +126,29 @@ class EdgeTopology:
         return self._by_src
 
 
+def owner_lists(topo: "EdgeTopology", pairing: "EdgePairing"):
+    """``nqa_pair_owner_lists``: the owner lists on the device, from the pairing and the dst-CSR.  Same content as
+    ``build_owner_csr`` below (the host-side statement of the rule, tested on the CPU) up to the order of the slots within a
+    node, which here is the CSR order."""
+    lib = _lib.load()
+    E, N, P = topo.num_edges, topo.num_nodes, pairing.num_pairs
+    dev = topo.device
+    rowptr, eid, nbr = topo.by_dst
+    i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)  # noqa: E731
+    owner_rowptr, other_rowptr = i32(N + 1), i32(N + 1)
+    pair_other, pair_row, e_in, e_out, other_slot = i32(P), i32(P), i32(P), i32(P), i32(P)
+    ws_bytes = lib.nqa_pair_owner_workspace_bytes(E, N)
+    if ws_bytes < 0:
+        raise RuntimeError("edge list exceeds the int32 index range supported by the kernels")
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nqa_pair_owner_lists(_ptr(pairing.rows), _ptr(pairing.rep_edge), _ptr(rowptr), _ptr(eid), _ptr(nbr), E, N,
+                                      _ptr(ws), ws_bytes, _ptr(owner_rowptr), _ptr(pair_other), _ptr(pair_row), _ptr(e_in),
+                                      _ptr(e_out), _ptr(other_rowptr), _ptr(other_slot), current_stream_ptr(dev))
+    _lib.check(rc, "nqa_pair_owner_lists")
+    return owner_rowptr, pair_other, pair_row, e_in, e_out, other_rowptr, other_slot
+
+
 def build_owner_csr(edge_dst: torch.Tensor, edge_src: torch.Tensor, rows: torch.Tensor, num_pairs: int, num_nodes: int):
     """Owner lists of the pair-centric backward from a paired edge list (``rows[e]`` = p for the representative edge of pair
     p, p + P for its reverse).  Pure index arithmetic (a few sorts, no synchronisation; runs on any device -- the host
@@ -186,10 +209,11 @@ class EdgePairing:
         ``(i < j) xor (i + j odd)`` picks i, which hands every node about half of its pairs -- and the pairs are grouped by
         owner (within an owner by the other node, for the locality of the gathered rows) and, separately, by the other node.
         Returns int32 device tensors ``(owner_rowptr, pair_other, pair_row, edge_in, edge_out, other_rowptr, other_slot)``.
-        Built once per neighbour list with a handful of ATen sorts (no synchronisation)."""
+        Built once per neighbour list from the dst-CSR (``nqa_pair_owner_lists``: counting passes and prefix sums, no sort,
+        no synchronisation; slots keep the CSR order)."""
         if self._owner_csr is None:
             topo = self._topo()
-            self._owner_csr = build_owner_csr(topo._dst, topo._src, self.rows, self.num_pairs, topo.num_nodes)
+            self._owner_csr = owner_lists(topo, self)
         return self._owner_csr
 
 

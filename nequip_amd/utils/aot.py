@@ -13,9 +13,14 @@ the ``nequip_custom_ops_libs.txt`` zip entry, ``nequip/utils/aoti_metadata.py:5-
 implementation through the C ABI), which is what the reference's ``import_custom_ops_libs`` does before
 ``aoti_load_package`` for its OpenEquivariance / cuEquivariance adapters.
 
-Scope: Python-hosted runtimes (ASE calculator, torch-sim, scripts) -- the ops are registered from Python, the same way
-the package is loaded by the reference's own Python loader.  A C++ host (LAMMPS ``pair_nequip``) would need the ops
-registered from a C++ library (``TORCH_LIBRARY``); that registration is not built.
+The weight-only part of the traced graph (path normalisation folded into ``o3.Linear`` weights, the per-type contraction of
+the self-connection weights, ...) is evaluated at export time (``utils/tracing.py::fold_constants``), so the package's
+constants are what the ops consume and their packed / transposed / split images are built once per loaded package
+(``utils/constcache.py``; the C++ registrations keep the same cache).
+
+Runtimes: Python hosts (ASE calculator, torch-sim, scripts) import ``nequip_amd``; hosts without an interpreter (a LAMMPS pair
+style, a C++ server) link ``libnequip_amd_torch.so`` (``csrc/torch_ops``, ``include/nequip_amd_torch.h``), which registers the
+same inference ops from C++ -- ``nequip_amd_aoti_run`` is such a host.
 """
 
 from __future__ import annotations

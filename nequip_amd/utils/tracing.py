@@ -5,11 +5,18 @@ The reference compiles a model by symbolic tracing (``make_fx`` over ``torch.com
 ``autograd.Function`` that calls a C library through raw pointers.  While :func:`traceable` is true every module of this
 package chooses a form a tracer can follow:
 
-* the tensor-product scatter and the edge embedding go through dispatcher ops (``torch.ops.nequip_amd.*``, with fake
-  kernels for shape propagation and autograd formulas that stay inside the op family),
-* the radial MLP, ``o3.Linear``, the self-connection, ``Gate``, the edge vectors and the force / virial tail use their ATen
-  formulations (the ones they keep for shapes outside the fused kernels),
-* nothing data dependent is decided on the host (no reverse-edge pairing, no side streams).
+* every fused kernel family goes through dispatcher ops (``torch.ops.nequip_amd.*``, with fake kernels for shape
+  propagation and autograd formulas that stay inside the op family).  An inference graph (eval mode, constant weights) is
+  made of the same launches as the eager evaluation: ``radial_tp_fwd / _bwd`` (radial MLP + tensor-product scatter of one
+  convolution; the reverse-edge pairing decision is taken INSIDE the op, at run time, from the topology cache),
+  ``node_stage_fwd / _bwd`` (Gate + linear_1 + self-connection of a layer boundary), ``node_linear``, ``energy_head_fwd /
+  _bwd``, ``edge_embed_*``, ``edge_vectors`` and ``force_virial`` (the eval-mode force / virial tail);
+* modules with differentiable parameters, graphs that differentiate the forces again, deep radial MLPs and irreps outside the
+  fused kernels take the separate, twice-differentiable ops (``radial_mlp_*``, ``tp_scatter_*``, ``gate*``,
+  ``edge_vectors_adj``) or their ATen formulations; ``NQA_NO_RADIAL_TP_OP=1``, ``NQA_TRACE_NO_NODE_FUSION=1`` and
+  ``NQA_TRACE_REFERENCE_TAIL=1`` select those forms for an inference graph too;
+* nothing data dependent is decided on the host OF THE GRAPH (no side streams; what depends on the edge list lives behind
+  the dispatcher).
 
 It is true while ``torch.compile`` is tracing and inside :func:`traceable_forms`.  Eager evaluation keeps the fused kernels.
 """

@@ -63,6 +63,51 @@ def test_pairing_is_a_reverse_edge_matching(device, system):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("system", ["water", "si_small_cell", "molecule", "shuffled"])
+def test_owner_lists_from_the_csr_match_the_host_statement_of_the_rule(device, system):
+    """`nqa_pair_owner_lists` (counting passes over the dst-CSR, no sort) against `build_owner_csr` (the rule written with ATen
+    sorts, itself tested on the CPU in test_host_logic.py): the same slots per owner and per other node -- as sets, the order
+    within a node is the CSR's here -- and every slot consistent with the edge list."""
+    from nequip_amd.nn._topology import build_owner_csr
+    from nequip_amd.utils import synthetic as syn
+
+    if system in ("water", "shuffled"):
+        pos, types, cell, names = syn.water_box(n_side=3, seed=1)
+        data = syn.make_data(pos, types, 4.5, cell)
+        if system == "shuffled":  # an edge list in no particular order (the CSR sort has work to do)
+            perm = torch.randperm(data["edge_index"].shape[1], generator=torch.Generator().manual_seed(0))
+            data["edge_index"] = data["edge_index"][:, perm].contiguous()
+            data["edge_cell_shift"] = data["edge_cell_shift"][perm].contiguous()
+    elif system == "si_small_cell":
+        pos, types, cell, names = syn.silicon_box(reps=1, seed=2)
+        data = syn.make_data(pos, types, 4.5, cell)
+    else:
+        pos, types, cell, names = syn.water_box(n_side=2, seed=3)
+        data = syn.make_data(pos, types, 4.5, None, pbc=False)
+    topo, pr = _pairing_of(data, device)
+    assert pr is not None
+    N, P = data["pos"].shape[0], pr.num_pairs
+    got = [t.cpu().long() for t in pr.owner_csr]
+    ref = [t.cpu().long() for t in build_owner_csr(topo._dst, topo._src, pr.rows, P, N)]
+    orow, oth, prow, ein, eout, trow, tslot = got
+    assert torch.equal(orow, ref[0]) and torch.equal(trow, ref[5])  # the same number of slots per node, both ways
+    dst, src = data["edge_index"][0], data["edge_index"][1]
+    rows = pr.rows.cpu().long()
+    assert sorted(prow.tolist()) == list(range(P)) and sorted(tslot.tolist()) == list(range(P))
+    owner = torch.repeat_interleave(torch.arange(N), orow[1:] - orow[:-1])
+    assert torch.equal(dst[ein], owner) and torch.equal(src[ein], oth[:P])     # edge_in: other -> owner
+    assert torch.equal(dst[eout], oth[:P]) and torch.equal(src[eout], owner)   # edge_out: owner -> other
+    assert torch.equal(rows[ein] % P, prow) and torch.equal(rows[eout] % P, prow) and not torch.equal(rows[ein], rows[eout])
+    other_of_slot = torch.repeat_interleave(torch.arange(N), trow[1:] - trow[:-1])
+    assert torch.equal(oth[:P][tslot], other_of_slot)
+    # as sets per owner: (pair, edge_in, edge_out) triples equal the reference's
+    def triples(lst):
+        o = torch.repeat_interleave(torch.arange(N), lst[0][1:] - lst[0][:-1])
+        return sorted(zip(o.tolist(), lst[2].tolist(), lst[3].tolist(), lst[4].tolist()))
+    assert triples(got) == triples(ref)
+
+
+@pytest.mark.gpu
 def test_unpairable_lists_are_rejected(device):
     from nequip_amd.nn._topology import EdgeTopology
 
