@@ -117,6 +117,43 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
         return f"{self.irreps_in} -> {self.irreps_out} | {self.weight_numel} weights"
 
 
+class _SkinnyMMFn(torch.autograd.Function):
+    """``a [T, V] @ b [V, K]`` with T, V small and K large (the per-type contraction of the self-connection weights: 5 x 64 x
+    20480).  The product itself is fine in a library GEMM; its gradient w.r.t. ``a`` is ``g [T, K] @ b^T [K, V]`` -- a T x V
+    output with a reduction of length K, which the library runs on ONE workgroup (57 us at K = 20480).  Here the reduction is
+    split over S batches of a batched GEMM and summed (8 us).  Plain differentiable ops: double backward works as is."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return torch.mm(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            T, K = g.shape
+            V = b.shape[0]
+            S = 1
+            while S < 64 and K % (2 * S) == 0 and K // (2 * S) >= 256:
+                S *= 2
+            if S > 1:
+                Kc = K // S
+                gs = g.reshape(T, S, Kc).transpose(0, 1)            # [S, T, Kc]
+                bs = b.reshape(V, S, Kc).permute(1, 2, 0)           # [S, Kc, V]
+                ga = torch.bmm(gs, bs).sum(0)
+            else:
+                ga = torch.mm(g, b.t())
+        if ctx.needs_input_grad[1]:
+            gb = torch.mm(a.t(), g)
+        return ga, gb
+
+
+def _skinny_mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _SkinnyMMFn.apply(a, b)
+
+
 class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
     """Self-connection ``sc(x, node_attrs)`` with scalar (``Nx0e``) second operand.
 
@@ -240,7 +277,7 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
                 # all instructions at once: gather the flat [u, v, w] blocks into one [v, sum(u*w)] matrix (fixed
                 # permutation, path scale folded in), then a single [T, v] x [v, sum(u*w)] product
                 perm, scale = self._contract_index(weight.device, weight.dtype)
-                return torch.mm(table, weight.index_select(0, perm).view(table.shape[1], -1) * scale)
+                return _skinny_mm(table, weight.index_select(0, perm).view(table.shape[1], -1) * scale)
 
             if differentiable_parameters(self.training, self.weight):
                 wp = contract(self.weight, table)

@@ -360,3 +360,25 @@ def test_mode_switches_and_volatile_weight_copies(monkeypatch):
         vt = meta_transposed_weights(meta, wg)
     assert vt.requires_grad is False and vt._nqa_volatile is True
     assert torch.equal(vt, wt)
+
+
+def test_skinny_product_gradients():
+    """`o3.modules._skinny_mm` (the per-type contraction of the self-connection weights in training): the split-K formulation
+    of the gradient w.r.t. the small operand is the gradient (first and second order), and equals torch.mm's at the real
+    size."""
+    from nequip_amd.o3.modules import _skinny_mm
+
+    g = torch.Generator().manual_seed(0)
+    for K in (1024, 1536, 100):
+        a = torch.randn(3, 4, dtype=torch.float64, generator=g, requires_grad=True)
+        b = torch.randn(4, K, dtype=torch.float64, generator=g, requires_grad=True)
+        assert torch.autograd.gradcheck(_skinny_mm, (a, b))
+        if K <= 200:
+            assert torch.autograd.gradgradcheck(_skinny_mm, (a, b))
+    a = torch.randn(5, 64, generator=g, requires_grad=True)
+    b = torch.randn(64, 20480, generator=g, requires_grad=True)
+    go = torch.randn(5, 20480, generator=g)
+    ref = torch.autograd.grad(torch.mm(a, b), (a, b), go)
+    got = torch.autograd.grad(_skinny_mm(a, b), (a, b), go)
+    assert float((ref[0] - got[0]).abs().max()) < 2e-6 * float(ref[0].abs().max())
+    assert torch.equal(ref[1], got[1])

@@ -318,6 +318,54 @@ def test_folded_graph_reproduces_the_eager_model_and_keeps_its_weight_images(dev
 
 
 @pytest.mark.gpu
+def test_traced_graph_on_two_frames_and_on_a_list_that_does_not_pair_up(device):
+    """The fused inference ops away from their comfortable case, against the eager model AND the CPU oracle:
+    (a) a batch of two periodic frames (per-frame cells; `force_virial` sums virials per frame),
+    (b) an edge list that does not pair up -- one directed edge removed, so `radial_tp_*` take the per-edge kernels inside the
+        same ops (the list is still what the model is asked to evaluate: the oracle gets the same list)."""
+    from nequip_amd.utils.tracing import trace_model
+    from oracle import model as omodel
+
+    cfg = dict(r_max=4.0, num_layers=2, l_max=2, parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=64,
+               num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=18.0, model_dtype="float32")
+    frames = []
+    for seed in (11, 12):
+        pos, types, cell, names = syn.water_box(n_side=2, seed=seed)
+        frames.append(syn.make_data(pos, types, 4.0, cell))
+    batch_cpu = AtomicDataDict.batched_from_list(frames)
+    model = NequIPGNNModel(seed=2, type_names=names, per_type_energy_scales=1.0, per_type_energy_shifts=0.0,
+                           **{k: v for k, v in cfg.items()}).to(device).eval()
+    weights = {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+    fields = FIELDS + ("batch", "num_atoms")
+    single = dict(frames[0])
+    keep = torch.ones(single["edge_index"].shape[1], dtype=torch.bool)
+    keep[5] = False
+    single["edge_index"] = single["edge_index"][:, keep].contiguous()
+    single["edge_cell_shift"] = single["edge_cell_shift"][keep].contiguous()
+    for label, cpu, keys in (("two frames", batch_cpu, fields), ("unpaired list", single, FIELDS)):
+        data = AtomicDataDict.to_device(cpu, device)
+        inputs = {k: data[k] for k in keys if k in data}
+        ref = model(dict(inputs))
+        gm, params, buffers = trace_model(model, inputs, tracing_mode="symbolic", fold=True)
+        ours = {str(n.target) for n in gm.graph.nodes if n.op == "call_function" and str(n.target).startswith("nequip_amd.")}
+        assert {"nequip_amd.radial_tp_fwd.default", "nequip_amd.radial_tp_bwd.default",
+                "nequip_amd.force_virial.default"} <= ours, (label, ours)
+        out = gm(params, buffers, inputs)
+        orc = omodel.energy_forces(cpu, cfg, weights, with_virial=True)
+        n = cpu["pos"].shape[0]
+        fs = max(1.0, float(orc["forces"].abs().max()))
+        for k in ("total_energy", "forces", "virial"):
+            torch.testing.assert_close(out[k], ref[k], rtol=1e-5, atol=3e-5 * max(1.0, float(ref[k].abs().max())),
+                                       msg=lambda m: f"{label}: {k} vs eager: {m}")
+        df = float((orc["forces"] - out["forces"].cpu()).abs().max())
+        assert df < 1e-4, f"{label}: forces differ from the oracle by {df:.3e} eV/A"
+        torch.testing.assert_close(out["total_energy"].cpu(), orc["total_energy"].view_as(out["total_energy"].cpu()),
+                                   atol=5e-5 * n, rtol=5e-5)
+        torch.testing.assert_close(out["virial"].cpu().view(-1, 3, 3), orc["virial"].view(-1, 3, 3), atol=5e-5 * n * fs,
+                                   rtol=5e-4)
+
+
+@pytest.mark.gpu
 def test_traced_graph_with_the_round_3_op_set(device, monkeypatch):
     """The separate-op forms stay selectable (and are what a graph that differentiates twice, or a deep radial MLP, gets):
     per-edge radial MLP + tensor-product ops, gate ops, the reference's strain formulation of the virial."""
