@@ -14,6 +14,9 @@ rm -f $O/r4_other_workloads.jsonl
 for w in si1k aspirin5 cu20k cu100k train256 water10k_S water10k_M water10k_L water10k_XL; do
   timeout 400 python bench.py --workload $w --no-cpu-baseline --no-pmc 2>/dev/null >> $O/r4_other_workloads.jsonl
 done
+timeout 600 python scripts/bench_deployed.py 2> $O/deployed.err | grep '^{' > $O/r4_deployed_forms.jsonl
+(echo "# scripts/bench_md.py, cfg-3 box, new neighbour list every step (eager launches)"; python scripts/bench_md.py 2>/dev/null | tail -1;
+ echo "# NQA_NO_PAIRED=1"; NQA_NO_PAIRED=1 python scripts/bench_md.py 2>/dev/null | tail -1) > $O/r4_md_like_step.log
 cp $R/gpurun_out/prof_r4/r4_* $O/ 2>/dev/null
 cp $R/gpurun_out/prof_r4/bench_trace.json $O/r4_bench_under_rocprof.json 2>/dev/null
 cp $R/gpurun_out/prof_r4/bench_trace_serial.json $O/r4_bench_under_rocprof_serial.json 2>/dev/null
