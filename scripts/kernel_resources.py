@@ -59,7 +59,7 @@ def kernels_of(obj_path):
 
 def waves_per_simd(vgpr):
     """gfx950: 512 VGPRs per SIMD lane, allocation granularity 8."""
-    return min(8, 512 // (((vgpr + 7) // 8) * 8))
+    return min(8, 512 // max(8, ((vgpr + 7) // 8) * 8))
 
 
 if __name__ == "__main__":
