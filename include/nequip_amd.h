@@ -460,8 +460,13 @@ int nqa_energy_head(int32_t backward, const void* h, const void* readout_weight,
  *   evaluates the MLP twice per pair.  nqa_edge_pairs finds the pairs of a list:
  *     weight_rows[e] = p (representative edge of pair p: dst < src, or a self image with a "positive" shift) or
  *                      p + P (its reverse), P = num_edges / 2;  rep_edge[p] = the representative edge;
+ *     partner_edge[e] = the reverse edge of e;
  *     *ok (device int32) = 1 iff every edge has exactly one reverse partner (else the arrays are not to be used).
- *   edge_cell_shift: [E, 3] float32 / float64 (shift_dtype) integer-valued, or NULL.
+ *   edge_cell_shift: [E, 3] float32 / float64 (shift_dtype) integer-valued, or NULL.  (rowptr_dst, edge_id_dst, src_sorted):
+ *   the dst-CSR of the same list (nqa_csr_build) -- the reverse of (i <- j, S) is looked up in row j, one thread per edge,
+ *   no sort; pairs are numbered in the edge order of their representative.
+ * nqa_csr_from_pairs: the by-SOURCE CSR of a paired list without sorting -- row j holds the partners of the edges of row j
+ *   of the dst-CSR: rowptr_src = rowptr_dst, edge_id_src[k] = partner_edge[edge_id_dst[k]], dst_sorted = src_sorted.
  * nqa_tp_scatter_{fwd,bwd_edge,bwd_x,bwd_fused}_paired: the tensor-product entry points above with
  *   w = [num_pairs, weight_numel] (one row per pair) and, for the edge backward, grad_w = [2 * num_pairs, weight_numel]
  *   (row weight_rows[e] receives edge e's gradient; the caller -- or nqa_radial_mlp_bwd's second stream -- adds the two
@@ -470,8 +475,11 @@ int nqa_energy_head(int32_t backward, const void* h, const void* readout_weight,
  * ------------------------------------------------------------------------------------------- */
 int64_t nqa_edge_pairs_workspace_bytes(int64_t num_edges);
 int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void* edge_cell_shift, int32_t shift_dtype,
-                   int64_t num_edges, int64_t num_nodes, void* workspace, int64_t workspace_bytes,
-                   int32_t* weight_rows, int64_t* rep_edge, int32_t* ok, nqa_stream stream);
+                   const int32_t* rowptr_dst, const int32_t* edge_id_dst, const int32_t* src_sorted, int64_t num_edges,
+                   int64_t num_nodes, void* workspace, int64_t workspace_bytes, int32_t* weight_rows, int64_t* rep_edge,
+                   int32_t* partner_edge, int32_t* ok, nqa_stream stream);
+int nqa_csr_from_pairs(const int32_t* edge_id_dst, const int32_t* partner_edge, int64_t num_edges, int32_t* edge_id_src,
+                       nqa_stream stream);
 /* nqa_pair_gather: rows_out[p, :] = rows_in[rep_edge[p], :] (the per-pair rows of a per-edge float32 array, e.g. the
  *   edge embedding fed to the radial MLP); nqa_pair_expand is its adjoint: edge_rows[e, :] = pair_rows[weight_rows[e], :]
  *   for representative edges and 0 for the reverse ones (every row written).  width = 32-bit words per row. */

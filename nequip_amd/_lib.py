@@ -100,9 +100,10 @@ SIGNATURES = {
     "nqa_edge_pairs_workspace_bytes": (c_int64, [c_int64]),
     "nqa_edge_pairs": (
         c_int32,
-        [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-         c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "nqa_csr_from_pairs": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "nqa_pair_owner_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "nqa_pair_owner_lists": (
         c_int32,

@@ -10,13 +10,14 @@
 //   weight_rows[e] = p      for the representative edge of pair p (dst < src, or dst == src with a "positive" shift)
 //                  = p + P  for its reverse               (P = E / 2 pairs)
 //   rep_edge[p]    = the representative edge
-// Method: canonical 64-bit key (min(i,j), max(i,j), shift of the canonical orientation) per edge, radix sort of
-// (key, edge id), then every even sorted position must hold exactly two edges with the same key and opposite
-// orientation.  Anything else (odd E, a missing reverse edge, duplicates, shifts outside [-8, 7], > 2^26 atoms) clears
-// the `ok` flag and the caller keeps the per-edge evaluation.
+// Method: the list grouped by destination (the dst-CSR every consumer needs anyway) already holds, in row j, every edge that
+// can be the reverse of an edge (i <- j, S): one thread per edge scans that row (~40 entries, contiguous) for the entries with
+// source i and shift -S.  Exactly one match for EVERY edge makes the matching an involution with opposite orientations;
+// representative edges are numbered in edge order by a prefix sum.  Anything else (odd E, a missing reverse edge, duplicates,
+// a self edge without a shift) clears the `ok` flag and the caller keeps the per-edge evaluation.  No sort: the by-source CSR
+// of a paired list is the by-destination CSR seen through the matching (nqa_csr_from_pairs).
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <cstdint>
@@ -28,82 +29,78 @@ namespace nqa {
 
 static int64_t ep_align256(int64_t v) { return (v + 255) / 256 * 256; }
 
-struct PairKey {
-  uint64_t key;
-  int rep;  // 1: this edge has the canonical orientation
-  int bad;
-};
-
 template <typename ST>
-__device__ __forceinline__ PairKey pair_key(const int64_t* __restrict__ dst, const int64_t* __restrict__ src,
-                                            const ST* __restrict__ shift, int64_t e, int64_t N) {
-  PairKey r;
-  const int64_t i = dst[e], j = src[e];
-  int sx = 0, sy = 0, sz = 0;
+__device__ __forceinline__ void ep_shift(const ST* __restrict__ shift, int64_t e, int& sx, int& sy, int& sz) {
+  sx = sy = sz = 0;
   if (shift != nullptr) {
     sx = (int)lrint((double)shift[3 * e + 0]);
     sy = (int)lrint((double)shift[3 * e + 1]);
     sz = (int)lrint((double)shift[3 * e + 2]);
   }
-  r.bad = (i < 0 || j < 0 || i >= N || j >= N || i >= (1 << 26) || j >= (1 << 26) || sx < -8 || sx > 7 || sy < -8 ||
-           sy > 7 || sz < -8 || sz > 7)
-              ? 1
-              : 0;
-  // canonical orientation: dst < src; self images by the sign of the first non-zero shift component
-  bool rep;
-  if (i != j) rep = i < j;
-  else rep = sx > 0 || (sx == 0 && (sy > 0 || (sy == 0 && sz > 0)));
-  if (i == j && sx == 0 && sy == 0 && sz == 0) r.bad = 1;  // a self edge without a shift has no partner
-  const int64_t lo = rep ? i : j, hi = rep ? j : i;
-  if (!rep) { sx = -sx; sy = -sy; sz = -sz; }
-  if (sx < -8 || sx > 7 || sy < -8 || sy > 7 || sz < -8 || sz > 7) r.bad = 1;
-  const uint64_t sc = (uint64_t)((sx + 8) & 15) << 8 | (uint64_t)((sy + 8) & 15) << 4 | (uint64_t)((sz + 8) & 15);
-  r.key = ((uint64_t)(lo & ((1 << 26) - 1)) << 38) | ((uint64_t)(hi & ((1 << 26) - 1)) << 12) | sc;
-  r.rep = rep ? 1 : 0;
-  return r;
 }
 
+// partner[e] = the one edge (src[e] <- dst[e], -S); is_rep[e] = canonical orientation (dst < src; self images: first
+// non-zero shift component positive)
 template <typename ST>
-__global__ __launch_bounds__(256) void edge_pairs_key_kernel(const int64_t* __restrict__ dst,
-                                                              const int64_t* __restrict__ src,
-                                                              const ST* __restrict__ shift, int64_t E, int64_t N,
-                                                              uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                                              int32_t* __restrict__ ok) {
+__global__ __launch_bounds__(256) void edge_partner_kernel(const int64_t* __restrict__ dst, const int64_t* __restrict__ src,
+                                                           const ST* __restrict__ shift,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ edge_id,
+                                                           const int32_t* __restrict__ src_sorted, int64_t E, int64_t N,
+                                                           int32_t* __restrict__ partner, int32_t* __restrict__ is_rep,
+                                                           int32_t* __restrict__ ok) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const PairKey k = pair_key(dst, src, shift, e, N);
-  if (k.bad) atomicAnd(ok, 0);
-  keys[e] = k.key;
-  vals[e] = (int32_t)e;
+  const int64_t i = dst[e], j = src[e];
+  int32_t found = (int32_t)e, rep = 0;
+  bool good = i >= 0 && j >= 0 && i < N && j < N;
+  if (good) {
+    int sx, sy, sz;
+    ep_shift(shift, e, sx, sy, sz);
+    if (i == j && sx == 0 && sy == 0 && sz == 0) good = false;  // a self edge without a shift has no partner
+    rep = (i != j) ? (i < j ? 1 : 0) : ((sx > 0 || (sx == 0 && (sy > 0 || (sy == 0 && sz > 0)))) ? 1 : 0);
+    int cnt = 0;
+    const int32_t want = (int32_t)i;
+    for (int32_t k = rowptr[j]; k < rowptr[j + 1]; ++k) {
+      if (src_sorted[k] != want) continue;
+      const int32_t e2 = edge_id[k];
+      if (e2 == (int32_t)e) continue;
+      int tx, ty, tz;
+      ep_shift(shift, (int64_t)e2, tx, ty, tz);
+      if (tx == -sx && ty == -sy && tz == -sz) {
+        found = e2;
+        ++cnt;
+      }
+    }
+    if (cnt != 1) good = false;
+  }
+  if (!good) atomicAnd(ok, 0);
+  partner[e] = found;
+  is_rep[e] = rep;
 }
 
-template <typename ST>
-__global__ __launch_bounds__(256) void edge_pairs_assign_kernel(const int64_t* __restrict__ dst,
-                                                                 const int64_t* __restrict__ src,
-                                                                 const ST* __restrict__ shift, int64_t E, int64_t N,
-                                                                 const uint64_t* __restrict__ keys_sorted,
-                                                                 const int32_t* __restrict__ vals_sorted,
-                                                                 int32_t* __restrict__ weight_rows,
-                                                                 int64_t* __restrict__ rep_edge,
-                                                                 int32_t* __restrict__ ok) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
-  const int64_t P = E / 2;
-  if (p >= P) return;
-  const uint64_t k0 = keys_sorted[2 * p], k1 = keys_sorted[2 * p + 1];
-  const int32_t e0 = vals_sorted[2 * p], e1 = vals_sorted[2 * p + 1];
-  bool good = k0 == k1;
-  if (2 * p + 2 < E && keys_sorted[2 * p + 2] == k0) good = false;  // more than two edges with this key
-  const int r0 = pair_key(dst, src, shift, (int64_t)e0, N).rep;
-  const int r1 = pair_key(dst, src, shift, (int64_t)e1, N).rep;
-  if (r0 == r1) good = false;  // duplicates instead of a reverse edge
-  if (!good) {
-    atomicAnd(ok, 0);
-    return;
+__global__ __launch_bounds__(256) void edge_pairs_number_kernel(const int32_t* __restrict__ partner,
+                                                                const int32_t* __restrict__ is_rep,
+                                                                const int32_t* __restrict__ pnum, int64_t E,
+                                                                int32_t* __restrict__ weight_rows,
+                                                                int64_t* __restrict__ rep_edge) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int32_t P = (int32_t)(E / 2);
+  if (is_rep[e]) {
+    const int32_t p = pnum[e];
+    weight_rows[e] = p;
+    if (p < P) rep_edge[p] = e;  // (p >= P only on a list that does not pair up: arrays not to be used)
+  } else {
+    weight_rows[e] = pnum[partner[e]] + P;
   }
-  const int32_t rep = r0 ? e0 : e1, other = r0 ? e1 : e0;
-  weight_rows[rep] = (int32_t)p;
-  weight_rows[other] = (int32_t)(p + P);
-  rep_edge[p] = (int64_t)rep;
+}
+
+__global__ __launch_bounds__(256) void csr_from_pairs_kernel(const int32_t* __restrict__ edge_id_dst,
+                                                             const int32_t* __restrict__ partner, int64_t E,
+                                                             int32_t* __restrict__ edge_id_src) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < E) edge_id_src[k] = partner[edge_id_dst[k]];
 }
 
 // out[p, :] = src[rep_edge[p], :]  (rows of `width` 32-bit words)
@@ -214,10 +211,10 @@ static size_t ep_scan_bytes(int64_t N) {
   return bytes;
 }
 
-static size_t ep_cub_bytes(int64_t E) {
+static size_t ep_scan_e_bytes(int64_t E) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                                  (int32_t*)nullptr, (unsigned int)E, 0u, 64u, (hipStream_t)0);
+  (void)rocprim::exclusive_scan(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)E,
+                                rocprim::plus<int32_t>(), (hipStream_t)0);
   return bytes;
 }
 
@@ -230,13 +227,16 @@ extern "C" {
 int64_t nqa_edge_pairs_workspace_bytes(int64_t num_edges) {
   if (num_edges < 0 || num_edges > 2147483647LL) return -1;
   const int64_t E = num_edges > 0 ? num_edges : 1;
-  return 2 * ep_align256(E * 8) + 2 * ep_align256(E * 4) + ep_align256((int64_t)ep_cub_bytes(E));
+  return 2 * ep_align256(E * 4) + ep_align256((int64_t)ep_scan_e_bytes(E));
 }
 
 int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void* edge_cell_shift, int32_t shift_dtype,
-                   int64_t num_edges, int64_t num_nodes, void* workspace, int64_t workspace_bytes,
-                   int32_t* weight_rows, int64_t* rep_edge, int32_t* ok, nqa_stream stream) {
-  if (num_edges < 0 || num_nodes < 0 || !ok || (num_edges > 0 && (!edge_dst || !edge_src || !weight_rows || !rep_edge)) ||
+                   const int32_t* rowptr_dst, const int32_t* edge_id_dst, const int32_t* src_sorted, int64_t num_edges,
+                   int64_t num_nodes, void* workspace, int64_t workspace_bytes, int32_t* weight_rows, int64_t* rep_edge,
+                   int32_t* partner_edge, int32_t* ok, nqa_stream stream) {
+  if (num_edges < 0 || num_nodes < 0 || !ok ||
+      (num_edges > 0 && (!edge_dst || !edge_src || !rowptr_dst || !edge_id_dst || !src_sorted || !weight_rows || !rep_edge ||
+                         !partner_edge)) ||
       (edge_cell_shift && shift_dtype != NQA_F32 && shift_dtype != NQA_F64)) {
     set_error("nqa_edge_pairs: invalid argument");
     return NQA_ERR_INVALID;
@@ -260,34 +260,47 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
   if (!init) return NQA_OK;
   const int64_t E = num_edges;
   char* p = static_cast<char*>(workspace);
-  uint64_t* keys = reinterpret_cast<uint64_t*>(p);
-  p += ep_align256(E * 8);
-  uint64_t* keys_sorted = reinterpret_cast<uint64_t*>(p);
-  p += ep_align256(E * 8);
-  int32_t* vals = reinterpret_cast<int32_t*>(p);
+  int32_t* is_rep = reinterpret_cast<int32_t*>(p);
   p += ep_align256(E * 4);
-  int32_t* vals_sorted = reinterpret_cast<int32_t*>(p);
+  int32_t* pnum = reinterpret_cast<int32_t*>(p);
   p += ep_align256(E * 4);
-  size_t cub_bytes = ep_cub_bytes(E);
-  const unsigned ge = (unsigned)((E + 255) / 256), gp = (unsigned)((E / 2 + 255) / 256);
-#define NQA_EP_RUN(ST)                                                                                          \
-  {                                                                                                            \
-    const ST* sh = static_cast<const ST*>(edge_cell_shift);                                                     \
-    hipLaunchKernelGGL(edge_pairs_key_kernel<ST>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src, sh, E,         \
-                       num_nodes, keys, vals, ok);                                                              \
-    if (rocprim::radix_sort_pairs(p, cub_bytes, keys, keys_sorted, vals, vals_sorted, (unsigned int)E, 0u, 64u,  \
-                                  s) != hipSuccess) {                                                           \
-      set_error("nqa_edge_pairs: radix sort failed");                                                           \
-      return NQA_ERR_LAUNCH;                                                                                    \
-    }                                                                                                          \
-    hipLaunchKernelGGL(edge_pairs_assign_kernel<ST>, dim3(gp), dim3(256), 0, s, edge_dst, edge_src, sh, E,      \
-                       num_nodes, keys_sorted, vals_sorted, weight_rows, rep_edge, ok);                         \
+  size_t scan_bytes = ep_scan_e_bytes(E);
+  const unsigned ge = (unsigned)((E + 255) / 256);
+  if (edge_cell_shift && shift_dtype == NQA_F32)
+    hipLaunchKernelGGL(edge_partner_kernel<float>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src,
+                       static_cast<const float*>(edge_cell_shift), rowptr_dst, edge_id_dst, src_sorted, E, num_nodes,
+                       partner_edge, is_rep, ok);
+  else
+    hipLaunchKernelGGL(edge_partner_kernel<double>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src,
+                       static_cast<const double*>(edge_cell_shift), rowptr_dst, edge_id_dst, src_sorted, E, num_nodes,
+                       partner_edge, is_rep, ok);
+  if (rocprim::exclusive_scan(p, scan_bytes, is_rep, pnum, (int32_t)0, (size_t)E, rocprim::plus<int32_t>(), s) !=
+      hipSuccess) {
+    set_error("nqa_edge_pairs: prefix sum failed");
+    return NQA_ERR_LAUNCH;
   }
-  if (edge_cell_shift && shift_dtype == NQA_F32) NQA_EP_RUN(float) else NQA_EP_RUN(double)
-#undef NQA_EP_RUN
+  hipLaunchKernelGGL(edge_pairs_number_kernel, dim3(ge), dim3(256), 0, s, partner_edge, is_rep, pnum, E, weight_rows,
+                     rep_edge);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_edge_pairs: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_csr_from_pairs(const int32_t* edge_id_dst, const int32_t* partner_edge, int64_t num_edges, int32_t* edge_id_src,
+                       nqa_stream stream) {
+  if (num_edges < 0 || (num_edges > 0 && (!edge_id_dst || !partner_edge || !edge_id_src))) {
+    set_error("nqa_csr_from_pairs: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  if (num_edges == 0) return NQA_OK;
+  hipLaunchKernelGGL(csr_from_pairs_kernel, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), edge_id_dst, partner_edge, num_edges, edge_id_src);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_csr_from_pairs: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

@@ -297,7 +297,7 @@ struct Csr {
 // p + P for its reverse), the representative edges, the rows in the slot order of the two CSRs, and the owner lists of the
 // pair-centric backward (build_owner_csr)
 struct Pairing {
-  Tensor rows, rep;
+  Tensor rows, rep, partner;
   int64_t P = 0;
   Tensor slots_dst, slots_src;
   Tensor owner[7];
@@ -408,7 +408,18 @@ const Csr& by_dst(Topology& t) {
 const Csr& by_src(Topology& t) {
   std::lock_guard<std::mutex> lock(t.build);
   if (!t.has_src) {
-    t.by_src = build_csr(t.src, t.dst, t.num_nodes, t.num_edges);
+    if (t.pairing && t.has_dst && t.num_edges > 0) {
+      // a paired list: row j of the by-source CSR holds the partners of the edges of row j of the dst-CSR (no sort)
+      t.by_src.rowptr = t.by_dst.rowptr;
+      t.by_src.other = t.by_dst.other;
+      t.by_src.edge_id = at::empty_like(t.by_dst.edge_id);
+      NQA_CALL(nqa_csr_from_pairs(static_cast<const int32_t*>(t.by_dst.edge_id.data_ptr()),
+                                  static_cast<const int32_t*>(t.pairing->partner.data_ptr()), t.num_edges,
+                                  static_cast<int32_t*>(t.by_src.edge_id.data_ptr()), stream_of(t.dst)),
+               "nqa_csr_from_pairs");
+    } else {
+      t.by_src = build_csr(t.src, t.dst, t.num_nodes, t.num_edges);
+    }
     t.has_src = true;
   }
   return t.by_src;
@@ -419,6 +430,7 @@ const int32_t* i32(const Tensor& t) { return static_cast<const int32_t*>(t.data_
 // EdgeTopology.pairing (nequip_amd/nn/_topology.py): nullptr when some edge has no unique reverse partner.  One host
 // synchronisation per topology entry to read the verdict.
 std::shared_ptr<Pairing> pairing_of(Topology& t, const OptTensor& shift) {
+  const Csr& cd = by_dst(t);  // (the reverse of (i <- j) is looked up in row j of the dst-CSR: no sort)
   std::lock_guard<std::mutex> lock(t.build);
   const void* sp = ptr(shift);
   if (t.pairing_done && t.pairing_shift == sp) return t.pairing;
@@ -438,14 +450,16 @@ std::shared_ptr<Pairing> pairing_of(Topology& t, const OptTensor& shift) {
   const auto o32 = t.dst.options().dtype(at::kInt);
   auto p = std::make_shared<Pairing>();
   p->rows = at::empty({E}, o32);
+  p->partner = at::empty({E}, o32);
   p->rep = at::empty({E / 2}, t.dst.options());
   Tensor ok = at::zeros({1}, o32);
   const int64_t ws_bytes = nqa_edge_pairs_workspace_bytes(E);
   TORCH_CHECK(ws_bytes >= 0, "nequip_amd: nqa_edge_pairs_workspace_bytes failed");
   Tensor ws = at::empty({std::max<int64_t>(ws_bytes, 1)}, t.dst.options().dtype(at::kByte));
   NQA_CALL(nqa_edge_pairs(static_cast<const int64_t*>(t.dst.data_ptr()), static_cast<const int64_t*>(t.src.data_ptr()),
-                          ptr(sh), sdt, E, t.num_nodes, ws.data_ptr(), ws_bytes, static_cast<int32_t*>(p->rows.data_ptr()),
-                          static_cast<int64_t*>(p->rep.data_ptr()), static_cast<int32_t*>(ok.data_ptr()), stream_of(t.dst)),
+                          ptr(sh), sdt, i32(cd.rowptr), i32(cd.edge_id), i32(cd.other), E, t.num_nodes, ws.data_ptr(), ws_bytes,
+                          static_cast<int32_t*>(p->rows.data_ptr()), static_cast<int64_t*>(p->rep.data_ptr()),
+                          static_cast<int32_t*>(p->partner.data_ptr()), static_cast<int32_t*>(ok.data_ptr()), stream_of(t.dst)),
            "nqa_edge_pairs");
   if (ok.item<int32_t>() != 1) return nullptr;
   p->P = E / 2;

@@ -99,17 +99,21 @@ class EdgeTopology:
                     sh = sh.to(torch.float64)
                 sh = sh.contiguous()
             rows = torch.empty(E, dtype=torch.int32, device=dev)
+            partner = torch.empty(E, dtype=torch.int32, device=dev)
             rep = torch.empty(E // 2, dtype=torch.int64, device=dev)
             ok = torch.zeros(1, dtype=torch.int32, device=dev)
             ws_bytes = lib.nqa_edge_pairs_workspace_bytes(E)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             sdt = _lib.NQA_F32 if (sh is not None and sh.dtype == torch.float32) else _lib.NQA_F64
+            rowptr, eid, nbr = self.by_dst  # (the reverse of (i <- j) is looked up in row j of the dst-CSR: no sort)
             with torch.cuda.device(dev):
-                rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, E, self.num_nodes, _ptr(ws),
-                                        ws_bytes, _ptr(rows), _ptr(rep), _ptr(ok), current_stream_ptr(dev))
+                rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, _ptr(rowptr), _ptr(eid), _ptr(nbr),
+                                        E, self.num_nodes, _ptr(ws), ws_bytes, _ptr(rows), _ptr(rep), _ptr(partner),
+                                        _ptr(ok), current_stream_ptr(dev))
             _lib.check(rc, "nqa_edge_pairs")
             if int(ok.item()) == 1:
                 result = EdgePairing(self, rows, rep)
+                result.partner = partner
         self._pairing = (key, result)
         return result
 
@@ -122,7 +126,18 @@ class EdgeTopology:
     @property
     def by_src(self):
         if self._by_src is None:
-            self._by_src = self._build(self._src, self._dst)
+            paired = getattr(self, "_pairing", None)
+            if paired is not None and paired[1] is not None and self._by_dst is not None and self.num_edges > 0:
+                # a paired list: row j of the by-source CSR holds the partners of the edges of row j of the dst-CSR
+                rowptr, eid, nbr = self._by_dst
+                eid_s = torch.empty_like(eid)
+                with torch.cuda.device(self.device):
+                    rc = _lib.load().nqa_csr_from_pairs(_ptr(eid), _ptr(paired[1].partner), self.num_edges, _ptr(eid_s),
+                                                        current_stream_ptr(self.device))
+                _lib.check(rc, "nqa_csr_from_pairs")
+                self._by_src = (rowptr, eid_s, nbr)
+            else:
+                self._by_src = self._build(self._src, self._dst)
         return self._by_src
 
 
@@ -184,6 +199,7 @@ class EdgePairing:
         self.rep_edge = rep_edge
         self.num_pairs = int(rep_edge.numel())
         self._topo = weakref.ref(topo)
+        self.partner: Optional[torch.Tensor] = None  # int32 [E]: the reverse edge of every edge
         self._slots_dst: Optional[torch.Tensor] = None
         self._slots_src: Optional[torch.Tensor] = None
         self._owner_csr = None
