@@ -13,7 +13,8 @@
 //               (>= 1, coarsened until the grid fits the workspace), so a bin is at least r_max thick unless the whole
 //               cell is thinner -- then ceil(r_max / thickness) bins/images are searched on either side.
 //   2. bin    : bin id per atom, stable radix sort of (bin, atom) (nqa_csr_build), atoms gathered in bin order.
-//   3. count  : one thread per atom walks the (2R+1)^3 neighbouring bins (with image bookkeeping), counts hits;
+//   3. count  : one wavefront per atom walks the (2R+1)^3 neighbouring bins (with image bookkeeping), 64 candidates at a
+//               time (ballot + population count), counts hits;
 //               exclusive scan -> rowptr.  The host reads rowptr[N] (the one unavoidable synchronisation: E is data
 //               dependent) and allocates the outputs.
 //   4. fill   : same walk, writes (i, j, S) at rowptr[i] + k.  Edges come out grouped by centre atom in ascending order
@@ -224,9 +225,12 @@ __global__ __launch_bounds__(256) void nl_gather_kernel(int64_t N, const int32_t
   }
 }
 
-// Shared walk of count and fill.  FILL == false: returns the number of neighbours of atom i.
+// Shared walk of count and fill, one WAVEFRONT per atom: the neighbouring bins are visited in a fixed order and the atoms of a
+// bin are tested 64 at a time, one per lane; a hit's position in the atom's edge row is the number of hits before it (ballot +
+// population count), i.e. exactly the order in which a single thread walking the same bins would emit them.
+// FILL == false: returns the number of neighbours of atom i (the same value in every lane).
 template <bool FILL>
-__device__ __forceinline__ int nl_walk(int64_t i, const NLHeader* __restrict__ h, const double* __restrict__ sfrac,
+__device__ __forceinline__ int nl_walk(int64_t i, int lane, const NLHeader* __restrict__ h, const double* __restrict__ sfrac,
                                        const int32_t* __restrict__ ioff, const int32_t* __restrict__ rowptr_bin,
                                        const int32_t* __restrict__ atom_sorted, const double* __restrict__ s_sorted,
                                        const int32_t* __restrict__ o_sorted, int64_t base, int64_t E,
@@ -266,19 +270,25 @@ __device__ __forceinline__ int nl_walk(int64_t i, const NLHeader* __restrict__ h
           continue;
         }
         const int64_t bin = ((int64_t)bx * h->nb[1] + by) * h->nb[2] + bz;
-        for (int k = rowptr_bin[bin]; k < rowptr_bin[bin + 1]; ++k) {
-          const double fx = s_sorted[3 * k] + nx - si[0];
-          const double fy = s_sorted[3 * k + 1] + ny - si[1];
-          const double fz = s_sorted[3 * k + 2] + nz - si[2];
-          const double rx = fx * c[0] + fy * c[3] + fz * c[6];
-          const double ry = fx * c[1] + fy * c[4] + fz * c[7];
-          const double rz = fx * c[2] + fy * c[5] + fz * c[8];
-          const double r2 = rx * rx + ry * ry + rz * rz;
-          if (!(r2 < h->rmax2)) continue;
-          const int j = atom_sorted[k];
-          if (j == i && nx == 0 && ny == 0 && nz == 0) continue;
-          if (FILL) {
-            const int64_t e = base + cnt;
+        const int k1 = rowptr_bin[bin + 1];
+        for (int kb = rowptr_bin[bin]; kb < k1; kb += 64) {
+          const int k = kb + lane;
+          bool hit = false;
+          int j = 0;
+          if (k < k1) {
+            const double fx = s_sorted[3 * k] + nx - si[0];
+            const double fy = s_sorted[3 * k + 1] + ny - si[1];
+            const double fz = s_sorted[3 * k + 2] + nz - si[2];
+            const double rx = fx * c[0] + fy * c[3] + fz * c[6];
+            const double ry = fx * c[1] + fy * c[4] + fz * c[7];
+            const double rz = fx * c[2] + fy * c[5] + fz * c[8];
+            const double r2 = rx * rx + ry * ry + rz * rz;
+            j = atom_sorted[k];
+            hit = (r2 < h->rmax2) && !(j == i && nx == 0 && ny == 0 && nz == 0);
+          }
+          const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
+          if (FILL && hit) {
+            const int64_t e = base + cnt + __popcll(m & ((1ull << lane) - 1ull));
             edge_index[e] = i;
             edge_index[E + e] = j;
             // pos_j - pos_i + S @ cell = (s_j + n - s_i) @ cell with pos = (s + o) @ cell  =>  S = n - o_j + o_i
@@ -286,7 +296,7 @@ __device__ __forceinline__ int nl_walk(int64_t i, const NLHeader* __restrict__ h
             shift[3 * e + 1] = (double)(ny - o_sorted[3 * k + 1] + oi[1]);
             shift[3 * e + 2] = (double)(nz - o_sorted[3 * k + 2] + oi[2]);
           }
-          ++cnt;
+          cnt += __popcll(m);
         }
       }
     }
@@ -294,15 +304,17 @@ __device__ __forceinline__ int nl_walk(int64_t i, const NLHeader* __restrict__ h
   return cnt;
 }
 
-__global__ __launch_bounds__(128) void nl_count_kernel(int64_t N, const NLHeader* __restrict__ h,
+__global__ __launch_bounds__(256) void nl_count_kernel(int64_t N, const NLHeader* __restrict__ h,
                                                        const double* __restrict__ sfrac, const int32_t* __restrict__ ioff,
                                                        const int32_t* __restrict__ rowptr_bin,
                                                        const int32_t* __restrict__ atom_sorted,
                                                        const double* __restrict__ s_sorted,
                                                        const int32_t* __restrict__ o_sorted, int32_t* __restrict__ counts) {
-  const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // one wavefront per atom
   if (i >= N) return;
-  counts[i] = nl_walk<false>(i, h, sfrac, ioff, rowptr_bin, atom_sorted, s_sorted, o_sorted, 0, 0, nullptr, nullptr);
+  const int lane = threadIdx.x & 63;
+  const int cnt = nl_walk<false>(i, lane, h, sfrac, ioff, rowptr_bin, atom_sorted, s_sorted, o_sorted, 0, 0, nullptr, nullptr);
+  if (lane == 0) counts[i] = cnt;
 }
 
 // exclusive scan of counts[0..N) into rowptr[0..N], one workgroup (N / 1024 sequential tiles)
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(1024) void nl_scan_kernel(int64_t N, const int32_t*
   }
 }
 
-__global__ __launch_bounds__(128) void nl_fill_kernel(int64_t N, int64_t E, const NLHeader* __restrict__ h,
+__global__ __launch_bounds__(256) void nl_fill_kernel(int64_t N, int64_t E, const NLHeader* __restrict__ h,
                                                       const double* __restrict__ sfrac, const int32_t* __restrict__ ioff,
                                                       const int32_t* __restrict__ rowptr_bin,
                                                       const int32_t* __restrict__ atom_sorted,
@@ -344,9 +356,10 @@ __global__ __launch_bounds__(128) void nl_fill_kernel(int64_t N, int64_t E, cons
                                                       const int32_t* __restrict__ o_sorted,
                                                       const int32_t* __restrict__ rowptr, int64_t* __restrict__ edge_index,
                                                       double* __restrict__ shift) {
-  const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // one wavefront per atom
   if (i >= N) return;
-  nl_walk<true>(i, h, sfrac, ioff, rowptr_bin, atom_sorted, s_sorted, o_sorted, rowptr[i], E, edge_index, shift);
+  nl_walk<true>(i, (int)(threadIdx.x & 63), h, sfrac, ioff, rowptr_bin, atom_sorted, s_sorted, o_sorted, rowptr[i], E,
+                edge_index, shift);
 }
 
 static int nl_status(const char* fn) {
@@ -402,7 +415,7 @@ int nqa_neighbor_list_count(const double* pos, const double* cell, const int32_t
                            nqa_csr_workspace_bytes(B, N), stream);
     if (rc != NQA_OK) return rc;
     hipLaunchKernelGGL(nl_gather_kernel, dim3(g256), dim3(256), 0, s, N, atom_sorted, sfrac, ioff, s_sorted, o_sorted);
-    hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, s, N, h, sfrac, ioff,
+    hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, N, h, sfrac, ioff,
                        rowptr_bin, atom_sorted, s_sorted, o_sorted, counts);
   }
   hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, s, N, counts, rowptr, (int32_t*)nullptr);
@@ -420,7 +433,7 @@ int nqa_neighbor_list_fill(const void* workspace, const int32_t* rowptr, int64_t
   const NLLayout L = nl_layout(num_atoms);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const char* w = static_cast<const char*>(workspace);
-  hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)((num_atoms + 127) / 128)), dim3(128), 0, s, num_atoms, num_edges,
+  hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)((num_atoms + 3) / 4)), dim3(256), 0, s, num_atoms, num_edges,
                      reinterpret_cast<const NLHeader*>(w + L.header), reinterpret_cast<const double*>(w + L.sfrac),
                      reinterpret_cast<const int32_t*>(w + L.ioff), reinterpret_cast<const int32_t*>(w + L.rowptr_bin),
                      reinterpret_cast<const int32_t*>(w + L.atom_sorted), reinterpret_cast<const double*>(w + L.s_sorted),
