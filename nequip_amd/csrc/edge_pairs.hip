@@ -142,23 +142,31 @@ __global__ __launch_bounds__(256) void pair_reverse_edge_kernel(const int32_t* _
   if (r >= P) rev_edge[r - P] = (int32_t)e;
 }
 
+// (one wavefront per node: a row is walked 64 entries at a time; a slot position is the number of qualifying entries before
+// it in the row -- ballot + population count --, i.e. the order a single thread walking the row would produce)
 __global__ __launch_bounds__(256) void pair_owner_count_kernel(const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ edge_id,
                                                                const int32_t* __restrict__ src_sorted,
                                                                const int32_t* __restrict__ rows, int64_t N, int32_t P,
                                                                int32_t* __restrict__ cnt_own, int32_t* __restrict__ cnt_oth) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (n > N) return;
+  const int lane = threadIdx.x & 63;
   int own = 0, oth = 0;
   if (n < N) {
-    for (int32_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
-      const bool in = ep_is_in((int)n, src_sorted[k], rows[edge_id[k]], P);
-      own += in ? 1 : 0;
-      oth += in ? 0 : 1;
+    const int32_t k1 = rowptr[n + 1];
+    for (int32_t kb = rowptr[n]; kb < k1; kb += 64) {
+      const int32_t k = kb + lane;
+      const bool valid = k < k1;
+      const bool in = valid && ep_is_in((int)n, src_sorted[k], rows[edge_id[k]], P);
+      own += __popcll(__builtin_amdgcn_ballot_w64(in));
+      oth += __popcll(__builtin_amdgcn_ballot_w64(valid && !in));
     }
   }
-  cnt_own[n] = own;  // (entry N = 0: the exclusive scan over N + 1 entries ends in the total)
-  cnt_oth[n] = oth;
+  if (lane == 0) {
+    cnt_own[n] = own;  // (entry N = 0: the exclusive scan over N + 1 entries ends in the total)
+    cnt_oth[n] = oth;
+  }
 }
 
 __global__ __launch_bounds__(256) void pair_owner_fill_kernel(const int32_t* __restrict__ rowptr,
@@ -171,19 +179,32 @@ __global__ __launch_bounds__(256) void pair_owner_fill_kernel(const int32_t* __r
                                                               int32_t* __restrict__ pair_other, int32_t* __restrict__ pair_row,
                                                               int32_t* __restrict__ edge_in, int32_t* __restrict__ edge_out,
                                                               int32_t* __restrict__ slot_of_pair) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (n >= N) return;
-  int32_t s = owner_rowptr[n];
-  for (int32_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
-    const int32_t e = edge_id[k], j = src_sorted[k], r = rows[e];
-    if (!ep_is_in((int)n, j, r, P)) continue;
-    const int32_t p = r < P ? r : r - P;
-    pair_other[s] = j;
-    pair_row[s] = p;
-    edge_in[s] = e;
-    edge_out[s] = r < P ? rev_edge[p] : (int32_t)rep_edge[p];
-    slot_of_pair[p] = s;
-    ++s;
+  const int lane = threadIdx.x & 63;
+  int32_t base = owner_rowptr[n];
+  const int32_t k1 = rowptr[n + 1];
+  for (int32_t kb = rowptr[n]; kb < k1; kb += 64) {
+    const int32_t k = kb + lane;
+    int32_t e = 0, j = 0, r = 0;
+    bool in = false;
+    if (k < k1) {
+      e = edge_id[k];
+      j = src_sorted[k];
+      r = rows[e];
+      in = ep_is_in((int)n, j, r, P);
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(in);
+    if (in) {
+      const int32_t s = base + __popcll(m & ((1ull << lane) - 1ull));
+      const int32_t p = r < P ? r : r - P;
+      pair_other[s] = j;
+      pair_row[s] = p;
+      edge_in[s] = e;
+      edge_out[s] = r < P ? rev_edge[p] : (int32_t)rep_edge[p];
+      slot_of_pair[p] = s;
+    }
+    base += __popcll(m);
   }
 }
 
@@ -194,13 +215,22 @@ __global__ __launch_bounds__(256) void pair_other_fill_kernel(const int32_t* __r
                                                               const int32_t* __restrict__ other_rowptr,
                                                               const int32_t* __restrict__ slot_of_pair,
                                                               int32_t* __restrict__ other_slot) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (n >= N) return;
-  int32_t t = other_rowptr[n];
-  for (int32_t k = rowptr[n]; k < rowptr[n + 1]; ++k) {
-    const int32_t r = rows[edge_id[k]];
-    if (ep_is_in((int)n, src_sorted[k], r, P)) continue;
-    other_slot[t++] = slot_of_pair[r < P ? r : r - P];
+  const int lane = threadIdx.x & 63;
+  int32_t base = other_rowptr[n];
+  const int32_t k1 = rowptr[n + 1];
+  for (int32_t kb = rowptr[n]; kb < k1; kb += 64) {
+    const int32_t k = kb + lane;
+    int32_t r = 0;
+    bool out = false;
+    if (k < k1) {
+      r = rows[edge_id[k]];
+      out = !ep_is_in((int)n, src_sorted[k], r, P);
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(out);
+    if (out) other_slot[base + __popcll(m & ((1ull << lane) - 1ull))] = slot_of_pair[r < P ? r : r - P];
+    base += __popcll(m);
   }
 }
 
@@ -345,7 +375,7 @@ int nqa_pair_owner_lists(const int32_t* weight_rows, const int64_t* rep_edge, co
   int32_t* cnt_oth = reinterpret_cast<int32_t*>(p);
   p += ep_align256((N + 1) * 4);
   size_t scan_bytes = ep_scan_bytes(N);
-  const unsigned gn = (unsigned)((N + 1 + 255) / 256);
+  const unsigned gn = (unsigned)((N + 1 + 3) / 4);  // one wavefront per node
   if (E > 0)
     hipLaunchKernelGGL(pair_reverse_edge_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, weight_rows, E, P,
                        rev_edge);
@@ -359,10 +389,10 @@ int nqa_pair_owner_lists(const int32_t* weight_rows, const int64_t* rep_edge, co
     return NQA_ERR_LAUNCH;
   }
   if (N > 0 && E > 0) {
-    hipLaunchKernelGGL(pair_owner_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowptr_dst, edge_id_dst,
+    hipLaunchKernelGGL(pair_owner_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, rowptr_dst, edge_id_dst,
                        src_sorted, weight_rows, rep_edge, rev_edge, N, P, owner_rowptr, pair_other, pair_row, pair_edge_in,
                        pair_edge_out, slot_of_pair);
-    hipLaunchKernelGGL(pair_other_fill_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rowptr_dst, edge_id_dst,
+    hipLaunchKernelGGL(pair_other_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, rowptr_dst, edge_id_dst,
                        src_sorted, weight_rows, N, P, other_rowptr, slot_of_pair, other_slot);
   }
   hipError_t err = hipGetLastError();
