@@ -94,6 +94,9 @@ int nqa_torch_linear_tables(const char* key, int transposed, int32_t* chunks, in
 int64_t nqa_torch_linear_transpose_perm(const char* key, int64_t* out, int64_t cap);
 /* gate column table (32-byte records; which = 0 forward, 1 backward); returns its size in bytes; dims = {dim_in, dim_out} */
 int64_t nqa_torch_gate_table(const char* key, int which, uint8_t* out, int64_t cap, int64_t* dims);
+/* the nqa_gate_block array (include/nequip_amd.h) that node_stage_fwd / _bwd derive from a gate key, as bytes; dims = {dim_in,
+ * dim_out} of the gate; returns the byte count, -1 for a key whose gates and gated irreps do not correspond one to one */
+int64_t nqa_torch_gate_blocks(const char* key, uint8_t* out, int64_t cap, int64_t* dims);
 /* out7 = {dim_in1, dim_in2, dim_out, weight_numel, out_needs_zero, prefer_fused_bwd, fused_rows_ok} of a plan text */
 int nqa_torch_plan_dims(const char* plan, int64_t* out7);
 

@@ -1606,6 +1606,19 @@ int64_t nqa_torch_gate_table(const char* key, int which, uint8_t* out, int64_t c
   }
 }
 
+// the nqa_gate_block array of a gate key (node_stage_*: GateMeta.blocks of the Python host), as bytes
+int64_t nqa_torch_gate_blocks(const char* key, uint8_t* out, int64_t cap, int64_t* dims /* din, dout */) {
+  try {
+    GateBlocks& g = gate_blocks(key);
+    if (dims) dims[0] = g.din, dims[1] = g.dout;
+    const int64_t n = (int64_t)(g.blocks.size() * sizeof(nqa_gate_block));
+    if (out && n <= cap && n > 0) std::memcpy(out, g.blocks.data(), (size_t)n);
+    return n;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
 // (dim_in1, dim_in2, dim_out, weight_numel, out_needs_zero, prefer_fused, fused_rows_ok) of a plan text
 int nqa_torch_plan_dims(const char* plan, int64_t* out7) {
   try {

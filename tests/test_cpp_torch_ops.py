@@ -39,6 +39,7 @@ def cpp():
     lib.nqa_torch_linear_tables.restype = ctypes.c_int
     lib.nqa_torch_linear_transpose_perm.restype = ctypes.c_int64
     lib.nqa_torch_gate_table.restype = ctypes.c_int64
+    lib.nqa_torch_gate_blocks.restype = ctypes.c_int64
     lib.nqa_torch_plan_dims.restype = ctypes.c_int
     return lib
 
@@ -48,7 +49,7 @@ def test_library_exports_what_its_header_declares(cpp):
 
     header = open(os.path.join(ROOT, "include", "nequip_amd_torch.h")).read()
     declared = set(re.findall(r"\b(nqa_torch_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 8, declared
+    assert len(declared) == 9, declared
     for name in declared:
         assert hasattr(cpp, name), name
     assert cpp.nqa_torch_ops_registered_here() == 1
@@ -121,6 +122,32 @@ def test_gate_tables_match_the_python_host(cpp):
             n = cpp.nqa_torch_gate_table(key.encode(), which, buf, len(buf), dims)
             assert n == len(ref) and bytes(buf)[:n] == ref, (key, which)
             assert list(dims) == [meta.din, meta.dout]
+
+
+def test_gate_blocks_of_the_fused_node_stage_match_the_python_host(cpp):
+    """`node_stage_*` in C++ derive the `nqa_gate_block` array of `nqa_node_fused` from the gate key: byte-identical to
+    `GateMeta.blocks_c()` of the Python host (cfg-3's gate, one with odd scalars / several activations, scalars only)."""
+    from nequip_amd.o3._node_ops import _gate_meta, gate_key
+    from nequip_amd.o3.irreps import Irreps
+
+    cases = [
+        ("64x0e", [("silu", 1.6790)], "64x0e+64x0e", [("silu", 1.6790), ("silu", 1.6790)], "64x1o+64x2e"),
+        ("16x0e+4x0o", [("silu", 1.679), ("tanh", 1.5925)], "8x0e+8x0e+4x0o", [("silu", 1.679), ("silu", 1.679), ("tanh", 1.59)],
+         "8x1o+8x2e+4x3o"),
+        ("32x0e", [("silu", 1.0)], "", [], ""),
+    ]
+    for s_s, a_s, s_g, a_g, s_d in cases:
+        key = gate_key(Irreps(s_s), a_s, Irreps(s_g), a_g, Irreps(s_d))
+        meta = _gate_meta(key)
+        arr, n = meta.blocks_c()
+        ref = bytes(arr)[: n * ctypes.sizeof(arr._type_)]
+        buf = (ctypes.c_uint8 * (len(ref) + 64))()
+        dims = (ctypes.c_int64 * 2)()
+        got = cpp.nqa_torch_gate_blocks(key.encode(), buf, len(buf), dims)
+        assert got == len(ref) and bytes(buf)[:got] == ref, key
+        assert list(dims) == [meta.din, meta.dout]
+    bad = gate_key(Irreps("64x0e"), [("silu", 1.0)], Irreps("128x0e"), [("silu", 1.0)], Irreps("64x1o+64x2e"))
+    assert cpp.nqa_torch_gate_blocks(bad.encode(), None, 0, None) == -1  # two gated irreps, one gate activation
 
 
 def test_plan_dimensions_match_the_python_host(cpp):
