@@ -77,41 +77,70 @@ class EdgeTopology:
             raise RuntimeError("edge index out of range [0, num_nodes)")
         return rowptr, eid, oth
 
+    @staticmethod
+    def _shift_key(shifts: Optional[torch.Tensor]):
+        return None if shifts is None else (shifts.data_ptr(), shifts._version, tuple(shifts.shape))
+
+    def start_pairing(self, shifts: Optional[torch.Tensor]) -> None:
+        """Launch the pairing kernels NOW and start copying their verdict to pinned host memory; ``pairing()`` then only
+        waits for that copy.  Called at the top of an evaluation (``GraphModel.forward``), so that the verdict's round trip to
+        the host overlaps with the launches of the embedding and the first node kernels instead of stalling the queue in front
+        of the first convolution (what a new neighbour list per step -- MD -- pays on every step).  No-op when the pairing of
+        this list is known, running, switched off or cannot be read (hipGraph capture)."""
+        key = self._shift_key(shifts)
+        cached = getattr(self, "_pairing", None)
+        pending = getattr(self, "_pairing_pending", None)
+        if (cached is not None and cached[0] == key) or (pending is not None and pending[0] == key):
+            return
+        E = self.num_edges
+        if (E == 0 or E % 2 != 0 or os.environ.get("NQA_NO_PAIRED", "") not in ("", "0")
+                or torch.cuda.is_current_stream_capturing()):
+            return
+        lib = _lib.load()
+        dev = self.device
+        sh = None
+        if shifts is not None:
+            sh = shifts.detach()
+            if sh.dtype not in (torch.float32, torch.float64):
+                sh = sh.to(torch.float64)
+            sh = sh.contiguous()
+        rows = torch.empty(E, dtype=torch.int32, device=dev)
+        partner = torch.empty(E, dtype=torch.int32, device=dev)
+        rep = torch.empty(E // 2, dtype=torch.int64, device=dev)
+        ok = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.nqa_edge_pairs_workspace_bytes(E)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        sdt = _lib.NQA_F32 if (sh is not None and sh.dtype == torch.float32) else _lib.NQA_F64
+        rowptr, eid, nbr = self.by_dst  # (the reverse of (i <- j) is looked up in row j of the dst-CSR: no sort)
+        with torch.cuda.device(dev):
+            rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, _ptr(rowptr), _ptr(eid), _ptr(nbr),
+                                    E, self.num_nodes, _ptr(ws), ws_bytes, _ptr(rows), _ptr(rep), _ptr(partner),
+                                    _ptr(ok), current_stream_ptr(dev))
+            _lib.check(rc, "nqa_edge_pairs")
+            verdict = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            verdict.copy_(ok, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        self._pairing_pending = (key, rows, rep, partner, verdict, done, ok)
+
     def pairing(self, shifts: Optional[torch.Tensor]):
         """Reverse-edge pairing of this list (``nqa_edge_pairs``): ``None`` when some edge has no unique reverse
         partner, else an ``EdgePairing`` with the weight rows in the slot order of both CSRs.  Computed once per
-        topology (one device synchronisation to read the verdict)."""
-        key = None if shifts is None else (shifts.data_ptr(), shifts._version, tuple(shifts.shape))
+        topology (one wait for the verdict -- a host synchronisation unless ``start_pairing`` ran early enough)."""
+        key = self._shift_key(shifts)
         cached = getattr(self, "_pairing", None)
         if cached is not None and cached[0] == key:
             return cached[1]
         if torch.cuda.is_current_stream_capturing():
             return None  # reading the verdict needs a synchronisation: not inside a hipGraph capture (not cached)
+        self.start_pairing(shifts)
         result = None
-        E = self.num_edges
-        if E > 0 and E % 2 == 0 and os.environ.get("NQA_NO_PAIRED", "") in ("", "0"):
-            lib = _lib.load()
-            dev = self.device
-            sh = None
-            if shifts is not None:
-                sh = shifts.detach()
-                if sh.dtype not in (torch.float32, torch.float64):
-                    sh = sh.to(torch.float64)
-                sh = sh.contiguous()
-            rows = torch.empty(E, dtype=torch.int32, device=dev)
-            partner = torch.empty(E, dtype=torch.int32, device=dev)
-            rep = torch.empty(E // 2, dtype=torch.int64, device=dev)
-            ok = torch.zeros(1, dtype=torch.int32, device=dev)
-            ws_bytes = lib.nqa_edge_pairs_workspace_bytes(E)
-            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-            sdt = _lib.NQA_F32 if (sh is not None and sh.dtype == torch.float32) else _lib.NQA_F64
-            rowptr, eid, nbr = self.by_dst  # (the reverse of (i <- j) is looked up in row j of the dst-CSR: no sort)
-            with torch.cuda.device(dev):
-                rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, _ptr(rowptr), _ptr(eid), _ptr(nbr),
-                                        E, self.num_nodes, _ptr(ws), ws_bytes, _ptr(rows), _ptr(rep), _ptr(partner),
-                                        _ptr(ok), current_stream_ptr(dev))
-            _lib.check(rc, "nqa_edge_pairs")
-            if int(ok.item()) == 1:
+        pending = getattr(self, "_pairing_pending", None)
+        if pending is not None and pending[0] == key:
+            _, rows, rep, partner, verdict, done, _ok = pending
+            self._pairing_pending = None
+            done.synchronize()
+            if int(verdict[0]) == 1:
                 result = EdgePairing(self, rows, rep)
                 result.partner = partner
         self._pairing = (key, result)

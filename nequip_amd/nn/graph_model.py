@@ -66,4 +66,18 @@ class GraphModel(GraphModuleMixin, torch.nn.Module):
         trust = (AtomicDataDict.LMP_MLIAP_DATA_KEY not in new_data
                  and os.environ.get("NQA_TOPOLOGY_CACHE", "1") not in ("0",))
         with topology_cache.scope(trust_identity=trust):
+            self._start_pairing(new_data)
             return self.model(new_data)
+
+    def _start_pairing(self, data) -> None:
+        """A new edge list (MD: every step): start its reverse-edge pairing before anything else is launched, so that the
+        verdict is on the host by the time the first convolution asks for it (``EdgeTopology.start_pairing``).  Only for the
+        evaluations that pair at all: float32 models differentiated w.r.t. positions."""
+        K = AtomicDataDict
+        ei, pos = data.get(K.EDGE_INDEX_KEY), data.get(K.POSITIONS_KEY)
+        if (ei is None or pos is None or not ei.is_cuda or K.EDGE_VECTORS_KEY in data or self.model_dtype != torch.float32
+                or os.environ.get("NQA_NO_EARLY_PAIRING", "") not in ("", "0")):
+            return
+        from ._topology import topology_cache
+
+        topology_cache.get(ei[0], ei[1], pos.shape[0]).start_pairing(data.get(K.EDGE_CELL_SHIFT_KEY))
