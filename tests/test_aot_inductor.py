@@ -38,6 +38,43 @@ def test_modifier_declares_aotinductor():
     assert "aotinductor" in list(modes)
 
 
+def test_folded_graph_exports_with_dynamic_sizes_on_cpu():
+    """The first half of `aot_export_model` without a GPU and without the compiler: trace (symbolic sizes) -> fold the
+    weight-only part -> wrap -> `torch.export` with dynamic atom / edge counts.  The folded constants travel as buffers of the
+    exported program, and the exported module's signature is the positional ASE input list."""
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import aot
+    from nequip_amd.utils import synthetic as syn
+    from nequip_amd.utils.tracing import trace_model
+
+    pos, types, cell, names = syn.water_box(n_side=2, seed=5)
+    data = syn.make_data(pos, types, 4.0, cell)
+    model = NequIPGNNModel(seed=3, model_dtype="float32", r_max=4.0, type_names=names, num_layers=2, l_max=1, parity=False,
+                           num_features=8, radial_mlp_depth=1, radial_mlp_width=16, avg_num_neighbors=20.0,
+                           per_type_energy_scales=1.0, per_type_energy_shifts=0.0).eval()
+    fields = aot.ASE_INPUTS
+    inputs = {k: data[k] for k in fields}
+    gm, params, buffers = trace_model(model, inputs, tracing_mode="symbolic", fold=True)
+    for nd in list(gm.graph.nodes):
+        if nd.op == "get_attr" and len(nd.users) == 0:
+            gm.graph.erase_node(nd)
+    gm.graph.eliminate_dead_code()
+    gm.recompile()
+    wrapped = aot._ListIO(gm, params, buffers, fields, ["total_energy", "forces", "virial"])
+    bm = {"graph": torch.export.Dim.STATIC, "node": torch.export.Dim("num_nodes", min=2, max=1 << 26),
+          "edge": torch.export.Dim("num_edges", min=2, max=1 << 30)}
+    ep = torch.export.export(wrapped, tuple(inputs[k] for k in fields),
+                             dynamic_shapes=(tuple(aot._field_dims(k, bm) for k in fields),), strict=False)
+    folded = [k for k in ep.state_dict if "_folded_" in k]
+    assert len(folded) >= 10, folded
+    placeholders = [n for n in ep.graph.nodes if n.op == "placeholder"]
+    user_inputs = [s for s in ep.graph_signature.user_inputs]
+    assert len(user_inputs) == len(fields) and len(placeholders) > len(fields)
+    # the edge count is a symbol of the exported graph, not the example's number
+    ei = [n for n in placeholders if n.name == user_inputs[fields.index("edge_index")]][0]
+    assert not isinstance(ei.meta["val"].shape[1], int)
+
+
 @pytest.mark.gpu
 def test_aotinductor_package_reproduces_eager_model(device, tmp_path):
     from nequip_amd.data import AtomicDataDict
