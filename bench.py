@@ -114,21 +114,25 @@ def build_model(cfg, names, device, seed=0):
     return model.to(device).eval()
 
 
-def cpu_baseline(workload_name: str, max_seconds: float = 40.0):
-    """Time the CPU oracle (reference op order, PyTorch CPU ops) on a bounded sample of the same workload, with the protocol
-    of SURVEY.md 8(d): 3 warm-up evaluations, then the median of 10 timed ones.  The sample is a smaller box of the
-    workload's density / r_max / model (one evaluation of the full 10 125-atom box costs the oracle about a minute).
-    Two thread settings are reported: ALL host cores (`all_cores_value`; the oracle is a chain of ATen ops on [E, ...]
-    tensors, which 256 threads oversubscribe) and the best of a few moderate settings (`value`, `cores`)."""
+def cpu_baseline(workload_name: str, max_seconds: float = 60.0, full_box: bool = True):
+    """Time the CPU oracle (reference op order, PyTorch CPU ops) beside the GPU number, protocol of SURVEY.md 8(d).
+
+    * `value` / `cores` (`sample_value`): a smaller box of the workload's density / r_max / model -- 3 warm-up evaluations,
+      then the median of up to 10 timed ones on the best of {8, 16, 32} threads; `all_cores_value`: the same with ALL host
+      cores (the oracle is a chain of ATen ops on [E, ...] tensors, which 256 threads oversubscribe).
+    * `full_box_value` (default workload only): the FULL 10 125-atom box of the metric, one warm evaluation + up to two
+      timed ones (about a minute each) -- when present this is `value`, the figure `gpu_over_cpu` uses; the small-box
+      figure stays next to it as `sample_value` (per-atom throughput on small boxes differs: fixed op overhead, threading)."""
     from oracle import model as omodel
 
     w = dict(WORKLOADS[workload_name])
+    w_full = dict(w)
     if w["box"] == "water":
-        w["n_side"] = min(w["n_side"], 5)  # 5^3 molecules = 375 atoms: ~1 s per evaluation, 13 evaluations in budget
+        w["n_side"] = min(w["n_side"], 7)  # 7^3 molecules = 1029 atoms (rounds 1-3; round 4 used 375)
     elif w["box"] == "si":
-        w["reps"] = min(w["reps"], 4)  # 512 atoms
+        w["reps"] = min(w["reps"], 5)  # 1000 atoms
     elif w["box"] == "cu":
-        w["reps"] = (3, 3, 3)  # 108 atoms (l_max = 3, 128 features)
+        w["reps"] = (4, 4, 4)  # 256 atoms (l_max = 3, 128 features)
     # (aspirin5 is small enough to be timed whole)
     data, names = build_box(w, seed=1)
     n_atoms = data["pos"].shape[0]
@@ -140,9 +144,9 @@ def cpu_baseline(workload_name: str, max_seconds: float = 40.0):
     ncpu = os.cpu_count() or 1
     t_start = time.perf_counter()
 
-    def one():
+    def one(d=data, c=cfg):
         t0 = time.perf_counter()
-        omodel.energy_forces(data, cfg, weights, specs)
+        omodel.energy_forces(d, c, weights, specs)
         return time.perf_counter() - t0
 
     torch.set_num_threads(min(ncpu, 32))
@@ -167,12 +171,13 @@ def cpu_baseline(workload_name: str, max_seconds: float = 40.0):
         ta = sorted(one() for _ in range(3))
         all_cores = n_atoms / ta[1]
     torch.set_num_threads(cores)
-    return {
+    res = {
         "value": n_atoms / med,
         "unit": "atom-steps/s",
         "cores": cores,
         "kind": "port",
         "host_cores": ncpu,
+        "sample_value": n_atoms / med,
         "all_cores_value": all_cores,
         "sample": f"{n_atoms}-atom {w['box']} box ({n_edges} edges), same density/r_max/model as the workload; 3 warm-up + "
         f"median of {len(times)} energy+forces evaluations ({med:.2f} s each) of the torch-CPU oracle on {cores} threads "
@@ -180,6 +185,27 @@ def cpu_baseline(workload_name: str, max_seconds: float = 40.0):
         + (f"{all_cores:.0f} atom-steps/s (median of 3)" if all_cores is not None else "same setting")
         + " (e3nn unavailable: restatement)",
     }
+    if full_box and workload_name == "water10k" and os.environ.get("NQA_BENCH_CPU_FULL_BOX", "1") not in ("", "0"):
+        # the box the metric names, whole: the same seed-0 box the GPU timed.  Activation checkpointing per layer keeps the
+        # [E, 2240]-sized autograd intermediates of the oracle within the host's memory (oracle/model.py).
+        fdata, fnames = build_box(w_full, seed=0)
+        fa, fe = fdata["pos"].shape[0], fdata["edge_index"].shape[1]
+        # (the weights do not depend on avg_num_neighbors: same model.  Edge ranges of 16384 under activation
+        # checkpointing, as tests/test_baseline_size_parity.py: the reference formulation's [E, mul, d1, d2] temporaries of
+        # this box would need > 100 GB of host memory otherwise; same arithmetic per edge, one recomputation in backward)
+        fcfg = dict(model_cfg(w_full, fe / fa), oracle_edge_chunk=16384)
+        tf = [one(fdata, fcfg)]  # first evaluation at this size = warm-up (allocator growth), reported too
+        budget = float(os.environ.get("NQA_BENCH_CPU_FULL_BOX_SECONDS", "200"))
+        while len(tf) < 3 and sum(tf) + 1.2 * tf[-1] < budget:
+            tf.append(one(fdata, fcfg))
+        best = min(tf[1:]) if len(tf) > 1 else tf[0]
+        res["full_box_value"] = fa / best
+        res["full_box_seconds"] = [round(t, 2) for t in tf]
+        res["value"] = res["full_box_value"]
+        res["sample"] = (f"FULL {fa}-atom box ({fe} edges) of the metric: {len(tf)} evaluation(s) of the torch-CPU oracle (edge ranges of 16384, "
+                         f"activation checkpointing) on {cores} threads, {', '.join(f'{t:.1f}' for t in tf)} s (first = warm-up; value = atoms / best "
+                         "later one); sample_value: " + res["sample"])
+    return res
 
 
 def _free_port() -> int:
@@ -249,11 +275,18 @@ def kernel_roofline(kname, ks, kernel_steps):
             r.update(achieved=ks["tflops"], peak=MFMA_F32_PEAK_TFLOPS, frac=ks["tflops"] / MFMA_F32_PEAK_TFLOPS,
                      pipe="fp32 MFMA (v_mfma_f32_32x32x2_f32)")
         return r
-    return {
+    r = {
         "bound": "hbm", "kernel": kname, "achieved": ks["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": ks["gbps"] / HBM_PEAK_GBPS, "avg_launch_ms": ks["avg_ms"],
         "algorithmic_bytes_per_launch": ks["bytes_per_call"], "launches_per_step": launches,
     }
+    if ks.get("fused_bytes_per_call") and ks["avg_ms"] > 0:
+        # "boundary-algorithmic" (frac, above: edge_weight rows counted) and "fused-algorithmic" (the weight
+        # rows counted as [E, H] hidden rows -- what a kernel with the MLP's last layer fused in would stream) side by side
+        fb = ks["fused_bytes_per_call"]
+        r["fused_algorithmic_bytes_per_launch"] = fb
+        r["frac_fused_algorithmic"] = fb / 1e9 / (ks["avg_ms"] / 1e3) / HBM_PEAK_GBPS
+    return r
 
 
 def add_traffic(r, pmc):
@@ -324,7 +357,7 @@ def static_traffic():
         return {}, "unavailable"
 
 
-def roofline_objects(kernels, kernel_steps, ms_per_step, workload, live_pmc):
+def roofline_objects(kernels, kernel_steps, ms_per_step, workload, live_pmc, boundary=None):
     """`roofline` (dominant hand-written kernel + the other hot ones) and `step_roofline` (whole step: the
     TensorProductScatter boundary bytes of SURVEY.md 8(d), forward + backward of every layer, against the HBM peak)."""
     if not kernels:
@@ -346,16 +379,144 @@ def roofline_objects(kernels, kernel_steps, ms_per_step, workload, live_pmc):
             others[kname] = add_traffic(kernel_roofline(kname, ks, kernel_steps), pmc)
     roofline["other_kernels"] = others
     tp_bytes = sum(v["bytes_per_call"] * v["calls"] for k, v in kernels.items() if k in TP_REGIONS) / max(kernel_steps, 1)
+    bnd, fus = (boundary if boundary is not None else (tp_bytes, None))
+    sec = ms_per_step / 1e3
     step = {
         "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-        "algorithmic_bytes_per_step": tp_bytes,
-        "definition": "SURVEY.md 8(d): operands and results of the gather -> tensor product -> scatter boundary of "
-                      "every layer, forward + backward, each counted once (edge_weight / grad_weight rows included)",
-        "achieved": tp_bytes / 1e9 / (ms_per_step / 1e3),
-        "frac": tp_bytes / 1e9 / (ms_per_step / 1e3) / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_step": bnd,
+        "definition": "SURVEY.md 8(d) boundary-algorithmic: sum over layers of E (12 W + 12 S + 32) + 4 N (3 D_in + 2 D_mid) "
+                      "-- operands and results of the gather -> tensor product -> scatter boundary, forward + backward, "
+                      "each counted once (edge_weight / grad_weight rows included)",
+        "achieved": bnd / 1e9 / sec,
+        "frac": bnd / 1e9 / sec / HBM_PEAK_GBPS,
+        "kernel_region_bytes_per_step": tp_bytes,
         "kernel_ms_per_step_sum": sum(v["total_ms"] for v in kernels.values()) / max(kernel_steps, 1),
     }
+    if fus is not None:
+        step["fused_algorithmic"] = {
+            "bytes_per_step": fus, "achieved": fus / 1e9 / sec, "frac": fus / 1e9 / sec / HBM_PEAK_GBPS,
+            "definition": "the same with W -> H (hidden width of the radial MLP): what a kernel with the MLP's last layer "
+                          "fused in would stream.  The kernels here do NOT fuse it (edge_weight is materialised): this is "
+                          "the smaller denominator SURVEY.md 8(d) asks to be shown next to the boundary figure",
+        }
+        # the same pair of fractions for the dominant tensor-product region (its launches carry a 'W' each)
     return roofline, step
+
+
+
+class GpuClockSampler:
+    """Shader clock / power / temperature of the GPU while it is busy (say WHY a box is slow).
+    Polls the amdgpu hwmon files of the device (freq1_input = current gfx clock in Hz, power1_average / power1_input in
+    microwatts, temp*_input in millidegrees) from a thread while the caller keeps the device busy; one `rocm-smi` call as
+    the fallback.  Never raises: a missing sysfs tree gives {"source": "unavailable"}."""
+
+    def __init__(self, dev_index: int = 0):
+        import glob
+        import threading
+
+        self._stop = threading.Event()
+        self._thread = None
+        self.samples = {"sclk_mhz": [], "power_w": [], "temp_c": []}
+        self.files = {}
+        self.source = "unavailable"
+        try:
+            cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+            if cards:
+                card = cards[min(dev_index, len(cards) - 1)]
+                hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*")))
+                if hw:
+                    for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input")),
+                                       ("temp_c", ("temp2_input", "temp1_input"))):
+                        for nm in names:
+                            f = os.path.join(hw[0], nm)
+                            if os.path.exists(f):
+                                self.files[key] = f
+                                break
+                self.files.setdefault("dpm", os.path.join(card, "pp_dpm_sclk"))
+                self.source = f"sysfs {card}"
+        except Exception:
+            self.files = {}
+
+    def _poll(self):
+        scale = {"sclk_mhz": 1e-6, "power_w": 1e-6, "temp_c": 1e-3}
+        while not self._stop.is_set():
+            for key in ("sclk_mhz", "power_w", "temp_c"):
+                f = self.files.get(key)
+                if f:
+                    try:
+                        self.samples[key].append(float(open(f).read().strip()) * scale[key])
+                    except Exception:
+                        pass
+            if "sclk_mhz" not in self.files and "dpm" in self.files:
+                try:
+                    for line in open(self.files["dpm"]).read().splitlines():
+                        if line.rstrip().endswith("*"):
+                            self.samples["sclk_mhz"].append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "")))
+                except Exception:
+                    pass
+            self._stop.wait(0.004)
+
+    def start(self):
+        import threading
+
+        if self.files:
+            self._thread = threading.Thread(target=self._poll, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        out = {"source": self.source}
+        for key, v in self.samples.items():
+            if v:
+                v = sorted(v)
+                out[key] = {"median": round(v[len(v) // 2], 1), "min": round(v[0], 1), "max": round(v[-1], 1), "n": len(v)}
+        return out
+
+
+def rocm_smi_snapshot():
+    """One `rocm-smi` reading (clocks, power cap, temperature) taken while the caller's kernels run; {} when unavailable."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {}
+    try:
+        res = subprocess.run([exe, "--showclocks", "--showpower", "--showmaxpower", "--showtemp", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20)
+        d = json.loads(res.stdout)
+        card = d.get("card0", next(iter(d.values())))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "power", "temperature (sensor junction)", "performance level")):
+                keep[k] = v
+        return keep
+    except Exception:
+        return {}
+
+
+def boundary_bytes(model, n_atoms: int, n_edges: int, hidden_width: int):
+    """SURVEY.md 8(d), energy + forces step at the TensorProductScatter boundary, fp32, 16 B of int64 indices per edge and
+    direction, every operand / result once: sum over layers of E (12 W + 12 S + 32) + 4 N (3 D_in + 2 D_mid).
+    `fused`: the same with the radial MLP's last layer inside the kernels (W -> H, the hidden width: the rows a fused
+    kernel would stream instead of edge_weight / grad_weight)."""
+    from nequip_amd.nn import TensorProductScatter
+
+    boundary = fused = 0.0
+    layers = []
+    for m in model.modules():
+        if isinstance(m, TensorProductScatter):
+            tp = m.tp
+            W, S = int(tp.weight_numel), int(tp.irreps_in2.dim)
+            d_in, d_mid = int(tp.irreps_in1.dim), int(tp.irreps_out.dim)
+            layers.append({"W": W, "S": S, "D_in": d_in, "D_mid": d_mid})
+            boundary += n_edges * (12.0 * W + 12.0 * S + 32.0) + 4.0 * n_atoms * (3 * d_in + 2 * d_mid)
+            fused += n_edges * (12.0 * min(W, hidden_width) + 12.0 * S + 32.0) + 4.0 * n_atoms * (3 * d_in + 2 * d_mid)
+    return boundary, fused, layers
 
 
 def train_bench(args, world, rank, device, distributed):
@@ -536,6 +697,8 @@ def main():
     model = build_model(cfg, names, device)
     data = AtomicDataDict.to_device(data_cpu, device)
     static_pos = data["pos"].clone()
+    ktimer.hidden_width = int(cfg["radial_mlp_width"])
+    bnd_bytes, fused_bytes, tp_layers = boundary_bytes(model, n_atoms, n_edges, int(cfg["radial_mlp_width"]))
 
     def step_eager():
         d = dict(data)
@@ -556,13 +719,13 @@ def main():
     torch.cuda.synchronize()
 
     use_graph = not args.no_graph
-    graph = None
-    if use_graph:
+
+    def capture():
+        """hipGraph of one evaluation (None when capture is unavailable).  The edge topology (CSR) is static for a fixed
+        neighbour list: it is built once in the eager warm-up and stays cached; the graph captures the model evaluation."""
         try:
-            # the edge topology (CSR) is static for a fixed neighbour list: it is built once in the eager
-            # warm-up above and stays cached; the graph captures the model evaluation only
             torch.cuda.empty_cache()  # the graph gets a private pool: hand the warm-up's cached blocks back first
-            graph = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -570,19 +733,22 @@ def main():
                     step_eager()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(g):
                 g_e, g_f = step_eager()
-            graph.replay()
+            g.replay()
             torch.cuda.synchronize()
             e2, f2 = step_eager()
             torch.cuda.synchronize()
             if not torch.allclose(g_f, f2, atol=1e-5, rtol=1e-5):
                 raise RuntimeError("graph replay disagrees with eager")
+            return g
         except Exception as exc:  # pragma: no cover
             if rank == 0:
                 print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); timing eager", file=sys.stderr)
-            graph = None
             topology_cache.clear()
+            return None
+
+    graph = capture() if use_graph else None
 
     def step():
         if graph is not None:
@@ -610,6 +776,59 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    # ---- what the clocks were while the device ran this very step (rank 0; outside the timed region) ----
+    gpu_state = None
+    if rank == 0 and os.environ.get("NQA_BENCH_NO_CLOCKS", "") in ("", "0"):
+        sampler = GpuClockSampler(dev_index).start()
+        t1 = time.perf_counter()
+        n_busy = 0
+        while time.perf_counter() - t1 < 0.8:
+            for _ in range(10):
+                step()
+            n_busy += 10
+        torch.cuda.synchronize()
+        busy_ms = (time.perf_counter() - t1) / max(n_busy, 1) * 1e3
+        gpu_state = sampler.stop()
+        gpu_state["ms_per_step_while_sampled"] = busy_ms
+        if "sclk_mhz" not in gpu_state:  # no hwmon files: one rocm-smi reading with the queue kept full
+            for _ in range(200):
+                step()
+            gpu_state["rocm_smi"] = rocm_smi_snapshot()
+            torch.cuda.synchronize()
+
+    # ---- the same step with every GEMM on the exact-fp32 MFMA pipe (the default splits fp32 operands into fp16 planes) ----
+    exact_ms = None
+    if rank == 0 and world == 1 and os.environ.get("NQA_BENCH_NO_EXACT_FP32", "") in ("", "0"):
+        saved = {k: os.environ.get(k) for k in ("NQA_MLP_EXACT_FP32", "NQA_NODE_EXACT_FP32")}
+        try:
+            os.environ["NQA_MLP_EXACT_FP32"] = "1"
+            os.environ["NQA_NODE_EXACT_FP32"] = "1"
+            for _ in range(3):
+                step_eager()
+            torch.cuda.synchronize()
+            g2 = capture() if use_graph else None
+            run = (g2.replay if g2 is not None else step_eager)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            torch.cuda.synchronize()
+            exact_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            del g2
+        except Exception as exc:  # pragma: no cover
+            print(f"[bench] exact-fp32 variant failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            for _ in range(2):  # back on the default path (weight images of the split modes are cached per mode)
+                step_eager()
+            torch.cuda.synchronize()
+
     # ---- per-kernel HIP-event timing of the hand-written kernels (eager, on the launching stream) ------
     roofline = step_roofline = None
     kernels = {}
@@ -630,7 +849,10 @@ def main():
             os.environ["NQA_NO_OVERLAP"] = prev_ov
         kernels = ktimer.summary()
         roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, ms_per_step, args.workload,
-                                                   live_pmc=(world == 1 and not args.no_pmc))
+                                                   live_pmc=(world == 1 and not args.no_pmc),
+                                                   boundary=(bnd_bytes, fused_bytes))
+        if step_roofline is not None:
+            step_roofline["layers"] = tp_layers
 
     if rank == 0:
         value = world * n_atoms * args.steps / elapsed
@@ -658,6 +880,16 @@ def main():
                 "launch": ("hipGraph replay" if graph is not None else "eager")
                 + ("" if os.environ.get("NQA_NO_OVERLAP", "") not in ("", "0") else
                    ", radial-MLP backward on a side stream (parallel graph branch)"),
+                # `dtype` f32 = what the path computes in: fp32 storage and accumulation everywhere; the three dense GEMM
+                # families are evaluated as split products on the fp16 matrix pipe (fp32-accurate), see exact_fp32_ms_per_step
+                "arithmetic": ("fp32 storage / accumulate (fp64 geometry + per-atom energies); radial-MLP and node (Linear, "
+                               "self-connection) GEMMs as 3 x fp16 MFMA products on 22-bit two-plane operand splits "
+                               "(error 2^-22 per operand: fp32 level); tensor product / scatter in plain fp32 FMA"
+                               if os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0") else
+                               "fp32 throughout: GEMMs on the exact-fp32 MFMA pipe (v_mfma_f32_32x32x2_f32)"),
+                "exact_fp32_ms_per_step": exact_ms,
+                "gpu_state": gpu_state,
+                "gpu_clock_mhz": (gpu_state or {}).get("sclk_mhz", {}).get("median") if gpu_state else None,
             },
             "roofline": roofline,
             "step_roofline": step_roofline,

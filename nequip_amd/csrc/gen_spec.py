@@ -1344,7 +1344,28 @@ def generate(out_dir: str) -> List[str]:
     return files
 
 
+MANIFEST = os.path.join(HERE, "generated_spec.manifest.json")
+
+
+def manifest() -> dict:
+    """file name -> {sha256, lines, key} of what the generator emits NOW (the generated sources are not tracked in git;
+    tests/test_bench_contract.py pins them to the committed manifest)."""
+    out = {}
+    for st in baseline_structures():
+        src = _emit(st)
+        out[f"tp_spec_{st.name}_{st.tag()}.hip"] = {"sha256": hashlib.sha256(src.encode()).hexdigest(),
+                                                     "lines": src.count("\n") + 1, "key": st.key()}
+    return out
+
+
 if __name__ == "__main__":
+    if "--write-manifest" in sys.argv:
+        import json
+
+        old = json.load(open(MANIFEST)) if os.path.exists(MANIFEST) else {"note": ""}
+        json.dump({"note": old.get("note", ""), "files": manifest()}, open(MANIFEST, "w"), indent=1)
+        print("wrote", MANIFEST)
+        sys.exit(0)
     fs = generate(os.path.join(HERE, "generated_spec"))
     for st in baseline_structures():
         print(st.name, st.tag(), "paths", len(st.instr), "kOD", sum(2 * l + 1 for l in st.out_ls))

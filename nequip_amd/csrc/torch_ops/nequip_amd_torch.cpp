@@ -316,6 +316,9 @@ struct Topology {
   bool has_dst = false, has_src = false;
   bool pairing_done = false;           // reverse-edge pairing (radial_tp_*): verdict read once per entry
   const void* pairing_shift = nullptr;
+  uint32_t pairing_shift_version = 0;  // Tensor::_version() of the shift tensor the pairing was decided on
+  int64_t pairing_shift_numel = -1;
+  Tensor pairing_shift_hold;  // keeps the storage alive: a freed and re-used address cannot alias the key
   std::shared_ptr<struct Pairing> pairing;
   std::mutex build;  // the CSRs are built on first use, outside the registry lock
   Topology(const Tensor& d, const Tensor& s)
@@ -433,9 +436,20 @@ std::shared_ptr<Pairing> pairing_of(Topology& t, const OptTensor& shift) {
   const Csr& cd = by_dst(t);  // (the reverse of (i <- j) is looked up in row j of the dst-CSR: no sort)
   std::lock_guard<std::mutex> lock(t.build);
   const void* sp = ptr(shift);
-  if (t.pairing_done && t.pairing_shift == sp) return t.pairing;
+  // key as EdgeTopology._shift_key (nn/_topology.py): address, in-place version counter and size -- cell shifts rewritten in
+  // place through torch (cache mode 2 keeps entries across evaluations) must not meet a stale pairing
+  const uint32_t sv = sp != nullptr ? (*shift)._version() : 0u;
+  const int64_t sn = sp != nullptr ? shift->numel() : -1;
+  if (t.pairing_done && t.pairing_shift == sp && t.pairing_shift_version == sv && t.pairing_shift_numel == sn) return t.pairing;
+  if (t.pairing_done && t.has_src) {  // the by-source CSR of a paired list was derived from the old partner map
+    t.has_src = false;
+    t.by_src = Csr();
+  }
   t.pairing_done = true;
   t.pairing_shift = sp;
+  t.pairing_shift_version = sv;
+  t.pairing_shift_numel = sn;
+  t.pairing_shift_hold = sp != nullptr ? *shift : Tensor();
   t.pairing.reset();
   const int64_t E = t.num_edges;
   if (E == 0 || (E & 1) != 0 || env_on("NQA_NO_PAIRED")) return nullptr;

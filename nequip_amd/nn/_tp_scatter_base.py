@@ -87,7 +87,8 @@ class _Kernels:
         nbytes = topo.num_edges * (es * (self.weight_numel + self.dim_in2) + 16) + topo.num_nodes * es * (
             self.dim_in1 + self.dim_out
         )
-        with torch.cuda.device(x.device), ktimer.region("tp_fwd", nbytes):
+        with torch.cuda.device(x.device), ktimer.region("tp_fwd", nbytes, 0.0, topo.num_edges * es * self.weight_numel,
+                                                        self.weight_numel):
             if pairing is None:
                 rc = lib.nqa_tp_scatter_fwd(
                     self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w),
@@ -131,7 +132,8 @@ class _Kernels:
             self.dim_in1 + self.dim_out
         )
         nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
-        with torch.cuda.device(x.device), ktimer.region("tp_bwd_edge", nbytes):
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_edge", nbytes, 0.0,
+                                                        E * es * self.weight_numel * (2 if need_gw else 1), self.weight_numel):
             if pairing is None:
                 rc = lib.nqa_tp_scatter_bwd_edge(
                     self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
@@ -166,9 +168,10 @@ class _Kernels:
         es = x.element_size()
         # algorithmic bytes: operands and results once (w, y, gw, gy per edge; x, g, gx per node) -- the intermediate
         # per-edge grad_x rows (written and read once, 2 * dim_in1 per edge) are traffic, not algorithm
-        nbytes = E * (es * (self.weight_numel + self.dim_in2) + 24) + N * es * (2 * self.dim_in1 + self.dim_out)
+        nbytes = E * (es * (self.weight_numel + self.dim_in2) + 16) + N * es * (2 * self.dim_in1 + self.dim_out)
         nbytes += E * es * ((self.weight_numel if need_gw else 0) + (self.dim_in2 if need_gy else 0))
-        with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused", nbytes):
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused", nbytes, 0.0,
+                                                        E * es * self.weight_numel * (2 if need_gw else 1), self.weight_numel):
             if pairing is None:
                 rc = lib.nqa_tp_scatter_bwd_fused(
                     self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
@@ -212,10 +215,11 @@ class _Kernels:
         # interface defines it (the same formulas as bwd_fused / bwd_edge) -- this kernel moves less than that because it
         # reads the shared weight row and writes its gradient once per pair
         if need_gx:
-            nbytes = E * (es * (2 * self.weight_numel + 2 * self.dim_in2) + 24) + N * es * (2 * self.dim_in1 + self.dim_out)
+            nbytes = E * (es * (2 * self.weight_numel + 2 * self.dim_in2) + 16) + N * es * (2 * self.dim_in1 + self.dim_out)
         else:
             nbytes = E * (es * (2 * self.weight_numel + 2 * self.dim_in2) + 16) + N * es * (self.dim_in1 + self.dim_out)
-        with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused" if need_gx else "tp_bwd_edge", nbytes):
+        with torch.cuda.device(x.device), ktimer.region("tp_bwd_fused" if need_gx else "tp_bwd_edge", nbytes, 0.0,
+                                                        E * es * 2 * self.weight_numel, self.weight_numel):
             rc = lib.nqa_tp_scatter_bwd_pairs(
                 self.plan.handle, _ptr(self.image), _nqa_dtype(x.dtype), _ptr(x), _ptr(y), _ptr(w), _ptr(g),
                 _ptr(orow), _ptr(oth), _ptr(prow), _ptr(ein), _ptr(eout), _ptr(trow), _ptr(tslot),
@@ -325,7 +329,8 @@ class _Kernels:
         nbytes = topo.num_edges * (es * (self.weight_numel + self.dim_in2) + 16) + topo.num_nodes * es * (
             self.dim_in1 + self.dim_out
         )
-        with torch.cuda.device(g.device), ktimer.region("tp_bwd_x", nbytes):
+        with torch.cuda.device(g.device), ktimer.region("tp_bwd_x", nbytes, 0.0, topo.num_edges * es * self.weight_numel,
+                                                        self.weight_numel):
             if pairing is None:
                 rc = lib.nqa_tp_scatter_bwd_x(
                     self.plan.handle, _ptr(self.image), _nqa_dtype(g.dtype), _ptr(y), _ptr(w), _ptr(g),

@@ -68,7 +68,12 @@ class PerTypeScaleShift(GraphModuleMixin, torch.nn.Module):
         self.shifts_shortcut = self.shifts.numel() == 1
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
-        if data.pop("_nqa_energy_scaled", False):
+        scaled_by = data.pop("_nqa_energy_scaled", None)
+        if scaled_by is not None and scaled_by != id(self):
+            raise RuntimeError("the fused energy head applied the scales / shifts of a PerTypeScaleShift module that is no "
+                               "longer the one in the model (module replaced after the model was built): rebuild the model "
+                               "or set NQA_NO_ENERGY_HEAD=1")
+        if scaled_by is not None:
             # the fused energy head (nn/_energy_head.py) has produced `field` in float64 with this module's scales and
             # shifts applied
             if self.out_field != self.field:

@@ -141,7 +141,9 @@ def cutoff_partialdict_to_tensor(partial_dict: Dict, type_names: List[str], r_ma
             rows.append([float(entry)] * len(type_names))
         else:
             rows.append([float(entry.get(other, r_max)) for other in type_names])
-    return torch.as_tensor(rows, dtype=_GLOBAL_DTYPE).contiguous()
+    table = torch.as_tensor(rows, dtype=_GLOBAL_DTYPE).contiguous()
+    assert torch.all(table > 0), "per-edge-type cutoffs must be positive"  # (nequip/nn/embedding/utils.py)
+    return table
 
 
 class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):
@@ -178,7 +180,8 @@ class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):
         if self._per_edge_type:
             if self.edge_type_field not in data:  # with_edge_type_ (nequip/nn/utils.py:121-133)
                 data[self.edge_type_field] = torch.index_select(
-                    data[AtomicDataDict.ATOM_TYPE_KEY].view(-1), 0, data[AtomicDataDict.EDGE_INDEX_KEY].view(-1)).view(2, -1)
+                    data[AtomicDataDict.ATOM_TYPE_KEY].reshape(-1), 0,
+                    data[AtomicDataDict.EDGE_INDEX_KEY].reshape(-1)).view(2, -1)
             et = data[self.edge_type_field]
             data["_nqa_rmax_recip_edge"] = torch.index_select(self._rmax_recip, 0, et[0] * self.num_types + et[1])
         return data

@@ -211,7 +211,7 @@ def _launch_last(pre, w, alpha: float, cache: _WeightImages, g=None):
     mode = _lib.NQA_MLP_F16X3
     backward = 0 if g is None else 1
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, backward, H, W)
-    ws, ready = cache.get(w, mode, backward, ws_bytes)
+    ws, ready = cache.get(w, mode, backward, ws_bytes, E)
     flops = 2.0 * E * H * W
     if g is None:
         out = torch.empty((E, W), dtype=pre.dtype, device=pre.device)
@@ -507,6 +507,10 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
         ss = tail[0]
         if ss.field != self.out_field or ss.out_field != self.out_field:
             return None
+        # the head reads scales / shifts as float64 and the types as int64 (a `model.float()` must not be reinterpreted)
+        if ((ss.has_scales and ss.scales.dtype != torch.float64) or (ss.has_shifts and ss.shifts.dtype != torch.float64)
+                or data[AtomicDataDict.ATOM_TYPE_KEY].dtype != torch.int64):
+            return None
         lin = fn.mlp[0]
         types = data[AtomicDataDict.ATOM_TYPE_KEY].view(-1)[: h.shape[0]].contiguous()
         _, _, _, _, _, act, cst = gate_meta.blocks[0]
@@ -537,7 +541,12 @@ class ScalarMLP(_WeightCacheMixin, GraphModuleMixin, torch.nn.Module):
             e = self._energy_head(data, h, gate_meta)
             if e is not None:
                 data[self.out_field] = e
-                data["_nqa_energy_scaled"] = True  # PerTypeScaleShift has been applied (it passes the field on)
+                # PerTypeScaleShift has been applied by THAT module's parameters (it passes the field on; a different
+                # module in its place -- the Sequential entry was replaced after the model was built -- raises)
+                data["_nqa_energy_scaled"] = id(self.__dict__["_scale_shift"][0])
+                # the gated last-layer features were never formed: the field must not keep the PRE-gate rows
+                if self.field != self.out_field:
+                    data.pop(self.field, None)
                 return data
             from ..o3 import _node_kernels
 

@@ -105,6 +105,10 @@ def aot_export_model(model: torch.nn.Module, data: AtomicDataDict.Type, output_p
     if not str(output_path).endswith(".nequip.pt2"):
         raise ValueError("AOTInductor packages are named `<name>.nequip.pt2` (nequip/scripts/compile.py:97-104)")
     model = model.eval()
+    for name, mod in model.named_modules():  # no dispatcher-op form: say so before tracing starts
+        if getattr(mod, "_per_edge_type", False):
+            raise NotImplementedError(f"aot_export_model: `{name}` uses per_edge_type_cutoff, which has no traceable "
+                                      "(compile) form; export a model with a single cutoff or run it eagerly")
     inputs = {k: data[k] for k in input_fields}
     device = inputs[AtomicDataDict.POSITIONS_KEY].device
     if device.type != "cuda":

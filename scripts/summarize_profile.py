@@ -63,6 +63,27 @@ REGIONS = {
     "edge_vectors": ([plain("edge_vectors_fwd_kernel", "edge_vectors_bwd_kernel")], []),
 }
 
+CALIBRATION = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r5_pmc_calibration.json")
+
+
+def load_calibration():
+    try:
+        return json.load(open(CALIBRATION))["factors"]
+    except Exception:
+        return {}
+
+
+def factors_for(kernel: str, calib: dict):
+    """(FETCH_SIZE factor, WRITE_SIZE factor) of a GPU kernel by its access pattern: the tensor-product kernels read and
+    write 4 B per lane (lane = channel, one 256 B row segment per wave access, nontemporal result stores); the radial MLP,
+    node and embedding kernels move 16 B per lane."""
+    tp = any(s in kernel for s in ("::fwd_kernel<", "bwd_edge_kernel", "bwd_pair", "bwd_x_kernel", "gx_rows_sum", "tp_fwd_kernel",
+                                    "tp_bwd", "spec_gy_reduce"))
+    if tp:
+        return (calib.get("fetch_4B_per_lane_rows") or 2.0, calib.get("write_4B_per_lane_rows_nontemporal") or 1.0)
+    return (calib.get("fetch_16B_per_lane_stream") or 2.0, calib.get("write_16B_per_lane_lines_nontemporal") or 1.0)
+
+
 def region_of(kernel_name: str):
     """bench.py region of a GPU kernel name ('main' or 'helper' role), or (None, None)."""
     k = kernel_name.replace("(anonymous namespace)::", "")
@@ -103,9 +124,14 @@ def main(out_dir, tag, commit=None):
         for k, c in n.items():
             per[k][counter + "_KB"] /= c
             per[k]["dispatches"] = c
+    calib = load_calibration()
     for k, v in per.items():
-        # gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads (x2); WRITE_SIZE is exact, both in KB
-        v["hbm_bytes_corrected"] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
+        # gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads (x2, MI355X_MICROARCH.md); other access
+        # widths and WRITE_SIZE as calibrated on known byte counts in this repo's own access patterns
+        # (scripts/pmc_calibrate.py -> profiles/r5_pmc_calibration.json), 2.0 / 1.0 when no calibration file is present
+        ff, wf = factors_for(k, calib)
+        v["fetch_factor"], v["write_factor"] = ff, wf
+        v["hbm_bytes_corrected"] = (ff * v["FETCH_SIZE_KB"] + wf * v["WRITE_SIZE_KB"]) * 1024.0
 
     bench = {}
     for region, (main_pats, helper_pats) in REGIONS.items():
@@ -127,7 +153,9 @@ def main(out_dir, tag, commit=None):
     res = {
         "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE collected in separate passes over bench.py's cfg-3 workload "
                 "(scripts/profile.sh). Units: KB per dispatch, averaged over that kernel's dispatches (all layers). "
-                "gfx950 correction per MI355X_MICROARCH.md: hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.",
+                "gfx950 correction: hbm bytes = (fetch_factor*FETCH_SIZE + write_factor*WRITE_SIZE) * 1024 with the factors "
+                "of profiles/r5_pmc_calibration.json per access pattern (2 / 1 of MI355X_MICROARCH.md when uncalibrated).",
+        "calibration": calib,
         "kernels": dict(sorted(per.items())),
         "bench_kernels": bench,
         "commit": commit or os.environ.get("NQA_COMMIT", "n/a"),

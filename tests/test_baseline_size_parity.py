@@ -285,3 +285,61 @@ def test_cfg4_full_batch_32_frames_training_step(device):
         torch.testing.assert_close(r, p.grad.cpu(), atol=tol * scale, rtol=tol * 10, msg=lambda m: f"{k}: {m}")
     print(f"[cfg-4 full batch] max|dF|={df:.3e} eV/A, {len(grads_ref)} parameter tensors, "
           f"worst |dgrad| / max|grad| = {worst:.2e}")
+
+
+# ---- round 5: cfg-5 at the size BASELINE.json names -------------------------------------------------------------------
+@pytest.mark.gpu
+def test_cfg5_full_size_100000_atoms_tiled_block_against_oracle(device):
+    """cfg-5 AT ITS OWN SIZE: 100 000 Cu atoms (25 x 25 x 40 fcc cells, ~3.8 M edges, l_max 3, 128 features), the box
+    ``bench.py --workload cu100k`` times.  The oracle cannot evaluate that box in test time, but a periodic crystal made of
+    identical blocks has the forces of ONE block: the box is built as the 5 x 5 x 5 tiling of a rattled 5 x 5 x 8-cell
+    block (800 atoms, rattle sigma 0.05 A, every edge of the block longer than 2 r_max), the oracle evaluates the block in
+    its own periodic cell, and the HIP model on the tiled box must return the block's forces replicated 125 times (bar
+    1e-4 eV/A, BASELINE north_star) and 125 x its energy and virial.  Exercises at full size what the smaller cfg-5 tests
+    cannot: the one-wavefront-per-(node, chunk) launch shape chosen by problem size, 3.8 M-edge CSRs / pairing / owner
+    lists, and [E, W] tensors of more than 2^31 elements (E x 2944 weights = 1.1e10)."""
+    import numpy as np
+
+    import bench
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.utils import synthetic as syn
+
+    w = bench.WORKLOADS["cu100k"]
+    assert tuple(w["reps"]) == (25, 25, 40) and w["l_max"] == 3 and w["num_features"] == 128
+    pos_b, types_b, cell_b, names = syn.copper_box(reps=(5, 5, 8), seed=0)
+    block = syn.make_data(pos_b, types_b, 4.5, cell_b)
+    nb_, eb = block["pos"].shape[0], block["edge_index"].shape[1]
+    assert nb_ == 800
+    reps = (5, 5, 5)
+    cell_b = np.asarray(cell_b, dtype=np.float64)
+    offs = [ix * cell_b[0] + iy * cell_b[1] + iz * cell_b[2] for ix in range(reps[0]) for iy in range(reps[1]) for iz in range(reps[2])]
+    pos = np.concatenate([np.asarray(pos_b) + o for o in offs], axis=0)
+    types = np.concatenate([np.asarray(types_b)] * len(offs), axis=0)
+    cell = cell_b * np.asarray(reps, dtype=np.float64)[:, None]
+    data = syn.make_data(pos, types, 4.5, cell)
+    n, e = data["pos"].shape[0], data["edge_index"].shape[1]
+    assert n == 100000 and e == 125 * eb, (n, e, eb)
+    cfg = bench.model_cfg(w, e / n)
+    model = bench.build_model(cfg, names, device)
+
+    _oracle_threads()
+    t0 = time.perf_counter()
+    ref = omodel.energy_forces(block, dict(cfg, oracle_edge_chunk=4096), _weights(model), with_virial=True)
+    print(f"[cfg-5 full size] oracle on the 800-atom block: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+
+    out = model(AtomicDataDict.to_device(data, device))
+    torch.cuda.synchronize()
+    f_out = out["forces"].cpu().view(125, nb_, 3)
+    f_ref = ref["forces"].view(1, nb_, 3)
+    fscale = float(f_ref.abs().max())
+    df = float((f_out - f_ref).abs().max())
+    spread = float((f_out - f_out[:1]).abs().max())  # the 125 copies among themselves (translation symmetry of the box)
+    e_out, e_ref = out["total_energy"].cpu().view(-1), ref["total_energy"].view(-1) * 125.0
+    dv = float((out["virial"].cpu().view(3, 3) - 125.0 * ref["virial"].view(3, 3)).abs().max())
+    print(f"[cfg-5 full size] N={n} E={e} max|dF|={df:.3e} eV/A (max|F|={fscale:.3e}; copies differ by {spread:.3e}) "
+          f"|dE|={float((e_out - e_ref).abs().max()):.3e} of {float(e_ref.abs().max()):.3e}  max|dV|={dv:.3e}")
+    assert df < 1e-4, f"forces differ from the oracle's block forces by {df:.3e} eV/A (bar 1e-4)"
+    torch.testing.assert_close(f_out, f_ref.expand(125, -1, -1).contiguous(), atol=5e-5 * max(1.0, fscale), rtol=5e-5)
+    torch.testing.assert_close(e_out, e_ref, atol=5e-5 * n, rtol=5e-5)
+    torch.testing.assert_close(out["virial"].cpu().view(3, 3), 125.0 * ref["virial"].view(3, 3),
+                               atol=5e-5 * n * max(1.0, fscale), rtol=5e-4)

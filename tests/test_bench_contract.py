@@ -86,8 +86,11 @@ def test_profile_summariser_classifies_every_generated_kernel():
     assert sp.region_of("nqa::radial_mlp_split_w1_fwd_f16_kernel(float const*)") == ("radial_mlp_fwd", "helper")
     spec_dir = os.path.join(ROOT, "nequip_amd", "csrc", "generated_spec")
     files = glob.glob(os.path.join(spec_dir, "*.hip"))
-    if not files:
-        pytest.skip("generated_spec/ not built yet (python -m nequip_amd.csrc.build)")
+    if not files:  # (the generated sources are not tracked: make them, as build() would)
+        sys.path.insert(0, os.path.join(ROOT, "nequip_amd", "csrc"))
+        import gen_spec
+
+        files = gen_spec.generate(spec_dir)
     seen = set()
     for f in files:
         for m in re.finditer(r"hipLaunchKernelGGL\(\((\w+<[^<>]*>)\)", open(f).read()):
@@ -126,3 +129,29 @@ def test_bench_two_ranks_training_line_on_a_shared_device(device):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and "all-reduce" in d["config"]["collective"]
     assert d["value"] > 0 and "node_linear" in d["kernels_ms_per_step"]
+
+
+def test_generated_kernel_sources_match_the_committed_manifest():
+    """``csrc/generated_spec/*.hip`` (37 structure-specialised kernel files, ~100 k lines) are build products of
+    ``gen_spec.py`` and are not tracked; ``csrc/generated_spec.manifest.json`` pins what the generator must emit (sha256 per
+    file, default generator switches), so a change of the generator shows up as a one-line manifest diff in review, and
+    whatever lies in ``generated_spec/`` (what the library was built from) must be exactly that."""
+    import hashlib
+
+    for k in list(os.environ):
+        assert not k.startswith("NQA_GEN_"), f"{k} is set: the manifest pins the default generator switches"
+    sys.path.insert(0, os.path.join(ROOT, "nequip_amd", "csrc"))
+    import gen_spec
+
+    want = json.load(open(gen_spec.MANIFEST))["files"]
+    got = gen_spec.manifest()
+    assert sorted(got) == sorted(want), (sorted(set(got) ^ set(want)))
+    stale = [f for f in got if got[f]["sha256"] != want[f]["sha256"]]
+    assert not stale, f"gen_spec.py output changed for {stale}: python nequip_amd/csrc/gen_spec.py --write-manifest"
+    spec_dir = os.path.join(ROOT, "nequip_amd", "csrc", "generated_spec")
+    if os.path.isdir(spec_dir):
+        on_disk = {f for f in os.listdir(spec_dir) if f.endswith(".hip")}
+        if on_disk:
+            assert on_disk == set(want), sorted(on_disk ^ set(want))
+            for f in sorted(on_disk):
+                assert hashlib.sha256(open(os.path.join(spec_dir, f), "rb").read()).hexdigest() == want[f]["sha256"], f

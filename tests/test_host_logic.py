@@ -382,3 +382,30 @@ def test_skinny_product_gradients():
     got = torch.autograd.grad(_skinny_mm(a, b), (a, b), go)
     assert float((ref[0] - got[0]).abs().max()) < 2e-6 * float(ref[0].abs().max())
     assert torch.equal(ref[1], got[1])
+
+
+def test_per_edge_type_cutoff_host_guards():
+    """The reference's guards around ``per_edge_type_cutoff`` (nequip/nn/embedding/utils.py: positive cutoffs;
+    nequip/nn/utils.py:121-133: ``with_edge_type_`` accepts any edge_index layout) and the early failure of the compile
+    path, which has no dispatcher-op form for it."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.nn.embedding import EdgeLengthNormalizer, cutoff_partialdict_to_tensor
+    from nequip_amd.utils.aot import aot_export_model
+
+    with pytest.raises(AssertionError):
+        cutoff_partialdict_to_tensor({"A": 0.0}, ["A", "B"], 4.0)
+    with pytest.raises(AssertionError):
+        cutoff_partialdict_to_tensor({"A": {"B": -1.0}}, ["A", "B"], 4.0)
+    norm = EdgeLengthNormalizer(r_max=4.0, type_names=["A", "B"], per_edge_type_cutoff={"A": 3.0, "B": {"A": 3.5, "B": 2.5}})
+    types = torch.tensor([0, 1, 1, 0])
+    ei_t = torch.tensor([[0, 1], [1, 2], [2, 3], [3, 0], [1, 0]])  # [E, 2]: its transpose is a non-contiguous [2, E]
+    vec = torch.randn(5, 3, dtype=torch.float64)
+    out = norm({K.EDGE_VECTORS_KEY: vec, K.ATOM_TYPE_KEY: types.view(-1, 1), K.EDGE_INDEX_KEY: ei_t.t()})
+    want = torch.tensor([[3.0, 3.0], [3.5, 2.5]], dtype=torch.float64).reciprocal()
+    torch.testing.assert_close(out["_nqa_rmax_recip_edge"], want[types[ei_t[:, 0]], types[ei_t[:, 1]]])
+
+    model = NequIPGNNModel(seed=0, model_dtype="float32", r_max=4.0, type_names=["A", "B"], num_layers=2, l_max=1,
+                           num_features=8, radial_mlp_width=64, avg_num_neighbors=10.0, per_edge_type_cutoff={"A": 3.0})
+    with pytest.raises(NotImplementedError, match="per_edge_type_cutoff"):
+        aot_export_model(model, {}, "/tmp/x.nequip.pt2")

@@ -147,6 +147,21 @@ def _reference_f64(h, types, table, gate, lin1, sc, scale1):
     return scale1 * l64(x), s64.forward_typed(x, types, table)
 
 
+def _reference_oracle_f64(h, types, table, gate, lin1, sc, scale1):
+    """The same stage through the ORACLE's restatements of e3nn's Gate / Linear / FullyConnectedTensorProduct
+    (oracle/nn.py: gate, o3_linear, fully_connected_tp), float64 -- independent of the product's own
+    ATen formulation in o3/modules.py."""
+    from oracle import nn as onn
+
+    names = {SILU: "silu", torch.tanh: "tanh"}
+    x = onn.gate(h, str(gate.irreps_scalars), [names[a] for a in gate.act_scalars], str(gate.irreps_gates),
+                 [names[a] for a in gate.act_gates], str(gate.irreps_gated))
+    y1 = onn.o3_linear(x, lin1.weight.detach().double().cpu(), str(lin1.irreps_in), str(lin1.irreps_out)) * scale1
+    ys = onn.fully_connected_tp(x, table[types], sc.weight.detach().double().cpu(), str(sc.irreps_in1), str(sc.irreps_in2),
+                                str(sc.irreps_out))
+    return y1, ys
+
+
 CASES = [
     ("64x0e+64x1o+64x2e", 2, 1003),                      # cfg-3 middle layer; N not a multiple of 32 / 10 / 6
     ("32x0e+32x0o+32x1e+32x1o", 4, 105),                  # tutorial shape (parity=True: tanh on odd scalars), 4 species
@@ -191,6 +206,14 @@ def test_fused_stage_matches_separate_launches_and_float64(device, hidden, n_typ
     close(x1, ref1, "linear_1(Gate(h)) / sqrt(avg)")
     close(s, refs, "sc(Gate(h))")
     close(g, g_ref, "gradient w.r.t. the pre-gate rows")
+    # ... and against the oracle's restatement of the three e3nn modules (not the product's own ATen formulation)
+    hq = h.clone().requires_grad_(True)
+    q1, qs = _reference_oracle_f64(hq, types, table, gate.cpu(), lin1.cpu(), sc.cpu(), scale1)
+    (g_orc,) = torch.autograd.grad((q1 * c1).sum() + (qs * cs).sum(), hq)
+    close(x1, q1.detach(), "linear_1(Gate(h)) / sqrt(avg) vs oracle.nn")
+    close(s, qs.detach(), "sc(Gate(h)) vs oracle.nn")
+    close(g, g_orc, "gradient w.r.t. the pre-gate rows vs oracle.nn")
+    gate, lin1, sc = gate.to(device), lin1.to(device), sc.to(device)
 
     # the separate launches (nqa_gate, nqa_node_linear_packed x 2; backward x 3 + an add)
     h2 = h.float().to(device).requires_grad_(True)

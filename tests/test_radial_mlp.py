@@ -258,3 +258,34 @@ def test_radial_mlp_training_aten_switch(device, monkeypatch):
     for a, b in zip(fused, [p.grad for p in mlp.parameters()]):
         assert torch.isfinite(a).all()
         torch.testing.assert_close(a, b, atol=1e-4 * float(b.abs().max()), rtol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_radial_mlp_zero_edges_first_then_real_graph(device, depth):
+    """A first call on an empty edge list (isolated atom) must not leave a never-filled weight image behind that the next
+    call with edges would take for a filled one (``_WeightImages.get(..., rows)``): every launch of the fused path, the
+    ``nqa_radial_mlp_last_*`` layers of a deeper MLP included, passes its row count."""
+    from nequip_amd.nn.mlp import ScalarMLPFunction
+
+    torch.manual_seed(11 + depth)
+    H, W, E = 64, 160, 777
+    mlp = ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=depth, hidden_layers_width=H).eval()
+    ws = [m.weight.detach().clone() for m in mlp.mlp if hasattr(m, "weight")]
+    emb = torch.randn(E, 8) * 0.7
+    e_ref = emb.clone().requires_grad_(True)
+    ref = onn.scalar_mlp(e_ref, ws, "silu")
+    g = torch.randn(E, W)
+    (ge_ref,) = torch.autograd.grad(ref, e_ref, g)
+
+    mlp = mlp.to(device)
+    e0 = torch.zeros(0, 8, device=device, requires_grad=True)
+    out0 = mlp(e0)
+    assert out0.shape == (0, W)
+    (g0,) = torch.autograd.grad(out0, e0, torch.zeros(0, W, device=device))
+    assert g0.shape == (0, 8)
+    e_dev = emb.to(device).requires_grad_(True)
+    out = mlp(e_dev)
+    (ge,) = torch.autograd.grad(out, e_dev, g.to(device))
+    torch.testing.assert_close(ref.detach(), out.detach().cpu(), atol=1e-5 * float(ref.abs().max()), rtol=1e-5)
+    torch.testing.assert_close(ge_ref, ge.cpu(), atol=2e-5 * float(ge_ref.abs().max()), rtol=2e-5)
