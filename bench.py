@@ -416,7 +416,7 @@ class GpuClockSampler:
 
         self._stop = threading.Event()
         self._thread = None
-        self.samples = {"sclk_mhz": [], "power_w": [], "temp_c": []}
+        self.samples = {"sclk_mhz": [], "dpm_sclk_mhz": [], "power_w": [], "temp_c": []}
         self.files = {}
         self.source = "unavailable"
         try:
@@ -447,11 +447,11 @@ class GpuClockSampler:
                         self.samples[key].append(float(open(f).read().strip()) * scale[key])
                     except Exception:
                         pass
-            if "sclk_mhz" not in self.files and "dpm" in self.files:
+            if "dpm" in self.files:  # the DPM level in use (the `*` line of pp_dpm_sclk), next to the hwmon reading
                 try:
                     for line in open(self.files["dpm"]).read().splitlines():
                         if line.rstrip().endswith("*"):
-                            self.samples["sclk_mhz"].append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "")))
+                            self.samples["dpm_sclk_mhz"].append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "")))
                 except Exception:
                     pass
             self._stop.wait(0.004)
@@ -790,11 +790,12 @@ def main():
         busy_ms = (time.perf_counter() - t1) / max(n_busy, 1) * 1e3
         gpu_state = sampler.stop()
         gpu_state["ms_per_step_while_sampled"] = busy_ms
-        if "sclk_mhz" not in gpu_state:  # no hwmon files: one rocm-smi reading with the queue kept full
-            for _ in range(200):
-                step()
-            gpu_state["rocm_smi"] = rocm_smi_snapshot()
-            torch.cuda.synchronize()
+        # one rocm-smi reading with the queue kept full (hwmon's freq1_input reads ~100 MHz on some boxes while busy:
+        # the sensor is not the XCDs' shader clock there -- the tool's own view is recorded next to it)
+        for _ in range(400):
+            step()
+        gpu_state["rocm_smi"] = rocm_smi_snapshot()
+        torch.cuda.synchronize()
 
     # ---- the same step with every GEMM on the exact-fp32 MFMA pipe (the default splits fp32 operands into fp16 planes) ----
     exact_ms = None
@@ -889,7 +890,8 @@ def main():
                                "fp32 throughout: GEMMs on the exact-fp32 MFMA pipe (v_mfma_f32_32x32x2_f32)"),
                 "exact_fp32_ms_per_step": exact_ms,
                 "gpu_state": gpu_state,
-                "gpu_clock_mhz": (gpu_state or {}).get("sclk_mhz", {}).get("median") if gpu_state else None,
+                "gpu_clock_mhz": (((gpu_state or {}).get("dpm_sclk_mhz") or (gpu_state or {}).get("sclk_mhz") or {}).get("median")
+                                  if gpu_state else None),
             },
             "roofline": roofline,
             "step_roofline": step_roofline,
