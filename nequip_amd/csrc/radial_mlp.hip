@@ -1059,6 +1059,10 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_bal_kernel(const 
     emit(a1A, a1B, prev_tile, prev_row0, prev_rs);
 }
 
+}  // namespace nqa
+#include "radial_mlp_pipe.h"
+namespace nqa {
+
 // TM (training mode, see nqa_radial_mlp_bwd_train): 0 = inference (g_emb only); 1 = additionally hid_out = silu(P)
 // and the per-workgroup partial of dW0 = emb^T (G_h silu'(P)); 2 = second order with a cotangent row block cemb:
 // Q = cemb W0, hid_out = Q silu'(P), g_emb = (Q G_h silu''(P)) W0^T, dW0 partial = emb^T (Q G_h silu'') + cemb^T (G_h silu').
@@ -1586,14 +1590,44 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
     if (!workspace_ready)
       hipLaunchKernelGGL(radial_mlp_split_w1_fwd_f16_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, b, (float)alpha1,
                          hidden, out_features, wf, ts);
-    const int64_t units = (int64_t)grid * ntiles;
-    const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
-    if (hidden == 128)
-      hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<128, true>), dim3(gb), dim3(256), 0, s, e, a, wf,
-                         (float)alpha0, num_basis, out_features, num_edges, o, ts);
-    else
-      hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<64, true>), dim3(gb), dim3(256), 0, s, e, a, wf,
-                         (float)alpha0, num_basis, out_features, num_edges, o, ts);
+    // round 5: outputs of complete 32-column tiles run on the issue-scheduled kernel (radial_mlp_pipe.h; NQA_MLP_PIPE=0:
+    // the general kernel)
+    static const bool pipe = [] {
+      const char* v = std::getenv("NQA_MLP_PIPE");
+      return v == nullptr || v[0] != '0';
+    }();
+    // (H = 64 stays on the general kernel: its 166 registers keep three wavefronts per SIMD, the scheduled form needs 170)
+    if (pipe && hidden == 128 && out_features % 32 == 0 && ntiles <= 128) {
+      const int64_t e_done = num_edges;
+      const int64_t units = (int64_t)grid * ntiles;
+      const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
+      // tile epilogue: through the wave-private LDS transpose (default: 128-133 us for the cfg-3 middle layer, 48 us for the
+      // first / last one) or straight from the accumulators with the MFMA operands swapped (NQA_MLP_PIPE_DIRECT=1: 134-161
+      // / 50 us at 244 registers) -- profiles/r5_mlp_fwd_kernel_trace.txt; the round-4 kernel: 149-161 / 60 us
+      static const bool via_lds = [] {
+        const char* v = std::getenv("NQA_MLP_PIPE_DIRECT");
+        return !(v != nullptr && v[0] == '1');
+      }();
+#define NQA_PIPE_LAUNCH(HH, ABL, DIRECT)                                                                          \
+  hipLaunchKernelGGL((radial_mlp_fwd_pipe_kernel<HH, ABL, DIRECT>), dim3(gb), dim3(256), 0, s, e, a, wf, (float)alpha0, \
+                     num_basis, out_features, e_done, o, ts, dbg)
+      if (dbg != 0 && via_lds) NQA_PIPE_LAUNCH(128, true, false);   // (timing ablations, radial_mlp_pipe.h)
+      else if (dbg != 0) NQA_PIPE_LAUNCH(128, true, true);
+      else if (via_lds) NQA_PIPE_LAUNCH(128, false, false);
+      else NQA_PIPE_LAUNCH(128, false, true);
+#undef NQA_PIPE_LAUNCH
+      return launch_status("nqa_radial_mlp_fwd");
+    }
+    {
+      const int64_t units = (int64_t)grid * ntiles;
+      const unsigned gb = (unsigned)(units < 2 * (int64_t)num_cus ? units : 2 * (int64_t)num_cus);
+      if (hidden == 128)
+        hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<128, true>), dim3(gb), dim3(256), 0, s, e, a, wf,
+                           (float)alpha0, num_basis, out_features, num_edges, o, ts);
+      else
+        hipLaunchKernelGGL((radial_mlp_fwd_split_bal_kernel<64, true>), dim3(gb), dim3(256), 0, s, e, a, wf,
+                           (float)alpha0, num_basis, out_features, num_edges, o, ts);
+    }
     return launch_status("nqa_radial_mlp_fwd");
   }
   if (mode == NQA_MLP_BF16X6) {
@@ -1721,6 +1755,37 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
   hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, TT, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,      \
                      (float)alpha0, num_basis, out_features, num_edges, o, 0, static_cast<const float*>(cotangent),  \
                      static_cast<float*>(hidden_out), static_cast<float*>(w0_partials), g2, ce)
+    // round 5: the inference backward over balanced work-unit ranges (radial_mlp_pipe.h) for gradients of complete
+    // 32-column chunks (NQA_MLP_PIPE=0: the general kernel, one workgroup per 128-row block)
+    static const bool pipe = [] {
+      const char* v = std::getenv("NQA_MLP_PIPE");
+      return v == nullptr || v[0] != '0';
+    }();
+    static const int num_cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    if (pipe && tm == 0 && g2 == nullptr && out_features % 32 == 0) {
+      const unsigned gb = (unsigned)((int64_t)grid < 2 * (int64_t)num_cus ? (int64_t)grid : 2 * (int64_t)num_cus);
+      if (hipMemsetAsync(o, 0, (size_t)num_edges * num_basis * sizeof(float), s) != hipSuccess) {
+        set_error("nqa_radial_mlp_bwd: hipMemsetAsync failed");
+        return NQA_ERR_LAUNCH;
+      }
+      static const int pf = [] {
+        const char* v = std::getenv("NQA_MLP_BWD_PF");
+        return v ? std::atoi(v) : 2;
+      }();
+#define NQA_BPIPE_LAUNCH(HH, PP, RR, AA)                                                                              \
+  hipLaunchKernelGGL((radial_mlp_bwd_pipe_kernel<HH, PP, RR, AA>), dim3(gb), dim3(256), 0, s, e, a, wb, g, (float)alpha0, \
+                     num_basis, out_features, num_edges, o, ce, dbg)
+      if (hidden == 64) NQA_BPIPE_LAUNCH(64, 2, true, false);
+      else if (dbg != 0) NQA_BPIPE_LAUNCH(128, 2, true, true);  // (timing ablations, radial_mlp_pipe.h)
+      else if (pf == 4) NQA_BPIPE_LAUNCH(128, 4, true, false);
+      else NQA_BPIPE_LAUNCH(128, 2, true, false);
+#undef NQA_BPIPE_LAUNCH
+      return launch_status("nqa_radial_mlp_bwd");
+    }
     if (hidden == 128) {
       if (g2 != nullptr) NQA_MLP_BWD_F16_LAUNCH(128, 0, true);
       else if (tm == 0) NQA_MLP_BWD_F16_LAUNCH(128, 0, false);

@@ -5,11 +5,15 @@ import torch
 from nequip_amd.nn.mlp import ScalarMLPFunction
 dev = torch.device("cuda:0")
 E = int(os.environ.get("E", 400558))
-for H, W in [(128, 704), (128, 192)]:
+SHAPES = [int(x) for x in os.environ.get("SHAPES", "704,192").split(",")]
+for H, W in [(128, w) for w in SHAPES]:
     mlp = ScalarMLPFunction(8, W, 1, H).to(dev).eval()
     emb = (torch.randn(E, 8, device=dev) * 0.5).requires_grad_(True)
     g = torch.randn(E, W, device=dev)
-    out = mlp(emb); torch.autograd.grad(out, emb, g)
+    FWD_ONLY = os.environ.get("FWD_ONLY", "") == "1"  # (ablation runs: the backward kernels read the same NQA_MLP_DBG bits)
+    out = mlp(emb)
+    if not FWD_ONLY:
+        torch.autograd.grad(out, emb, g)
     torch.cuda.synchronize()
     def timeit(fn, n=20):
         s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
@@ -18,6 +22,9 @@ for H, W in [(128, 704), (128, 192)]:
         e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
     with torch.no_grad():
         tf = timeit(lambda: mlp(emb))
+    if FWD_ONLY:
+        print(f"H={H} W={W}: fwd {tf*1e3:.0f} us", flush=True)
+        continue
     out = mlp(emb)
     tb = timeit(lambda: torch.autograd.grad(out, emb, g, retain_graph=True))
     fl = 2.0 * E * H * W

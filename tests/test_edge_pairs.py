@@ -246,4 +246,6 @@ def test_paired_mlp_backward_adds_the_two_streams(device, E, H, W):
     args = (emb, mod.mlp[0].weight.detach(), mod.mlp[2].weight.detach(), mod._alphas[0], mod._alphas[1])
     got = M._launch_bwd_paired(*args, ga, gb, M._lib.NQA_MLP_BF16X6, cache)
     ref = M._launch_bwd(*args, (ga + gb).contiguous(), M._lib.NQA_MLP_BF16X6, cache)
-    assert torch.equal(got, ref)
+    # (two different kernels since round 5 -- the single-stream form runs on the balanced launch of radial_mlp_pipe.h, whose
+    # partial sums and SiLU' evaluation are not bit-identical to the paired kernel's: equal at the fp32 rounding level)
+    torch.testing.assert_close(got, ref, rtol=0, atol=4e-6 * float(ref.abs().max()))
