@@ -1755,27 +1755,49 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
   hipLaunchKernelGGL((radial_mlp_bwd_split_kernel<HH, TT, PP, true>), dim3(grid), dim3(256), 0, s, e, a, wb, g,      \
                      (float)alpha0, num_basis, out_features, num_edges, o, 0, static_cast<const float*>(cotangent),  \
                      static_cast<float*>(hidden_out), static_cast<float*>(w0_partials), g2, ce)
-    // round 5: the inference backward over balanced work-unit ranges (radial_mlp_pipe.h) for gradients of complete
-    // 32-column chunks (NQA_MLP_PIPE=0: the general kernel, one workgroup per 128-row block)
+    // round 5 (radial_mlp_pipe.h): two more forms of the inference backward over balanced work-unit ranges, both OPT-IN:
+    //   NQA_MLP_BWD_COAL=1     radial_mlp_bwd_coal_kernel (widths that are multiples of 64): g_w in coalesced 256-byte row pieces
+    //                          through an LDS transpose -- alone 226-230 us for the cfg-3 middle layer against 240-244 us of the
+    //                          general kernel (94 / 96 us first / last layer; profiles/r5_mlp_bwd_kernel_trace.txt);
+    //   NQA_MLP_BWD_BALANCED=1 radial_mlp_bwd_pipe_kernel: lane-=-row loads like the general kernel, 235-243 us.
+    // Neither is the default: in the step the radial backward runs on a side stream NEXT TO the node / tensor-product kernels,
+    // and a persistent launch that holds two workgroups on every CU for its whole duration costs those more than it saves
+    // (same-box A/B of the whole step, profiles/r5_step_ab_mlp.txt: 2.37-2.39 ms with the general backward kernel, 2.48-2.49 ms
+    // with the coalesced persistent one, both with the new forward).
     static const bool pipe = [] {
       const char* v = std::getenv("NQA_MLP_PIPE");
       return v == nullptr || v[0] != '0';
+    }();
+    static const bool coal = [] {
+      const char* v = std::getenv("NQA_MLP_BWD_COAL");
+      return v != nullptr && v[0] == '1';
+    }();
+    static const bool balanced = [] {
+      const char* v = std::getenv("NQA_MLP_BWD_BALANCED");
+      return v != nullptr && v[0] == '1';
+    }();
+    static const int pf = [] {
+      const char* v = std::getenv("NQA_MLP_BWD_PF");
+      return v ? std::atoi(v) : 2;
     }();
     static const int num_cus = [] {
       int dev = 0, n = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
       return n;
     }();
-    if (pipe && tm == 0 && g2 == nullptr && out_features % 32 == 0) {
+    const bool use_coal = coal && hidden == 128 && out_features % 64 == 0 && dbg == 0;
+    const bool use_bal = (balanced || dbg != 0) && out_features % 32 == 0;
+    if (pipe && tm == 0 && g2 == nullptr && (use_coal || use_bal)) {
       const unsigned gb = (unsigned)((int64_t)grid < 2 * (int64_t)num_cus ? (int64_t)grid : 2 * (int64_t)num_cus);
       if (hipMemsetAsync(o, 0, (size_t)num_edges * num_basis * sizeof(float), s) != hipSuccess) {
         set_error("nqa_radial_mlp_bwd: hipMemsetAsync failed");
         return NQA_ERR_LAUNCH;
       }
-      static const int pf = [] {
-        const char* v = std::getenv("NQA_MLP_BWD_PF");
-        return v ? std::atoi(v) : 2;
-      }();
+      if (use_coal && !(balanced || dbg != 0)) {
+        hipLaunchKernelGGL((radial_mlp_bwd_coal_kernel<128>), dim3(gb), dim3(256), 0, s, e, a, wb, g, (float)alpha0,
+                           num_basis, out_features, num_edges, o, ce);
+        return launch_status("nqa_radial_mlp_bwd");
+      }
 #define NQA_BPIPE_LAUNCH(HH, PP, RR, AA)                                                                              \
   hipLaunchKernelGGL((radial_mlp_bwd_pipe_kernel<HH, PP, RR, AA>), dim3(gb), dim3(256), 0, s, e, a, wb, g, (float)alpha0, \
                      num_basis, out_features, num_edges, o, ce, dbg)

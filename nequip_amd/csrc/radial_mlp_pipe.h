@@ -660,4 +660,276 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_pipe_kernel(const float
   }
 }
 
+
+// ---- f16x3 inference backward, g_w read in COALESCED 256-byte row pieces --------------------------------------------------
+// What bounds radial_mlp_bwd_pipe_kernel (and the round-4 kernel) is how its A operand arrives: lane = row, i.e. every load
+// instruction of a wavefront touches 32 rows with 2 x 16 bytes each.  scripts/micro/strided_read.hip (profiles/
+// r3_node_measurements.txt) puts that pattern -- 128-byte row pieces, 32 rows per wavefront step -- at 2.3-2.7 TB/s whatever
+// is in flight (the kernels: 2.4-2.5 TB/s; deeper prefetch and two-chunk bursts changed nothing, profiles/r5_mlp_bwd_*),
+// against 4.2-5.5 TB/s for 256-byte pieces of a few rows per instruction.  Here a wavefront fetches its 32 rows x 64 columns
+// as eight instructions of FOUR rows x 256 contiguous bytes, passes them through a wave-private padded LDS tile (row stride 68
+// floats: both the 16-byte row-major writes and the fragment reads are conflict-free) and picks the A fragments up from
+// there.  Work units are (128-row block) x (64-column super-chunk); the weight fragments keep their 32-column chunks (one
+// workgroup barrier each).  Everything else -- running row exponent, split, epilogue, balanced ranges with float atomics
+// for shared blocks -- as radial_mlp_bwd_pipe_kernel.
+// Memory-queue order inside a super-chunk (vmcnt retires in order): the weight fragments of BOTH coming chunks are requested
+// first, then the eight row pieces of the next super-chunk -- so neither hand-over of fragments to LDS waits for HBM.
+// Preconditions (host): E > 0, W % 64 == 0, gridDim.x <= ceil(E / kMlpRows), g_emb zero-filled.
+template <int H>
+__global__ __launch_bounds__(256, 2) void radial_mlp_bwd_coal_kernel(const float* __restrict__ emb,
+                                                                     const float* __restrict__ W0,
+                                                                     const u32x4* __restrict__ Wb,
+                                                                     const float* __restrict__ gw, float a0, int nb,
+                                                                     int W, int64_t E, float* __restrict__ g_emb,
+                                                                     const int* __restrict__ chunk_exp) {
+  constexpr int NT = H / 32;
+  constexpr int CH = 2 * 2 * NT * 64;  // uint4 per 32-column chunk of B fragments (two k-steps x two planes)
+  constexpr int NV = CH / 256;
+  constexpr int GS = H + 1;
+  constexpr int kTS = 68;              // row stride of the transpose tile (floats)
+  constexpr int kTileFloats = 32 * kTS;
+  constexpr int kMainBytes = 2 * CH * 16 + 4 * kTileFloats * 4;
+  constexpr int kEpiBytes = kMlpRows * GS * 4;
+  constexpr int kBufBytes = kMainBytes > kEpiBytes ? kMainBytes : kEpiBytes;
+  __shared__ __align__(16) unsigned char smem_raw[kBufBytes];
+  __shared__ float w0s[H * kMaxNb];        // [k][c]
+  __shared__ float w0t[kMaxNb * H];        // [c][k]
+  __shared__ float es[kMlpRows * kMaxNb];  // embedding tile [row][c]
+  __shared__ int rowexp[kMlpRows];
+  u32x4* __restrict__ bsm = reinterpret_cast<u32x4*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  float* tile = reinterpret_cast<float*>(smem_raw + 2 * CH * 16) + wv * kTileFloats;  // this wavefront's transpose tile
+  const int nsc = W >> 6;  // 64-column super-chunks
+  const int64_t nblk = (E + kMlpRows - 1) / kMlpRows;
+  const int64_t U = nblk * nsc;
+  const int64_t u0 = U * (int64_t)blockIdx.x / gridDim.x;
+  const int64_t u1 = U * ((int64_t)blockIdx.x + 1) / gridDim.x;
+  if (u0 >= u1) return;  // (workgroup-uniform)
+
+  for (int i = tid; i < H * kMaxNb; i += 256) {
+    const int k = i / kMaxNb, c = i - k * kMaxNb;
+    const float v = c < nb ? W0[c * H + k] * a0 : 0.f;
+    w0s[i] = v;
+    w0t[c * H + k] = v;
+  }
+  constexpr int kUnset = 1 << 20;
+  // transpose tile: this lane writes the float4 (row 4 q + lane / 16, columns 4 (lane % 16) ..) of load q and reads, as row
+  // l31 of chunk hc, its 16 floats 32 hc + 16 half ..
+  float* tw = tile + (lane >> 4) * kTS + 4 * (lane & 15);  // + 4 q kTS
+  const float* tr = tile + l31 * kTS + 16 * half;          // + 32 hc + 8 s: the fragment order of Wb (k = 16 half + 8 s + t)
+
+  auto rows_from_lanes = [&](int value, int (&out)[16]) __attribute__((always_inline)) {
+    int* __restrict__ rb = rowexp + wv * 32;
+    if (half == 0) rb[l31] = value;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = rb[(r & 3) + 8 * (r >> 2) + 4 * half];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  int64_t u = u0;
+  while (u < u1) {
+    const int64_t blk = u / nsc;
+    const int s0 = (int)(u - blk * nsc);
+    const int n = (int)((u1 - u) < (int64_t)(nsc - s0) ? (u1 - u) : (int64_t)(nsc - s0));  // super-chunks of this segment
+    const int s1 = s0 + n;
+    u += n;
+    const int c1 = 2 * s1;  // one past the segment's last 32-column chunk
+    const int64_t blk0 = blk * kMlpRows;
+    const float* __restrict__ gbase = gw + blk0 * W;  // wave-uniform
+    const int rows_here = (int)(E - blk0 < (int64_t)kMlpRows ? E - blk0 : (int64_t)kMlpRows);
+    // lane parts (bytes) of the eight row pieces: row 32 wv + 4 q + lane / 16 (clamped into a ragged block), 16 bytes at
+    // 16 (lane % 16) of the super-chunk's 256
+    unsigned goff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int rl = wv * 32 + 4 * q + (lane >> 4);
+      goff[q] = ((unsigned)(rl < rows_here ? rl : rows_here - 1) * (unsigned)W + 4u * (unsigned)(lane & 15)) * 4u;
+    }
+
+    __syncthreads();  // the previous segment's epilogue is done with smem_raw / es (first segment: w0s / w0t are in place)
+    for (int i = tid; i < kMlpRows * kMaxNb; i += 256) {
+      const int r = i / kMaxNb, c = i - r * kMaxNb;
+      const float v = emb[(blk0 + (r < rows_here ? r : rows_here - 1)) * nb + (c < nb ? c : nb - 1)];
+      es[i] = (c < nb && r < rows_here) ? v : 0.f;
+    }
+
+    mlp_v4f raw[8];  // (native vector type: the HIP float4 struct array went through scratch memory here)
+    u32x4 pbA[NV], pbB[NV];
+    auto load_rows = [&](int sc, mlp_v4f (&dst)[8]) __attribute__((always_inline)) {
+      const int cc = sc < s1 ? sc : s1 - 1;  // past the segment: a valid super-chunk, never used
+      const char* __restrict__ src = reinterpret_cast<const char*>(gbase + 64 * cc);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const mlp_v4f*>(src + goff[q]);
+    };
+    auto load_b = [&](int ch, u32x4 (&pb)[NV]) __attribute__((always_inline)) {
+      const int cc = ch < c1 ? ch : c1 - 1;
+      const u32x4* __restrict__ src = Wb + (int64_t)cc * CH;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) pb[v] = src[tid + v * 256];
+    };
+    auto store_b = [&](int buf, const u32x4 (&pb)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) bsm[buf * CH + tid + v * 256] = pb[v];
+    };
+    load_b(2 * s0, pbA);
+    load_rows(s0, raw);
+    store_b(0, pbA);
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+    int S = kUnset;                   // exponent of this lane's row (unset while the row is all zero)
+
+    // one 32-column chunk: its 16 floats per lane come out of the transpose tile (k-steps 2 hc, 2 hc + 1 of the super-chunk)
+    auto body = [&](int ch, int first, auto hc_tag, mlp_v4f (&rows)[8], u32x4 (&pb0)[NV], u32x4 (&pb1)[NV])
+        __attribute__((always_inline)) {
+      constexpr int hc = decltype(hc_tag)::value;  // 0 / 1: first / second chunk of the super-chunk; LDS weight buffer = hc
+      float4 pa[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) pa[v] = *reinterpret_cast<const float4*>(tr + 32 * hc + 4 * v);
+      const int we = chunk_exp[ch];
+      float m = 0.f;  // the row's largest magnitude in this chunk (its other 16 values sit in lane ^ 32)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(pa[v].x), fabsf(pa[v].y)), fmaxf(fabsf(pa[v].z), fabsf(pa[v].w))));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      int shift = 0;
+      if (m > 0.f && m < 3.0e38f) {
+        int em;
+        (void)frexpf(m, &em);          // m < 2^em
+        const int cap = 15 - em + we;  // largest S that keeps m 2^(S - we) below 2^15
+        if (cap < S) {
+          int ns = cap - 3;
+          ns = ns > we + 100 ? we + 100 : (ns < we - 100 ? we - 100 : ns);
+          shift = S == kUnset ? 0 : S - ns;
+          S = ns;
+        }
+      }
+      if (!first && __any(shift > 0)) {  // (rare after the first chunks: a new maximum 8x above every earlier one)
+        int kr[16];
+        rows_from_lanes(shift, kr);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = ldexpf(acc[t][r], -kr[r]);
+      }
+      int q = S == kUnset ? 0 : S - we;
+      q = q > 120 ? 120 : (q < -120 ? -120 : q);
+      const float qs = ldexpf(1.f, q);
+      u32x4 ah[2], al[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t a, b;
+        split_pair_f16(pa[2 * s].x * qs, pa[2 * s].y * qs, a, b);
+        ah[s][0] = a; al[s][0] = b;
+        split_pair_f16(pa[2 * s].z * qs, pa[2 * s].w * qs, a, b);
+        ah[s][1] = a; al[s][1] = b;
+        split_pair_f16(pa[2 * s + 1].x * qs, pa[2 * s + 1].y * qs, a, b);
+        ah[s][2] = a; al[s][2] = b;
+        split_pair_f16(pa[2 * s + 1].z * qs, pa[2 * s + 1].w * qs, a, b);
+        ah[s][3] = a; al[s][3] = b;
+      }
+      if constexpr (hc == 0) {
+        // fragments of the two coming chunks, THEN the row pieces of the next super-chunk (see the header)
+        load_b(ch + 1, pb0);
+        load_b(ch + 2, pb1);
+        load_rows((ch >> 1) + 1, rows);
+      }
+      const u32x4* __restrict__ bs = bsm + hc * CH + lane;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4 fb[2][NT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) fb[p][t] = bs[((s * 2 + p) * NT + t) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(al[s], fb[0][t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(ah[s], fb[1][t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(ah[s], fb[0][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (hc == 0) store_b(1, pb0); else store_b(0, pb1);
+      lds_barrier();
+    };
+    for (int j = 0; j < n; ++j) {
+      // the super-chunk's rows: registers (requested one super-chunk ago) -> transpose tile
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<mlp_v4f*>(tw + 4 * q * kTS) = raw[q];
+      body(2 * (s0 + j), j == 0, std::integral_constant<int, 0>{}, raw, pbA, pbB);
+      body(2 * (s0 + j) + 1, 0, std::integral_constant<int, 1>{}, raw, pbA, pbB);
+    }
+
+    {  // accumulators back to the true scale: 2^-S of their row
+      int sr[16];
+      rows_from_lanes(S == kUnset ? 0 : S, sr);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = ldexpf(acc[t][r], -sr[r]);
+    }
+    // epilogue (exact fp32): as radial_mlp_bwd_pipe_kernel.  (every wavefront is past the last chunk's barrier: the weight
+    // buffers and the transpose tiles are free)
+    float* __restrict__ gp = reinterpret_cast<float*>(smem_raw);
+    {
+      const float* __restrict__ erow = es + (wv * 32 + l31) * kMaxNb;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x16 pacc = {0};
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+          const float av = erow[2 * s2 + half];
+          const float bv = w0t[(2 * s2 + half) * H + t * 32 + l31];
+          pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, pacc, 0, 0, 0);
+        }
+        const int col = t * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          gp[lr * GS + col] = acc[t][r] * silu_grad_fast_f(pacc[r]);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int r = tid >> 1, kh = tid & 1;
+      float sacc[kMaxNb];
+#pragma unroll
+      for (int c = 0; c < kMaxNb; ++c) sacc[c] = 0.f;
+      const float* __restrict__ gr = gp + r * GS + kh * (H / 2);
+      const float* __restrict__ wr = w0s + kh * (H / 2) * kMaxNb;
+#pragma unroll 4
+      for (int k = 0; k < H / 2; ++k) {
+        const float gv = gr[k];
+        const float4 w0 = *reinterpret_cast<const float4*>(wr + k * kMaxNb);
+        const float4 w1 = *reinterpret_cast<const float4*>(wr + k * kMaxNb + 4);
+        sacc[0] += gv * w0.x; sacc[1] += gv * w0.y; sacc[2] += gv * w0.z; sacc[3] += gv * w0.w;
+        sacc[4] += gv * w1.x; sacc[5] += gv * w1.y; sacc[6] += gv * w1.z; sacc[7] += gv * w1.w;
+      }
+#pragma unroll
+      for (int c = 0; c < kMaxNb; ++c) sacc[c] += __shfl_xor(sacc[c], 1, 64);
+      if (kh == 0 && r < rows_here) {
+        float* __restrict__ dst = g_emb + (blk0 + r) * nb;
+        if (n == nsc) {  // the whole block: plain stores (nobody else adds to these rows)
+          for (int c = 0; c < nb; ++c) dst[c] = sacc[c];
+        } else {
+          for (int c = 0; c < nb; ++c) unsafeAtomicAdd(dst + c, sacc[c]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace nqa
