@@ -733,7 +733,10 @@ def main():
                     step_eager()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            # NQA_BENCH_MAIN_PRIO=1 (experiment): capture on a high-priority stream, so that the side-stream branches (radial
+            # backward, self-connection) yield to the main chain wherever both have work
+            main = torch.cuda.Stream(priority=-1) if os.environ.get("NQA_BENCH_MAIN_PRIO", "") == "1" else None
+            with torch.cuda.graph(g, stream=main):
                 g_e, g_f = step_eager()
             g.replay()
             torch.cuda.synchronize()
