@@ -299,6 +299,13 @@ def _plan(model: torch.nn.Module) -> None:
                     and b.in_field == a.edge_invariant_field and b.out_field == b.in_field):
                 a.factor = float(a.factor) * float(b.factor)
                 b._folded = True
+        sph = [m for m in kids if isinstance(m, aemb.SphericalHarmonicEdgeAttrs)]
+        nrm = [m for m in kids if isinstance(m, aemb.EdgeLengthNormalizer)]
+        bes = [m for m in kids if isinstance(m, aemb.BesselEdgeLengthEncoding)]
+        if len(sph) == 1 and len(nrm) == 1 and len(bes) == 1 and kids.index(sph[0]) < kids.index(bes[0]):
+            from ..model.nequip_models import _plan_embedding_fusion
+
+            _plan_embedding_fusion(sph[0], nrm[0], bes[0])
         convs = [m for m in kids if isinstance(m, ann.ConvNetLayer)]
         if not convs:
             continue

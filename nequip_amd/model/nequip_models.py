@@ -195,6 +195,7 @@ def _full_nequip_energy_model(
                                                              out_field=AtomicDataDict.TOTAL_ENERGY_KEY))
 
     _plan_fusions(convnets, edge_norm, readout, scale_shift, readout_mlp_hidden_layers_depth)
+    _plan_embedding_fusion(chain.modules["spharm"], edge_norm, bessel)
     return ForceStressOutput(SequentialGraphNetwork(chain.modules), do_derivatives)
 
 
@@ -211,6 +212,14 @@ class _Chain:
         self.modules[name] = module
         self._irreps = module.irreps_out
         return module
+
+
+def _plan_embedding_fusion(spharm, edge_norm, bessel) -> None:
+    """Spherical harmonics and radial basis in ONE launch per direction (`nn/embedding/_edge.py`): only for a plain `r_max`
+    (per-edge-type cutoffs reach the radial kernel through `edge_norm`, which runs between the two modules).  A plain list
+    entry, no registration: module names, parameters and state-dict keys are untouched."""
+    if not edge_norm._per_edge_type and spharm._output_dtype == bessel._output_dtype:
+        spharm.__dict__["_fuse_radial"] = [bessel, edge_norm]
 
 
 def _plan_fusions(convnets, edge_norm, readout, scale_shift, readout_depth: int) -> None:

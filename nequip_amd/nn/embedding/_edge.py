@@ -11,6 +11,7 @@ pass over the edges; their vector-Jacobian product feeds the force backward.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -231,6 +232,10 @@ class BesselEdgeLengthEncoding(GraphModuleMixin, torch.nn.Module):
         data = with_edge_vectors_(data, with_lengths=False)
         vec = data[AtomicDataDict.EDGE_VECTORS_KEY]
         rmax_edge = data.get("_nqa_rmax_recip_edge")
+        pre = data.pop("_nqa_fused_edge_embedding", None)
+        if pre is not None and pre[1] is self and rmax_edge is None:  # evaluated with the spherical harmonics (see there)
+            data[self.edge_invariant_field] = pre[0]
+            return data
         if self.trainable and self.bessel_weights.requires_grad and torch.is_grad_enabled() and self.training:
             data[self.edge_invariant_field] = self._forward_differentiable_weights(data, vec, rmax_edge)
             return data
@@ -268,7 +273,23 @@ class SphericalHarmonicEdgeAttrs(GraphModuleMixin, torch.nn.Module):
 
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         data = with_edge_vectors_(data, with_lengths=False)
+        vec = data[AtomicDataDict.EDGE_VECTORS_KEY]
+        fused = self.__dict__.get("_fuse_radial")
+        if fused is not None and not traceable() and os.environ.get("NQA_NO_EMBED_FUSION", "") in ("", "0"):
+            # one launch for the spherical harmonics AND the radial basis of the Bessel module further down the chain (set by
+            # the model builder, `_plan_fusions`: plain r_max, constant roots), one launch for their joint backward -- the
+            # kernel evaluates both in one pass over the edges anyway; saves a launch each way and the add of the two edge-vector
+            # gradients.  The Bessel module picks its rows up from `data` (and evaluates itself if they are not there).
+            bessel = fused[0]
+            if (not (bessel.trainable and bessel.bessel_weights.requires_grad and torch.is_grad_enabled() and bessel.training)
+                    and bessel._output_dtype == self._output_dtype):
+                cfg = dict(dtype=self._output_dtype, lmax=self.lmax, want_sh=True, want_emb=True, nb=bessel.num_bessels,
+                           rmax_recip=1.0 / float(fused[1].r_max), p=float(bessel.cutoff.p), factor=float(bessel.factor))
+                sh, emb = _embed(vec, bessel.bessel_weights.detach().view(-1), cfg)
+                data[self.out_field] = sh
+                data["_nqa_fused_edge_embedding"] = (emb, bessel)
+                return data
         cfg = dict(dtype=self._output_dtype, lmax=self.lmax, want_sh=True, want_emb=False, nb=0, rmax_recip=1.0,
                    p=6.0, factor=1.0)
-        data[self.out_field] = _embed(data[AtomicDataDict.EDGE_VECTORS_KEY], self._dummy_bw, cfg)
+        data[self.out_field] = _embed(vec, self._dummy_bw, cfg)
         return data

@@ -142,7 +142,18 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         data[K.EDGE_VECTORS_KEY] = edge_vec
         data = self.func(data)
         with inputs_only_backward():
-            g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].to(torch.float64).contiguous()
+            pe = data.get(K.PER_ATOM_ENERGY_KEY)
+            if (pe is not None and pe.requires_grad and not tracing and pe.dim() == 2 and pe.shape[1] == 1
+                    and os.environ.get("NQA_NO_ENERGY_SEED", "") in ("", "0")):
+                # d(sum of the frames' total energies) / d(per-atom energy) = 1: seed the backward at the per-atom energies
+                # with a cached tensor of ones instead of letting autograd build it (sum -> fill -> expand -> copy: three
+                # launches of ~6 us each inside the graph; profiles/r5_timeline_*.txt)
+                ones = self.__dict__.get("_ones")
+                if ones is None or ones.shape != pe.shape or ones.device != pe.device or ones.dtype != pe.dtype:
+                    ones = self.__dict__["_ones"] = torch.ones_like(pe, requires_grad=False)
+                g = torch.autograd.grad([pe], [edge_vec], grad_outputs=[ones])[0].to(torch.float64).contiguous()
+            else:
+                g = torch.autograd.grad([data[K.TOTAL_ENERGY_KEY].sum()], [edge_vec])[0].to(torch.float64).contiguous()
         num_nodes = pos.shape[0]
         if tracing:
             from ._force_ops import force_virial
