@@ -1788,7 +1788,13 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
     const bool use_coal = coal && hidden == 128 && out_features % 64 == 0 && dbg == 0;
     const bool use_bal = (balanced || dbg != 0) && out_features % 32 == 0;
     if (pipe && tm == 0 && g2 == nullptr && (use_coal || use_bal)) {
-      const unsigned gb = (unsigned)((int64_t)grid < 2 * (int64_t)num_cus ? (int64_t)grid : 2 * (int64_t)num_cus);
+      static const int wgs_per_cu = [] {  // NQA_MLP_BWD_WGS_PER_CU=1: half the chip for the (side-stream) persistent launch
+        const char* v = std::getenv("NQA_MLP_BWD_WGS_PER_CU");
+        const int n = v ? std::atoi(v) : 2;
+        return n >= 1 && n <= 2 ? n : 2;
+      }();
+      const int64_t slots = (int64_t)wgs_per_cu * num_cus;
+      const unsigned gb = (unsigned)((int64_t)grid < slots ? (int64_t)grid : slots);
       if (hipMemsetAsync(o, 0, (size_t)num_edges * num_basis * sizeof(float), s) != hipSuccess) {
         set_error("nqa_radial_mlp_bwd: hipMemsetAsync failed");
         return NQA_ERR_LAUNCH;

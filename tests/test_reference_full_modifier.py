@@ -223,3 +223,57 @@ def test_full_modifier_leaves_other_modules_alone_and_reads_the_e3nn_layout(ref)
     model.model.func.add_module("extra", Extra())
     out = nequip_full.convert(model)
     assert type(out.model.func.extra) is Extra
+
+
+OTHER_SHAPES = {
+    # configs/tutorial.yaml's hyper-parameters (BASELINE cfg-1): parity irreps, four layers, radial MLP of depth 2 / width 64
+    "tutorial": dict(seed=5, model_dtype="float32", type_names=["C", "H", "O"], r_max=5.0, num_layers=4, l_max=1, parity=True,
+                     num_features=32, radial_mlp_depth=2, radial_mlp_width=64, avg_num_neighbors=13.0),
+    # per-edge-type cutoffs (asymmetric: the reverse-edge pairing must be off), per-type neighbour counts, norm nonlinearity,
+    # trainable Bessel roots, no self-connection, resnet update
+    "options": dict(seed=7, model_dtype="float32", type_names=["H", "O"], r_max=4.0, num_layers=3, l_max=2, parity=False,
+                    num_features=8, radial_mlp_width=16, avg_num_neighbors={"H": 11.0, "O": 23.0},
+                    per_edge_type_cutoff={"H": {"H": 3.0, "O": 3.5}, "O": 4.0}, convnet_nonlinearity_type="norm",
+                    bessel_trainable=True, convnet_sc=False, convnet_resnet=True,
+                    per_type_energy_shifts={"H": 0.5, "O": -0.25}),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(OTHER_SHAPES))
+def test_full_modifier_other_model_shapes(ref, monkeypatch, shape):
+    """The same check on the tutorial's hyper-parameters and on a model that uses the options outside the benchmarked
+    configs: the converted chain equals the natively built one module for module, with the reference's parameters."""
+    from nequip_amd.integrations import nequip_full
+    from nequip_amd.model import NequIPGNNModel
+
+    hyper = OTHER_SHAPES[shape]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = ref["model"].NequIPGNNModel(**hyper)
+        native = NequIPGNNModel(**hyper)
+    keys_before = list(model.state_dict().keys())
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.version, "hip", "7.0", raising=False)
+    nequip_full.register_full()
+    converted = ref["modify_utils"].modify(model, [{"modifier": nequip_full.FULL_MODIFIER_NAME}])
+    assert list(converted.state_dict().keys()) == keys_before
+    chain, nchain = converted.model.func, native.model.func
+    assert [n for n, _ in chain.named_children()] == [n for n, _ in nchain.named_children()]
+    for (name, a), (_, b) in zip(chain.named_children(), nchain.named_children()):
+        assert type(a) is type(b), name
+        assert {k: str(a.irreps_out[k]) for k in b.irreps_out} == {k: str(v) for k, v in b.irreps_out.items()}, name
+        if hasattr(b, "conv"):
+            assert a.defer_gate == b.defer_gate and a.resnet == b.resnet, name
+            assert type(a.equivariant_nonlin) is type(b.equivariant_nonlin), name
+            assert a.conv.use_sc == b.conv.use_sc and a.conv.paired_radial_ok == b.conv.paired_radial_ok, name
+            assert a.conv.edge_mlp.dims == b.conv.edge_mlp.dims, name
+            assert a.conv.tp_scatter.instructions == b.conv.tp_scatter.instructions, name
+            assert torch.equal(a.conv.avg_num_neighbors_norm.norm_const, b.conv.avg_num_neighbors_norm.norm_const), name
+    assert chain.edge_norm.symmetric == nchain.edge_norm.symmetric
+    assert torch.equal(chain.edge_norm._rmax_recip, nchain.edge_norm._rmax_recip)
+    assert chain.bessel_encode.trainable == nchain.bessel_encode.trainable
+    assert isinstance(chain.bessel_encode.bessel_weights, torch.nn.Parameter) == hyper.get("bessel_trainable", False)
+    assert ("_fuse_radial" in chain.spharm.__dict__) == ("_fuse_radial" in nchain.spharm.__dict__)
+    assert ("_scale_shift" in chain.per_atom_energy_readout.__dict__) == ("_scale_shift" in nchain.per_atom_energy_readout.__dict__)
+    missing, unexpected = native.load_state_dict(converted.state_dict(), strict=False)
+    assert not missing and all(k.endswith("_empty") for k in unexpected)
