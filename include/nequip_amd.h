@@ -256,6 +256,12 @@ int nqa_edge_embed_bwd_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, 
  * gradient rows by a running per-row exponent that is lowered, together with the row's accumulators, when a chunk
  * outgrows it.  The workspace of this mode differs from BF16X6's (nqa_radial_mlp_workspace_bytes). */
 #define NQA_MLP_F16X3 2
+/* OR-ed into `mode` of nqa_radial_mlp_bwd (ignored elsewhere): a scheduling hint, no effect on results beyond the order of
+ * fp32 roundings -- "nothing else will run on the device next to this launch".  The inference backward of a NARROW output
+ * (W <= 256) may then take the persistent form with all weight fragments resident in LDS (radial_mlp_pipe.h; enabled by
+ * NQA_MLP_BWD_SMALL=1, see radial_mlp.hip for the measurements); without the hint it keeps the many-short-workgroups form, which shares the chip better with concurrent streams (nequip_amd's host runs
+ * the radial backward of all layers but the first next to the main chain). */
+#define NQA_MLP_HINT_DEVICE_IS_IDLE 0x100
 int nqa_radial_mlp_supported(int32_t dtype, int32_t num_basis, int32_t hidden, int32_t out_features);
 int64_t nqa_radial_mlp_workspace_bytes(int32_t mode, int32_t backward, int32_t hidden, int32_t out_features);
 int nqa_radial_mlp_fwd(int32_t dtype, int32_t mode, const void* edge_embedding, const void* w0, double alpha0,

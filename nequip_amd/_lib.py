@@ -21,6 +21,7 @@ NQA_F64 = 1
 NQA_MLP_FP32 = 0  # radial MLP GEMM on exact-fp32 MFMA
 NQA_MLP_BF16X6 = 1  # ... on bf16 MFMA with 3-way split operands (fp32-accurate)
 NQA_MLP_F16X3 = 2  # forward: scaled operands split into two fp16 terms, three products (fp32-accurate)
+NQA_MLP_HINT_DEVICE_IS_IDLE = 0x100  # OR-ed into `mode` of nqa_radial_mlp_bwd: nothing runs next to this launch
 NQA_LAYOUT_MUL_IR = 0
 NQA_LAYOUT_IR_MUL = 1
 

@@ -1715,6 +1715,8 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
                         int32_t num_basis, int32_t hidden,
                         int32_t out_features, int64_t num_edges, void* grad_edge_embedding, void* workspace,
                         int64_t workspace_bytes, int32_t workspace_ready, nqa_stream stream) {
+  const bool device_idle = (mode & NQA_MLP_HINT_DEVICE_IS_IDLE) != 0;
+  mode &= ~NQA_MLP_HINT_DEVICE_IS_IDLE;
   int rc = check_mode(dtype, mode, "nqa_radial_mlp_bwd");
   if (rc != NQA_OK) return rc;
   rc = check_args(edge_embedding, w0, w1, num_basis, hidden, out_features, num_edges, "nqa_radial_mlp_bwd");
@@ -1785,6 +1787,35 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
       return n;
     }();
+    // narrow outputs (W <= 256: the first / last layer of the BASELINE models) when the caller says that the launch has the
+    // device to itself (NQA_MLP_HINT_DEVICE_IS_IDLE): all fragments resident in LDS, independent wavefronts, epilogue in
+    // registers (radial_mlp_bwd_small_kernel: alone 96 -> 76 us at cfg-3's W = 192, inside the step 87 -> 72 us for the
+    // first layer's launch -- and yet the step as a whole comes out 2 % SLOWER in four of four same-box repetitions, with
+    // the hint and without (profiles/r5_mlp_bwd_small.txt); opt-in: NQA_MLP_BWD_SMALL=1 with the hint, 2 always)
+    static const int small_mode = [] {  // NQA_MLP_BWD_SMALL: 0 never (default), 1 with the hint, 2 whenever the shape fits
+      const char* v = std::getenv("NQA_MLP_BWD_SMALL");
+      return v ? std::atoi(v) : 0;
+    }();
+    const bool small_ok = small_mode == 2 || (small_mode == 1 && device_idle);
+    if (pipe && small_ok && tm == 0 && g2 == nullptr && hidden == 128 && out_features % 32 == 0 && out_features <= 256 &&
+        dbg == 0) {
+      const size_t lds = (size_t)nchunks * (2 * 2 * (hidden / 32) * 64) * 16 + (size_t)(hidden / 32) * 16 * 2 * kMaxNb * 4 +
+                         (size_t)kMaxNb * hidden * 4 + (((size_t)nchunks * 4 + 15) & ~(size_t)15);
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&radial_mlp_bwd_small_kernel<128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) {
+          (void)hipGetLastError();
+        }
+        attr_set = true;
+      }
+      const int64_t nb32 = (num_edges + 31) / 32;
+      const int64_t want = (nb32 + 7) / 8;  // one 32-row block per wavefront at least
+      const unsigned gb = (unsigned)(want < (int64_t)num_cus ? want : (int64_t)num_cus);
+      hipLaunchKernelGGL((radial_mlp_bwd_small_kernel<128>), dim3(gb), dim3(512), lds, s, e, a, wb, g, (float)alpha0,
+                         num_basis, out_features, num_edges, o, ce);
+      return launch_status("nqa_radial_mlp_bwd");
+    }
     const bool use_coal = coal && hidden == 128 && out_features % 64 == 0 && dbg == 0;
     const bool use_bal = (balanced || dbg != 0) && out_features % 32 == 0;
     if (pipe && tm == 0 && g2 == nullptr && (use_coal || use_bal)) {

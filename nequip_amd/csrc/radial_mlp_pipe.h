@@ -932,4 +932,210 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_coal_kernel(const float
   }
 }
 
+
+// ---- f16x3 inference backward for NARROW outputs: all weight fragments resident in LDS -------------------------------------
+// For W <= 256 (the first / last layer of the BASELINE models: W = 192, six 32-column chunks) the general kernels spend their
+// time around the six chunks, not in them: with matrix instructions, weight staging and fragment reads all ablated the W = 192
+// launch still takes 95 of its 96 us (profiles/r5_mlp_bwd_small.txt) -- per 128-row block a pipeline restart (first rows from
+// HBM, first fragments from L2, two workgroup barriers), the embedding tile staged through LDS, and an epilogue that passes
+// g_pre through a 66 KB LDS tile with two more barriers.  Here
+//  * the launch is one 8-wavefront workgroup per CU that loads ALL fragments (W / 32 x 16 KiB) into LDS once; after that the
+//    wavefronts are independent -- no workgroup barrier, no staging -- and walk contiguous ranges of 32-row blocks with the row
+//    stream running two chunks ahead ACROSS block boundaries;
+//  * the two operands of the matrix instruction are swapped (same fragments): the accumulators come out as
+//    D[hidden][row] with lane = row, so the running exponent is the lane's own, the pre-activations are recomputed in the
+//    same layout, and g_emb[row][:] = sum_hidden g_pre[hidden][row] W0s[:][hidden] is a dot product over the lane's own 64
+//    registers (weights broadcast from a 4 KiB LDS table) + one exchange with lane ^ 32 -- no LDS tile, no barrier;
+//  * every row block is whole (all chunks): plain stores, no zero-fill, no atomics.
+// Preconditions (host): E > 0, W % 32 == 0, W / 32 * CH * 16 + 8.5 KiB of dynamic LDS granted, blockDim = 512.
+template <int H>
+__global__ __launch_bounds__(512, 2) void radial_mlp_bwd_small_kernel(const float* __restrict__ emb,
+                                                                      const float* __restrict__ W0,
+                                                                      const u32x4* __restrict__ Wb,
+                                                                      const float* __restrict__ gw, float a0, int nb,
+                                                                      int W, int64_t E, float* __restrict__ g_emb,
+                                                                      const int* __restrict__ chunk_exp) {
+  constexpr int NT = H / 32;
+  constexpr int CH = 2 * 2 * NT * 64;  // uint4 per chunk of fragments (two k-steps x two planes)
+  extern __shared__ __align__(16) unsigned char dyn_smem[];
+  const int nchunks = W >> 5;
+  u32x4* __restrict__ wsm = reinterpret_cast<u32x4*>(dyn_smem);                       // [nchunks][CH]
+  float* __restrict__ w0q = reinterpret_cast<float*>(dyn_smem + (size_t)nchunks * CH * 16);  // [NT][16][2][kMaxNb]
+  float* __restrict__ w0t = w0q + NT * 16 * 2 * kMaxNb;                                // [kMaxNb][H]
+  int* __restrict__ cexp = reinterpret_cast<int*>(w0t + kMaxNb * H);                   // [nchunks]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  for (int i = tid; i < nchunks * CH; i += 512) wsm[i] = Wb[i];
+  for (int i = tid; i < NT * 16 * 2 * kMaxNb; i += 512) {
+    const int c = i % kMaxNb, hf = (i / kMaxNb) & 1, r = (i / (2 * kMaxNb)) % 16, t = i / (32 * kMaxNb);
+    const int k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;  // hidden index of accumulator register r of tile t in lane-half hf
+    w0q[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
+  }
+  for (int i = tid; i < kMaxNb * H; i += 512) {
+    const int c = i / H, k = i - c * H;
+    w0t[i] = c < nb ? W0[c * H + k] * a0 : 0.f;
+  }
+  for (int i = tid; i < nchunks; i += 512) cexp[i] = chunk_exp[i];
+  __syncthreads();
+
+  // this wavefront's contiguous range of 32-row blocks
+  const int64_t NB = (E + 31) / 32;
+  const int64_t NW = (int64_t)gridDim.x * 8;
+  const int64_t gwv = (int64_t)blockIdx.x * 8 + wv;
+  const int64_t b0 = NB * gwv / NW, b1 = NB * (gwv + 1) / NW;
+  if (b0 >= b1) return;
+  const int64_t units = (b1 - b0) * nchunks;
+  constexpr int kUnset = 1 << 20;
+
+  // row stream: unit j = (block b0 + j / nchunks, chunk j % nchunks); this lane's 16 floats 32 ch + 16 half .. of its row
+  auto row_ptr = [&](int64_t blk) {
+    const int64_t row = blk * 32 + l31;
+    return gw + (row < E ? row : E - 1) * W + 16 * half;
+  };
+  auto load_a = [&](const float* __restrict__ rp, int ch, float4 (&pa)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) pa[v] = *reinterpret_cast<const float4*>(rp + 32 * ch + 4 * v);
+  };
+  float4 paA[4], paB[4];
+  // (position of the prefetch stream: two units ahead of the unit being consumed)
+  int64_t pblk = b0;
+  int pch = 0;
+  const float* prow = row_ptr(pblk);
+  auto advance = [&]() __attribute__((always_inline)) {
+    if (++pch == nchunks) {
+      pch = 0;
+      pblk = pblk + 1 < b1 ? pblk + 1 : pblk;  // past the range: the last block again (valid, never used)
+      prow = row_ptr(pblk);
+    }
+  };
+  load_a(prow, pch, paA);
+  advance();
+  load_a(prow, pch, paB);
+  advance();
+
+  f32x16 acc[NT];
+  int S = kUnset;
+  int64_t blk = b0;
+  int ch = 0;
+  float ev[kMaxNb];
+  auto load_ev = [&](int64_t b) __attribute__((always_inline)) {
+    const int64_t row = b * 32 + l31;
+    const float* __restrict__ er = emb + (row < E ? row : E - 1) * nb;
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) ev[c] = er[c < nb ? c : nb - 1];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) ev[c] = c < nb ? ev[c] : 0.f;
+  };
+
+  auto body = [&](float4 (&pa)[4]) __attribute__((always_inline)) {
+    if (ch == 0) {  // a new row block
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+      S = kUnset;
+      load_ev(blk);
+    }
+    const int we = cexp[ch];
+    float m = 0.f;  // the row's largest magnitude in this chunk (its other 16 values sit in lane ^ 32)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(pa[v].x), fabsf(pa[v].y)), fmaxf(fabsf(pa[v].z), fabsf(pa[v].w))));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    int shift = 0;
+    if (m > 0.f && m < 3.0e38f) {
+      int em;
+      (void)frexpf(m, &em);          // m < 2^em
+      const int cap = 15 - em + we;  // largest S that keeps m 2^(S - we) below 2^15
+      if (cap < S) {
+        int ns = cap - 3;
+        ns = ns > we + 100 ? we + 100 : (ns < we - 100 ? we - 100 : ns);
+        shift = S == kUnset ? 0 : S - ns;
+        S = ns;
+      }
+    }
+    if (ch > 0 && __any(shift > 0)) {  // (rare) the row is the lane's own: no exchange
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = ldexpf(acc[t][r], -shift);
+    }
+    int q = S == kUnset ? 0 : S - we;
+    q = q > 120 ? 120 : (q < -120 ? -120 : q);
+    const float qs = ldexpf(1.f, q);
+    u32x4 ah[2], al[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint32_t a, b;
+      split_pair_f16(pa[2 * s].x * qs, pa[2 * s].y * qs, a, b);
+      ah[s][0] = a; al[s][0] = b;
+      split_pair_f16(pa[2 * s].z * qs, pa[2 * s].w * qs, a, b);
+      ah[s][1] = a; al[s][1] = b;
+      split_pair_f16(pa[2 * s + 1].x * qs, pa[2 * s + 1].y * qs, a, b);
+      ah[s][2] = a; al[s][2] = b;
+      split_pair_f16(pa[2 * s + 1].z * qs, pa[2 * s + 1].w * qs, a, b);
+      ah[s][3] = a; al[s][3] = b;
+    }
+    load_a(prow, pch, pa);  // two units ahead (this register set is free again)
+    advance();
+    const u32x4* __restrict__ bs = wsm + (int64_t)ch * CH + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fb[2][NT];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[p][t] = bs[((s * 2 + p) * NT + t) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      // operands swapped: D[hidden][row], lane = row
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(fb[0][t], al[s], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(fb[1][t], ah[s], acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_f16(fb[0][t], ah[s], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++ch < nchunks) return;
+    // ---- the block is complete: epilogue in registers
+    ch = 0;
+    const float back = ldexpf(1.f, S == kUnset ? 0 : -S);  // accumulators back to the true scale (|S| <= ~130: finite)
+    float sacc[kMaxNb];
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) sacc[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 pacc = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < kMaxNb / 2; ++s2) {
+        const float av = w0t[(2 * s2 + half) * H + t * 32 + l31];
+        const float bv = half ? ev[2 * s2 + 1] : ev[2 * s2];
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, pacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float gp = acc[t][r] * back * silu_grad_fast_f(pacc[r]);
+        const float4 wa = *reinterpret_cast<const float4*>(w0q + ((t * 16 + r) * 2 + half) * kMaxNb);
+        const float4 wb = *reinterpret_cast<const float4*>(w0q + ((t * 16 + r) * 2 + half) * kMaxNb + 4);
+        sacc[0] += gp * wa.x; sacc[1] += gp * wa.y; sacc[2] += gp * wa.z; sacc[3] += gp * wa.w;
+        sacc[4] += gp * wb.x; sacc[5] += gp * wb.y; sacc[6] += gp * wb.z; sacc[7] += gp * wb.w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxNb; ++c) sacc[c] += __shfl_xor(sacc[c], 32, 64);
+    const int64_t row = blk * 32 + l31;
+    if (half == 0 && row < E) {
+      float* __restrict__ dst = g_emb + row * nb;
+      for (int c = 0; c < nb; ++c) dst[c] = sacc[c];
+    }
+    ++blk;
+  };
+  for (int64_t j = 0; j < units; j += 2) {
+    body(paA);
+    if (j + 1 < units) body(paB);
+  }
+}
+
 }  // namespace nqa

@@ -123,7 +123,9 @@ class _PairedRadialTPFn(torch.autograd.Function):
                 q.stream.wait_stream(cur)  # grad_w is complete
                 with torch.cuda.stream(q.stream):
                     if folded:
-                        part = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache)
+                        # the first layer's backward is the last launch of the queue: the main chain is waiting for it, so
+                        # it has the device to itself (the other layers' launches run next to the main chain)
+                        part = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache, device_idle=q.layers <= 0)
                     else:
                         part = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
                     q.acc = part if q.acc is None else q.acc.add_(part)

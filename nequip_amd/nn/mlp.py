@@ -88,8 +88,9 @@ def _launch_fwd(emb, w0, w1, alpha0: float, alpha1: float, mode: int, cache: _We
     return out
 
 
-def _launch_bwd(emb, w0, w1, alpha0: float, alpha1: float, g_w, mode: int, cache: _WeightImages):
-    """Gradient of the fused MLP w.r.t. the edge embedding (``nqa_radial_mlp_bwd``; hidden layer recomputed on chip)."""
+def _launch_bwd(emb, w0, w1, alpha0: float, alpha1: float, g_w, mode: int, cache: _WeightImages, device_idle: bool = False):
+    """Gradient of the fused MLP w.r.t. the edge embedding (``nqa_radial_mlp_bwd``; hidden layer recomputed on chip).
+    ``device_idle``: the launch has the device to itself (``NQA_MLP_HINT_DEVICE_IS_IDLE``, include/nequip_amd.h)."""
     from ._topology import _ptr, current_stream_ptr
 
     lib = _lib.load()
@@ -101,8 +102,9 @@ def _launch_bwd(emb, w0, w1, alpha0: float, alpha1: float, g_w, mode: int, cache
     ws_bytes = lib.nqa_radial_mlp_workspace_bytes(mode, 1, H, W)
     ws, ready = cache.get(w1, mode, 1, ws_bytes, E)
     with torch.cuda.device(emb.device), ktimer.region("radial_mlp_bwd", 4.0 * E * (2 * nb + W), flops):
-        rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, mode, _ptr(emb), _ptr(w0), alpha0, _ptr(w1), alpha1, _ptr(g_w), nb, H,
-                                    W, E, _ptr(g_emb), _ptr(ws), ws_bytes, int(ready), current_stream_ptr(emb.device))
+        rc = lib.nqa_radial_mlp_bwd(_lib.NQA_F32, mode | (_lib.NQA_MLP_HINT_DEVICE_IS_IDLE if device_idle else 0), _ptr(emb),
+                                    _ptr(w0), alpha0, _ptr(w1), alpha1, _ptr(g_w), nb, H, W, E, _ptr(g_emb), _ptr(ws), ws_bytes,
+                                    int(ready), current_stream_ptr(emb.device))
     _lib.check(rc, "nqa_radial_mlp_bwd")
     return g_emb
 
