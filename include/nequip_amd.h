@@ -218,6 +218,22 @@ int nqa_edge_embed_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int6
                        double rmax_recip, const double* rmax_recip_edge, int32_t num_bessels,
                        const double* bessel_weights, double cutoff_p, double factor, const void* g_sh,
                        const void* g_emb, double* g_edge_vec, nqa_stream stream);
+/* The same two kernels for an edge list with a reverse-edge pairing (nqa_edge_pairs: pair_row[e] < num_pairs for the
+ * representative edge of a pair, its row in the per-pair arrays; >= num_pairs for the reverse edge): the radial rows are
+ * ALSO written per pair, emb_pairs [P, num_bessels] = emb[rep_edge[p]] (what the radial MLP consumes when it is evaluated
+ * once per pair -- the gather nqa_pair_gather would do), and the backward takes the per-pair cotangent g_emb_pairs [P,
+ * num_bessels] directly (the adjoint nqa_pair_expand would do) next to / instead of the per-edge one; emb, g_sh, g_emb,
+ * g_emb_pairs may be NULL.  Plain r_max only (no per-edge cutoffs: those lists are not paired).  Replaces, for a paired
+ * list, `edge_embedding[rep]` / its autograd adjoint of nequip_amd's own host (nn/_paired_radial.py); the reference
+ * evaluates edge_mlp per directed edge (nequip/nn/interaction_block.py:190-199). */
+int nqa_edge_embed_fwd_paired(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges,
+                              double rmax_recip, int32_t num_bessels, const double* bessel_weights, double cutoff_p,
+                              double factor, const int32_t* pair_row, int64_t num_pairs, void* sh, void* emb,
+                              void* emb_pairs, nqa_stream stream);
+int nqa_edge_embed_bwd_paired(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges,
+                              double rmax_recip, int32_t num_bessels, const double* bessel_weights, double cutoff_p,
+                              double factor, const int32_t* pair_row, int64_t num_pairs, const void* g_sh,
+                              const void* g_emb, const void* g_emb_pairs, double* g_edge_vec, nqa_stream stream);
 /* Second order (force-matching training, nequip/nn/grad_output.py:220 create_graph=True): for the cotangent
  * cot_g_edge_vec [E,3] of the VJP output above, gg_sh / gg_emb = J(v) c (gradients w.r.t. g_sh / g_emb) and
  * g_edge_vec2 = (sum_k g_k Hessian_k(v)) c (gradient w.r.t. the edge vector).  Evaluated with forward-mode dual

@@ -178,6 +178,16 @@ SIGNATURES = {
         [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]
         + [c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "nqa_edge_embed_fwd_paired": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_int64, c_double, c_int32, c_void_p, c_double, c_double, c_void_p, c_int64]
+        + [c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "nqa_edge_embed_bwd_paired": (
+        c_int32,
+        [c_int32, c_int32, c_void_p, c_int64, c_double, c_int32, c_void_p, c_double, c_double, c_void_p, c_int64]
+        + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "nqa_edge_embed_bwd_bwd": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_int64, c_double, c_void_p, c_int32, c_void_p, c_double, c_double]

@@ -83,6 +83,12 @@ struct EdgeEmbedParams {
   double factor;
   int32_t nb;
   int32_t p_int;  // p as integer if integral, else -1
+  // paired radial rows (nqa_edge_embed_*_paired): pair_row[e] < P for the representative edge of a pair (its row in the per-pair
+  // arrays), >= P for the reverse edge.  emb_pairs [P, nb] / its cotangent are the per-pair forms of the radial embedding.
+  const int32_t* __restrict__ pair_row;
+  void* emb_pairs;
+  const void* g_emb_pairs;
+  int32_t P;
 };
 
 template <typename S>
@@ -214,18 +220,23 @@ __device__ __forceinline__ void embed_vjp(const EdgeEmbedParams& prm, int64_t e,
       gz = G[2] * gm.inv;
     }
   }
-  if (g_emb != nullptr) {
+  int32_t prow = 0;
+  const bool from_pairs = prm.g_emb_pairs != nullptr && (prow = prm.pair_row[e]) < prm.P;
+  if (g_emb != nullptr || from_pairs) {
     const double rr = prm.rr_edge ? prm.rr_edge[e] : prm.rr;
     const S x = gm.r * rr;
     const S c = poly_cutoff(x, prm.p, prm.p_int);
     const S dc = poly_cutoff_grad(x, prm.p, prm.p_int);
-    const T* __restrict__ gi = g_emb + e * prm.nb;
+    const T* __restrict__ gi = g_emb != nullptr ? g_emb + e * prm.nb : nullptr;
+    const T* __restrict__ gp = from_pairs ? static_cast<const T*>(prm.g_emb_pairs) + (int64_t)prow * prm.nb : nullptr;
     S acc = S(0.0);
     BesselBasis<S> bb(prm, x);
     for (int n = 0; n < prm.nb; ++n) {
       const double w = prm.bw[n];
       bb.step(x, w);
-      acc += (double)gi[n] * (bb.grad(w) * c + bb.value(w) * dc);
+      // (cotangent of the per-edge rows + cotangent of the per-pair row this edge represents)
+      const double gn = (gi != nullptr ? (double)gi[n] : 0.0) + (gp != nullptr ? (double)gp[n] : 0.0);
+      acc += gn * (bb.grad(w) * c + bb.value(w) * dc);
     }
     const S gr = acc * (prm.factor * rr);  // dE/dr ; d|v|/dv = u
     gx += gr * gm.ux;
@@ -251,20 +262,25 @@ __global__ __launch_bounds__(256) void edge_embed_fwd_kernel(const EdgeEmbedPara
 #pragma unroll
     for (int s = 0; s < NS; ++s) o[s] = (T)Y[s];
   }
-  if (emb != nullptr || cutoff != nullptr) {
+  if (emb != nullptr || cutoff != nullptr || prm.emb_pairs != nullptr) {
     const double rr = prm.rr_edge ? prm.rr_edge[e] : prm.rr;
     const double x = gm.r * rr;
     const T c = (T)poly_cutoff<double>(x, prm.p, prm.p_int);
     if (cutoff != nullptr) cutoff[e] = c;
-    if (emb != nullptr) {
+    int32_t prow = 0;
+    const bool to_pairs = prm.emb_pairs != nullptr && (prow = prm.pair_row[e]) < prm.P;
+    if (emb != nullptr || to_pairs) {
       const T f = (T)prm.factor;
-      T* __restrict__ o = emb + e * prm.nb;
+      T* __restrict__ o = emb != nullptr ? emb + e * prm.nb : nullptr;
+      T* __restrict__ op = to_pairs ? static_cast<T*>(prm.emb_pairs) + (int64_t)prow * prm.nb : nullptr;
       BesselBasis<double> bb(prm, x);
       for (int n = 0; n < prm.nb; ++n) {
         const double w = prm.bw[n];
         bb.step(x, w);
         const T b = (T)bb.value(w);
-        o[n] = f * (b * c);  // same rounding order as the reference: factor * (bessel.to(T) * cutoff.to(T))
+        const T v = f * (b * c);  // same rounding order as the reference: factor * (bessel.to(T) * cutoff.to(T))
+        if (o != nullptr) o[n] = v;
+        if (op != nullptr) op[n] = v;
       }
     }
   }
@@ -460,6 +476,55 @@ int nqa_edge_embed_bwd(int32_t dtype, int32_t lmax, const double* edge_vec, int6
   int rc = make_params(prm, edge_vec, num_edges, rmax_recip, rmax_recip_edge, num_bessels, bessel_weights, cutoff_p,
                        factor, g_emb != nullptr, "nqa_edge_embed_bwd");
   if (rc != NQA_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == NQA_F32 ? launch_bwd<float>(lmax, prm, g_sh, g_emb, g_edge_vec, s)
+                          : launch_bwd<double>(lmax, prm, g_sh, g_emb, g_edge_vec, s);
+}
+
+int nqa_edge_embed_fwd_paired(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges, double rmax_recip,
+                              int32_t num_bessels, const double* bessel_weights, double cutoff_p, double factor,
+                              const int32_t* pair_row, int64_t num_pairs, void* sh, void* emb, void* emb_pairs,
+                              nqa_stream stream) {
+  if (dtype != NQA_F32 && dtype != NQA_F64) {
+    set_error("nqa_edge_embed_fwd_paired: unsupported dtype");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (lmax < 0 || num_pairs < 0 || num_pairs > 0x7fffffff || (num_edges > 0 && (pair_row == nullptr || emb_pairs == nullptr))) {
+    set_error("nqa_edge_embed_fwd_paired: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  EdgeEmbedParams prm{};
+  int rc = make_params(prm, edge_vec, num_edges, rmax_recip, nullptr, num_bessels, bessel_weights, cutoff_p, factor, true,
+                       "nqa_edge_embed_fwd_paired");
+  if (rc != NQA_OK) return rc;
+  prm.pair_row = pair_row;
+  prm.emb_pairs = emb_pairs;
+  prm.P = (int32_t)num_pairs;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == NQA_F32 ? launch_fwd<float>(lmax, prm, sh, emb, nullptr, s)
+                          : launch_fwd<double>(lmax, prm, sh, emb, nullptr, s);
+}
+
+int nqa_edge_embed_bwd_paired(int32_t dtype, int32_t lmax, const double* edge_vec, int64_t num_edges, double rmax_recip,
+                              int32_t num_bessels, const double* bessel_weights, double cutoff_p, double factor,
+                              const int32_t* pair_row, int64_t num_pairs, const void* g_sh, const void* g_emb,
+                              const void* g_emb_pairs, double* g_edge_vec, nqa_stream stream) {
+  if (dtype != NQA_F32 && dtype != NQA_F64) {
+    set_error("nqa_edge_embed_bwd_paired: unsupported dtype");
+    return NQA_ERR_UNSUPPORTED;
+  }
+  if (lmax < 0 || num_pairs < 0 || num_pairs > 0x7fffffff || (num_edges > 0 && g_edge_vec == nullptr) ||
+      (g_emb_pairs != nullptr && pair_row == nullptr)) {
+    set_error("nqa_edge_embed_bwd_paired: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  EdgeEmbedParams prm{};
+  int rc = make_params(prm, edge_vec, num_edges, rmax_recip, nullptr, num_bessels, bessel_weights, cutoff_p, factor,
+                       g_emb != nullptr || g_emb_pairs != nullptr, "nqa_edge_embed_bwd_paired");
+  if (rc != NQA_OK) return rc;
+  prm.pair_row = pair_row;
+  prm.g_emb_pairs = g_emb_pairs;
+  prm.P = (int32_t)num_pairs;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == NQA_F32 ? launch_bwd<float>(lmax, prm, g_sh, g_emb, g_edge_vec, s)
                           : launch_bwd<double>(lmax, prm, g_sh, g_emb, g_edge_vec, s);

@@ -123,6 +123,13 @@ class EdgeTopology:
             done.record(torch.cuda.current_stream(dev))
         self._pairing_pending = (key, rows, rep, partner, verdict, done, ok)
 
+    def pairing_if_known(self, shifts: Optional[torch.Tensor]):
+        """``pairing(shifts)`` when its verdict has been read already (no wait, no launch), else ``None``."""
+        cached = getattr(self, "_pairing", None)
+        if cached is not None and cached[0] == self._shift_key(shifts):
+            return cached[1]
+        return None
+
     def pairing(self, shifts: Optional[torch.Tensor]):
         """Reverse-edge pairing of this list (``nqa_edge_pairs``): ``None`` when some edge has no unique reverse
         partner, else an ``EdgePairing`` with the weight rows in the slot order of both CSRs.  Computed once per

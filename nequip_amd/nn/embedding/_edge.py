@@ -147,6 +147,57 @@ def cutoff_partialdict_to_tensor(partial_dict: Dict, type_names: List[str], r_ma
     return table
 
 
+class _EdgeEmbedPairedFn(torch.autograd.Function):
+    """``edge_vec [E, 3] -> (sh [E, S], emb [E, nb], emb_pairs [P, nb])`` in one launch for a list with a reverse-edge pairing
+    (``nqa_edge_embed_fwd_paired``): the per-pair rows are what ``pair_rows(emb, pairing)`` would gather, and the backward
+    takes their cotangent as it comes out of the radial MLP's backward (``nqa_edge_embed_bwd_paired``) -- no ``pair_gather`` /
+    ``pair_expand`` launches.  First order (eval mode)."""
+
+    @staticmethod
+    def forward(ctx, edge_vec, bessel_weights, cfg, pairing):
+        if not edge_vec.is_cuda:
+            raise RuntimeError("nequip_amd edge embedding runs on the GPU only (HIP kernel); no CPU fallback exists")
+        assert edge_vec.dtype == torch.float64, "edge vectors must be float64 (nequip _GLOBAL_DTYPE)"
+        lib = _lib.load()
+        vec = edge_vec.contiguous()
+        E, P = vec.shape[0], pairing.num_pairs
+        out_dtype, lmax, nb = cfg["dtype"], cfg["lmax"], cfg["nb"]
+        sh = torch.empty((E, (lmax + 1) ** 2), dtype=out_dtype, device=vec.device)
+        emb = torch.empty((E, nb), dtype=out_dtype, device=vec.device)
+        emb_pairs = torch.empty((P, nb), dtype=out_dtype, device=vec.device)
+        nbytes = E * (24 + out_dtype.itemsize * ((lmax + 1) ** 2 + nb)) + P * nb * out_dtype.itemsize
+        with torch.cuda.device(vec.device), ktimer.region("edge_embed_fwd", nbytes):
+            rc = lib.nqa_edge_embed_fwd_paired(
+                _dt(out_dtype), lmax, _ptr(vec), E, cfg["rmax_recip"], nb, _ptr(bessel_weights), cfg["p"], cfg["factor"],
+                _ptr(pairing.rows), P, _ptr(sh), _ptr(emb), _ptr(emb_pairs), current_stream_ptr(vec.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_edge_embed_fwd_paired")
+        ctx.save_for_backward(vec, bessel_weights)
+        ctx.cfg, ctx.pairing = cfg, pairing
+        return sh, emb, emb_pairs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sh, g_emb, g_pairs):
+        vec, bw = ctx.saved_tensors
+        cfg, pairing = ctx.cfg, ctx.pairing
+        lib = _lib.load()
+        g_sh = g_sh.contiguous() if g_sh is not None else None
+        g_emb = g_emb.contiguous() if g_emb is not None else None
+        g_pairs = g_pairs.contiguous() if g_pairs is not None else None
+        E = vec.shape[0]
+        g_vec = torch.empty((E, 3), dtype=torch.float64, device=vec.device)
+        nbytes = E * (48 + cfg["dtype"].itemsize * ((cfg["lmax"] + 1) ** 2)) + pairing.num_pairs * cfg["nb"] * cfg["dtype"].itemsize
+        with torch.cuda.device(vec.device), ktimer.region("edge_embed_bwd", nbytes):
+            rc = lib.nqa_edge_embed_bwd_paired(
+                _dt(cfg["dtype"]), cfg["lmax"], _ptr(vec), E, cfg["rmax_recip"], cfg["nb"], _ptr(bw), cfg["p"],
+                cfg["factor"], _ptr(pairing.rows), pairing.num_pairs, _ptr(g_sh), _ptr(g_emb), _ptr(g_pairs), _ptr(g_vec),
+                current_stream_ptr(vec.device),
+            )  # fmt: skip
+        _lib.check(rc, "nqa_edge_embed_bwd_paired")
+        return g_vec, None, None, None
+
+
 class EdgeLengthNormalizer(GraphModuleMixin, torch.nn.Module):
     """Holds ``1/r_max`` -- one number, or one per (centre type, neighbour type) with ``per_edge_type_cutoff``
     (``nequip/nn/embedding/_edge.py:19-80``); the product ``r * (1/r_max)`` itself is formed inside the fused radial kernel,
@@ -271,6 +322,24 @@ class SphericalHarmonicEdgeAttrs(GraphModuleMixin, torch.nn.Module):
         self._output_dtype = torch.get_default_dtype()
         self.register_buffer("_dummy_bw", torch.ones(1, dtype=_GLOBAL_DTYPE), persistent=False)
 
+    @staticmethod
+    def _known_pairing(data, vec):
+        """The reverse-edge pairing of this evaluation's edge list IF it is known without waiting (a cached topology whose
+        verdict has been read: a static list, or any list once the first convolution asked) -- float32 eval evaluations
+        differentiated w.r.t. positions only, as `GraphModel._start_pairing`."""
+        K = AtomicDataDict
+        if (vec.dtype != torch.float64 or K.POSITIONS_KEY not in data
+                or os.environ.get("NQA_NO_PAIRED_EMBED", "") not in ("", "0")
+                or os.environ.get("NQA_NO_PAIRED", "") not in ("", "0")):
+            return None
+        ei = data.get(K.EDGE_INDEX_KEY)
+        if ei is None or not ei.is_cuda:
+            return None
+        from .._topology import topology_cache
+
+        topo = topology_cache.get(ei[0], ei[1], data[K.POSITIONS_KEY].shape[0])
+        return topo.pairing_if_known(data.get(K.EDGE_CELL_SHIFT_KEY))
+
     def forward(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         data = with_edge_vectors_(data, with_lengths=False)
         vec = data[AtomicDataDict.EDGE_VECTORS_KEY]
@@ -285,7 +354,15 @@ class SphericalHarmonicEdgeAttrs(GraphModuleMixin, torch.nn.Module):
                     and bessel._output_dtype == self._output_dtype):
                 cfg = dict(dtype=self._output_dtype, lmax=self.lmax, want_sh=True, want_emb=True, nb=bessel.num_bessels,
                            rmax_recip=1.0 / float(fused[1].r_max), p=float(bessel.cutoff.p), factor=float(bessel.factor))
-                sh, emb = _embed(vec, bessel.bessel_weights.detach().view(-1), cfg)
+                pairing = None
+                if not self.training and self._output_dtype == torch.float32:  # (first order only: eval mode)
+                    pairing = self._known_pairing(data, vec)
+                if pairing is not None:
+                    # the list pairs up (verdict already on the host): the per-pair radial rows come out of the same launch
+                    sh, emb, emb_pairs = _EdgeEmbedPairedFn.apply(vec, bessel.bessel_weights.detach().view(-1), cfg, pairing)
+                    data["_nqa_edge_embedding_pairs"] = emb_pairs
+                else:
+                    sh, emb = _embed(vec, bessel.bessel_weights.detach().view(-1), cfg)
                 data[self.out_field] = sh
                 data["_nqa_fused_edge_embedding"] = (emb, bessel)
                 return data

@@ -249,3 +249,42 @@ def test_paired_mlp_backward_adds_the_two_streams(device, E, H, W):
     # (two different kernels since round 5 -- the single-stream form runs on the balanced launch of radial_mlp_pipe.h, whose
     # partial sums and SiLU' evaluation are not bit-identical to the paired kernel's: equal at the fp32 rounding level)
     torch.testing.assert_close(got, ref, rtol=0, atol=4e-6 * float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("system", ["water", "si_small_cell"])
+def test_paired_edge_embedding_launch_matches_gather_and_expand(device, system):
+    """`nqa_edge_embed_fwd_paired / _bwd_paired` (round 5): the per-pair radial rows of the joint embedding launch are
+    bitwise `emb[rep_edge]`, and its backward with a per-pair cotangent is bitwise the per-edge backward of the expanded
+    cotangent (what `pair_gather` / `pair_expand` + the plain launches computed)."""
+    from nequip_amd.nn.embedding import _edge
+    from nequip_amd.nn._paired_radial import _PairExpandFn
+    from nequip_amd.utils import synthetic as syn
+
+    if system == "water":
+        pos, types, cell, names = syn.water_box(n_side=3, seed=4)
+    else:
+        pos, types, cell, names = syn.silicon_box(reps=1, seed=5)
+    data = syn.make_data(pos, types, 4.5, cell)
+    topo, pr = _pairing_of(data, device)
+    assert pr is not None
+    ei = data["edge_index"]
+    vec = (data["pos"][ei[1]] - data["pos"][ei[0]] + data["edge_cell_shift"].to(torch.float64) @ data["cell"].view(3, 3)).to(device)
+    vec = vec.to(torch.float64).contiguous().requires_grad_(True)
+    bw = torch.linspace(1.0, 8.0, 8, dtype=torch.float64, device=device)
+    cfg = dict(dtype=torch.float32, lmax=2, want_sh=True, want_emb=True, nb=8, rmax_recip=1.0 / 4.5, p=6.0, factor=0.31)
+    sh, emb, emb_pairs = _edge._EdgeEmbedPairedFn.apply(vec, bw, cfg, pr)
+    sh0, emb0 = _edge._EdgeEmbedFn.apply(vec, bw, cfg)
+    assert torch.equal(sh, sh0) and torch.equal(emb, emb0)
+    assert torch.equal(emb_pairs, emb0[pr.rep_edge])
+    g_sh = torch.randn_like(sh)
+    g_pairs = torch.randn_like(emb_pairs)
+    g_emb = torch.randn_like(emb)
+    (gv,) = torch.autograd.grad([sh, emb, emb_pairs], [vec], [g_sh, g_emb, g_pairs], retain_graph=True)
+    expanded = _PairExpandFn.apply(g_pairs, pr, vec.shape[0])
+    (gv0,) = torch.autograd.grad([sh0, emb0], [vec], [g_sh, g_emb + expanded], retain_graph=True)
+    # (the kernel adds the two float32 cotangents in float64, `g_emb + expanded` above rounds their sum to float32 first)
+    torch.testing.assert_close(gv, gv0, rtol=0, atol=2e-6 * float(gv0.abs().max()))
+    (gv_p,) = torch.autograd.grad([emb_pairs], [vec], [g_pairs], retain_graph=True)  # only the per-pair cotangent
+    (gv_p0,) = torch.autograd.grad([emb0], [vec], [expanded])
+    assert torch.equal(gv_p, gv_p0)
