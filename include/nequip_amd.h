@@ -485,8 +485,10 @@ int nqa_energy_head(int32_t backward, const void* h, const void* readout_weight,
  *     partner_edge[e] = the reverse edge of e;
  *     *ok (device int32) = 1 iff every edge has exactly one reverse partner (else the arrays are not to be used).
  *   edge_cell_shift: [E, 3] float32 / float64 (shift_dtype) integer-valued, or NULL.  (rowptr_dst, edge_id_dst, src_sorted):
- *   the dst-CSR of the same list (nqa_csr_build) -- the reverse of (i <- j, S) is looked up in row j, one thread per edge,
- *   no sort; pairs are numbered in the edge order of their representative.
+ *   the dst-CSR of the same list (nqa_csr_build) -- the reverse of (i <- j, S) is looked up in row j, eight lanes per edge,
+ *   no sort; pairs are numbered in the edge order of their representative.  For nqa_edge_pairs edge_id_dst may be NULL: the
+ *   dst-CSR then lists the edges in edge order (edge_id[k] == k: a list grouped by centre atom, as the device neighbour list
+ *   emits it), one dependent load less per look-up.
  * nqa_csr_from_pairs: the by-SOURCE CSR of a paired list without sorting -- row j holds the partners of the edges of row j
  *   of the dst-CSR: rowptr_src = rowptr_dst, edge_id_src[k] = partner_edge[edge_id_dst[k]], dst_sorted = src_sorted.
  * nqa_tp_scatter_{fwd,bwd_edge,bwd_x,bwd_fused}_paired: the tensor-product entry points above with
@@ -520,6 +522,11 @@ int nqa_pair_owner_lists(const int32_t* weight_rows, const int64_t* rep_edge, co
                          void* workspace, int64_t workspace_bytes, int32_t* owner_rowptr, int32_t* pair_other,
                          int32_t* pair_row, int32_t* pair_edge_in, int32_t* pair_edge_out, int32_t* other_rowptr,
                          int32_t* other_slot, nqa_stream stream);
+/* nqa_pair_owner_lists_guard: for callers that cannot wait for nqa_edge_pairs' verdict (a hipGraph capture): when *ok == 0 on
+ *   the device, both row pointers are zeroed -- the pair-centric kernels then walk empty lists instead of unwritten slots.
+ *   The evaluation is void in that case; the caller reads `ok` afterwards. */
+int nqa_pair_owner_lists_guard(const int32_t* ok, int64_t num_nodes, int32_t* owner_rowptr, int32_t* other_rowptr,
+                               nqa_stream stream);
 int nqa_pair_expand(const void* pair_rows, const int32_t* weight_rows, int64_t num_edges, int64_t num_pairs,
                     int32_t width, void* edge_rows, nqa_stream stream);
 int nqa_tp_scatter_fwd_paired(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
@@ -640,6 +647,24 @@ int nqa_neighbor_list_count(const double* pos, const double* cell, const int32_t
                             void* workspace, int64_t workspace_bytes, int32_t* rowptr, nqa_stream stream);
 int nqa_neighbor_list_fill(const void* workspace, const int32_t* rowptr, int64_t num_atoms, int64_t num_edges,
                            int64_t* edge_index, double* edge_cell_shift, nqa_stream stream);
+/* Capacity-padded variant: no read-back of the edge count, so neighbour list -> pairing -> model can be captured in ONE
+ *   hipGraph and replayed with new positions (molecular dynamics; the reference rebuilds its list on the host every step,
+ *   nequip/integrations/ase.py:125-160 -> data/_nl.py:63-165).  After nqa_neighbor_list_count, writes exactly `edge_capacity`
+ *   (even) edges: the E_real = rowptr[N] real ones, and behind the real edges of each atom its share of the E_cap - E_real
+ *   padding edges -- self-image pairs (i <- i, +S), (i <- i, -S) with S = k >= k0 cells along the shortest periodic lattice
+ *   vector, k0 |a| > r_max.  Padding edges lie outside the polynomial cutoff (nequip/nn/embedding/cutoffs.py:23-27: exactly
+ *   zero there, with zero slope), so their radial embedding, their bias-free radial-MLP weights
+ *   (nequip/nn/interaction_block.py:119-127) and every derivative w.r.t. their length vanish: energies and forces are those
+ *   of the unpadded list.  A cell is required (edge vectors of self images come from the shift alone).
+ *   rowptr_padded [N+1] int32 = the dst-CSR row pointer of the padded list (rowptr_padded[N] = edge_capacity);
+ *   src_sorted int32 [edge_capacity] (may be NULL) = edge_index[1] as the int32 neighbour array of that CSR (whose edge ids
+ *   are 0 .. edge_capacity - 1 in order).
+ *   status int32[2] (device, may be NULL): status[0] = 1 when the list did not fit (E_real > capacity, or capacity - E_real
+ *   odd) -- the output then holds padding edges ONLY (all indices valid, results void) and the caller repeats the step with a
+ *   larger capacity; status[1] = E_real. */
+int nqa_neighbor_list_fill_padded(const void* workspace, const int32_t* rowptr, int64_t num_atoms, int64_t edge_capacity,
+                                  int32_t* rowptr_padded, int64_t* edge_index, double* edge_cell_shift, int32_t* src_sorted,
+                                  int32_t* status, nqa_stream stream);
 
 #ifdef __cplusplus
 }

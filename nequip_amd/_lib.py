@@ -111,6 +111,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "nqa_pair_owner_lists_guard": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "nqa_pair_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "nqa_pair_expand": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nqa_tp_scatter_fwd_paired": (
@@ -254,6 +255,8 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "nqa_neighbor_list_fill": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nqa_neighbor_list_fill_padded": (
+        c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nqa_gate": (
         c_int32,
         [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p],

@@ -40,8 +40,14 @@ __device__ __forceinline__ void ep_shift(const ST* __restrict__ shift, int64_t e
 }
 
 // partner[e] = the one edge (src[e] <- dst[e], -S); is_rep[e] = canonical orientation (dst < src; self images: first
-// non-zero shift component positive)
-template <typename ST>
+// non-zero shift component positive).  EIGHT lanes per edge read row src[e] of the dst-CSR (~40 entries, shared through the
+// cache by the ~40 edges that point into it), six entries per lane in flight at once, and compare shifts only where the source
+// matches.  The kernel is a chain of dependent loads (src -> rowptr -> row -> [edge id ->] shift): its time is the number of
+// wavefronts over the number the device holds, times the chain -- hence few lanes per edge and all row loads issued together.
+// IDENT: the dst-CSR lists the edges in edge order (edge_id[k] == k: a list grouped by centre atom), one load less in the chain.
+constexpr int kPartnerLanes = 8;
+constexpr int kPartnerDepth = 6;
+template <typename ST, bool IDENT>
 __global__ __launch_bounds__(256) void edge_partner_kernel(const int64_t* __restrict__ dst, const int64_t* __restrict__ src,
                                                            const ST* __restrict__ shift,
                                                            const int32_t* __restrict__ rowptr,
@@ -49,33 +55,52 @@ __global__ __launch_bounds__(256) void edge_partner_kernel(const int64_t* __rest
                                                            const int32_t* __restrict__ src_sorted, int64_t E, int64_t N,
                                                            int32_t* __restrict__ partner, int32_t* __restrict__ is_rep,
                                                            int32_t* __restrict__ ok) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kPartnerLanes;
+  const int sub = threadIdx.x % kPartnerLanes;
+  if (e >= E) return;  // (whole groups leave together)
   const int64_t i = dst[e], j = src[e];
-  int32_t found = (int32_t)e, rep = 0;
+  int32_t match = -1, rep = 0;
+  int cnt = 0;
   bool good = i >= 0 && j >= 0 && i < N && j < N;
   if (good) {
     int sx, sy, sz;
     ep_shift(shift, e, sx, sy, sz);
     if (i == j && sx == 0 && sy == 0 && sz == 0) good = false;  // a self edge without a shift has no partner
     rep = (i != j) ? (i < j ? 1 : 0) : ((sx > 0 || (sx == 0 && (sy > 0 || (sy == 0 && sz > 0)))) ? 1 : 0);
-    int cnt = 0;
     const int32_t want = (int32_t)i;
-    for (int32_t k = rowptr[j]; k < rowptr[j + 1]; ++k) {
-      if (src_sorted[k] != want) continue;
-      const int32_t e2 = edge_id[k];
-      if (e2 == (int32_t)e) continue;
-      int tx, ty, tz;
-      ep_shift(shift, (int64_t)e2, tx, ty, tz);
-      if (tx == -sx && ty == -sy && tz == -sz) {
-        found = e2;
-        ++cnt;
+    const int32_t k1 = rowptr[j + 1];
+    for (int32_t kb = rowptr[j] + sub; kb < k1; kb += kPartnerLanes * kPartnerDepth) {
+      int32_t v[kPartnerDepth];
+#pragma unroll
+      for (int u = 0; u < kPartnerDepth; ++u) {
+        const int32_t k = kb + kPartnerLanes * u;
+        v[u] = k < k1 ? src_sorted[k] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kPartnerDepth; ++u) {
+        if (v[u] != want) continue;
+        const int32_t k = kb + kPartnerLanes * u;
+        const int32_t e2 = IDENT ? k : edge_id[k];
+        if (e2 == (int32_t)e) continue;
+        int tx, ty, tz;
+        ep_shift(shift, (int64_t)e2, tx, ty, tz);
+        if (tx == -sx && ty == -sy && tz == -sz) {
+          match = e2;
+          ++cnt;
+        }
       }
     }
-    if (cnt != 1) good = false;
   }
+#pragma unroll
+  for (int off = kPartnerLanes / 2; off > 0; off >>= 1) {
+    cnt += __shfl_xor(cnt, off, kPartnerLanes);
+    const int32_t m = __shfl_xor(match, off, kPartnerLanes);
+    match = m > match ? m : match;
+  }
+  if (sub != 0) return;
+  if (cnt != 1) good = false;
   if (!good) atomicAnd(ok, 0);
-  partner[e] = found;
+  partner[e] = match >= 0 ? match : (int32_t)e;
   is_rep[e] = rep;
 }
 
@@ -87,12 +112,15 @@ __global__ __launch_bounds__(256) void edge_pairs_number_kernel(const int32_t* _
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int32_t P = (int32_t)(E / 2);
+  // (row numbers beyond the P pairs only arise on a list that does not pair up, whose arrays are not to be used: they are
+  // clamped all the same, so that a caller that reads the verdict late -- a captured graph -- never holds an index out of range)
   if (is_rep[e]) {
     const int32_t p = pnum[e];
-    weight_rows[e] = p;
-    if (p < P) rep_edge[p] = e;  // (p >= P only on a list that does not pair up: arrays not to be used)
+    weight_rows[e] = p < P ? p : P - 1;
+    if (p < P) rep_edge[p] = e;
   } else {
-    weight_rows[e] = pnum[partner[e]] + P;
+    const int32_t p = pnum[partner[e]];
+    weight_rows[e] = (p < P ? p : P - 1) + P;
   }
 }
 
@@ -195,8 +223,8 @@ __global__ __launch_bounds__(256) void pair_owner_fill_kernel(const int32_t* __r
       in = ep_is_in((int)n, j, r, P);
     }
     const uint64_t m = __builtin_amdgcn_ballot_w64(in);
-    if (in) {
-      const int32_t s = base + __popcll(m & ((1ull << lane) - 1ull));
+    const int32_t s = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (in && s < P) {  // (s >= P: a list that does not pair up, see edge_pairs_number_kernel)
       const int32_t p = r < P ? r : r - P;
       pair_other[s] = j;
       pair_row[s] = p;
@@ -229,9 +257,22 @@ __global__ __launch_bounds__(256) void pair_other_fill_kernel(const int32_t* __r
       out = !ep_is_in((int)n, src_sorted[k], r, P);
     }
     const uint64_t m = __builtin_amdgcn_ballot_w64(out);
-    if (out) other_slot[base + __popcll(m & ((1ull << lane) - 1ull))] = slot_of_pair[r < P ? r : r - P];
+    const int32_t s = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (out && s < P) other_slot[s] = slot_of_pair[r < P ? r : r - P];
     base += __popcll(m);
   }
+}
+
+// Deferred verdict (a captured graph cannot wait for `ok`): a list that did not pair up gets EMPTY owner lists, so the
+// pair-centric kernels walk nothing instead of following unwritten slots.  The evaluation is void either way; this keeps it
+// in bounds until the caller has read the flag.
+__global__ __launch_bounds__(256) void pair_lists_guard_kernel(const int32_t* __restrict__ ok, int64_t N,
+                                                               int32_t* __restrict__ owner_rowptr,
+                                                               int32_t* __restrict__ other_rowptr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > N || *ok != 0) return;
+  owner_rowptr[i] = 0;
+  other_rowptr[i] = 0;
 }
 
 static size_t ep_scan_bytes(int64_t N) {
@@ -265,7 +306,7 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
                    int64_t num_nodes, void* workspace, int64_t workspace_bytes, int32_t* weight_rows, int64_t* rep_edge,
                    int32_t* partner_edge, int32_t* ok, nqa_stream stream) {
   if (num_edges < 0 || num_nodes < 0 || !ok ||
-      (num_edges > 0 && (!edge_dst || !edge_src || !rowptr_dst || !edge_id_dst || !src_sorted || !weight_rows || !rep_edge ||
+      (num_edges > 0 && (!edge_dst || !edge_src || !rowptr_dst || !src_sorted || !weight_rows || !rep_edge ||
                          !partner_edge)) ||
       (edge_cell_shift && shift_dtype != NQA_F32 && shift_dtype != NQA_F64)) {
     set_error("nqa_edge_pairs: invalid argument");
@@ -296,14 +337,18 @@ int nqa_edge_pairs(const int64_t* edge_dst, const int64_t* edge_src, const void*
   p += ep_align256(E * 4);
   size_t scan_bytes = ep_scan_e_bytes(E);
   const unsigned ge = (unsigned)((E + 255) / 256);
-  if (edge_cell_shift && shift_dtype == NQA_F32)
-    hipLaunchKernelGGL(edge_partner_kernel<float>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src,
-                       static_cast<const float*>(edge_cell_shift), rowptr_dst, edge_id_dst, src_sorted, E, num_nodes,
-                       partner_edge, is_rep, ok);
-  else
-    hipLaunchKernelGGL(edge_partner_kernel<double>, dim3(ge), dim3(256), 0, s, edge_dst, edge_src,
-                       static_cast<const double*>(edge_cell_shift), rowptr_dst, edge_id_dst, src_sorted, E, num_nodes,
-                       partner_edge, is_rep, ok);
+  const unsigned gp = (unsigned)((E * kPartnerLanes + 255) / 256);
+  const bool f32 = edge_cell_shift && shift_dtype == NQA_F32;
+  const bool ident = edge_id_dst == nullptr;  // the dst-CSR lists the edges in edge order
+#define NQA_PARTNER(ST, ID)                                                                                          \
+  hipLaunchKernelGGL((edge_partner_kernel<ST, ID>), dim3(gp), dim3(256), 0, s, edge_dst, edge_src,                     \
+                     static_cast<const ST*>(edge_cell_shift), rowptr_dst, edge_id_dst, src_sorted, E, num_nodes,      \
+                     partner_edge, is_rep, ok)
+  if (f32 && ident) NQA_PARTNER(float, true);
+  else if (f32) NQA_PARTNER(float, false);
+  else if (ident) NQA_PARTNER(double, true);
+  else NQA_PARTNER(double, false);
+#undef NQA_PARTNER
   if (rocprim::exclusive_scan(p, scan_bytes, is_rep, pnum, (int32_t)0, (size_t)E, rocprim::plus<int32_t>(), s) !=
       hipSuccess) {
     set_error("nqa_edge_pairs: prefix sum failed");
@@ -398,6 +443,22 @@ int nqa_pair_owner_lists(const int32_t* weight_rows, const int64_t* rep_edge, co
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("nqa_pair_owner_lists: ") + hipGetErrorString(err));
+    return NQA_ERR_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+int nqa_pair_owner_lists_guard(const int32_t* ok, int64_t num_nodes, int32_t* owner_rowptr, int32_t* other_rowptr,
+                               nqa_stream stream) {
+  if (!ok || num_nodes < 0 || !owner_rowptr || !other_rowptr) {
+    set_error("nqa_pair_owner_lists_guard: invalid argument");
+    return NQA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(pair_lists_guard_kernel, dim3((unsigned)((num_nodes + 1 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), ok, num_nodes, owner_rowptr, other_rowptr);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string("nqa_pair_owner_lists_guard: ") + hipGetErrorString(err));
     return NQA_ERR_LAUNCH;
   }
   return NQA_OK;

@@ -130,6 +130,108 @@ def _compute_neighborlist_single_frame(
     return edge_index, shifts.to(out_dtype)
 
 
+class PaddedNeighborList:
+    """Neighbour list of ONE frame with a fixed number of edge slots and no host read-back (``nqa_neighbor_list_count`` +
+    ``nqa_neighbor_list_fill_padded``): every launch of ``build`` goes to the current stream and every shape is static, so
+    ``positions -> neighbour list -> pairing -> model`` can be captured in one hipGraph and replayed (molecular dynamics;
+    the reference builds the list on the host at every step, ``nequip/integrations/ase.py:125-160`` ->
+    ``nequip/data/_nl.py:63-165``).
+
+    The ``edge_capacity - E`` unused slots hold padding edges: self-image pairs ``(i <- i, +-S)`` longer than ``r_max``, dealt
+    out evenly over the atoms.  They lie outside the polynomial cutoff, so their radial embedding, their (bias-free) radial-MLP
+    weights and all derivatives vanish: energies, forces and virials are those of the unpadded list.  Needs a cell.
+
+    ``status()`` (a synchronising read, for AFTER the step) reports ``(fits, E)``: when the list did not fit, the output of that
+    ``build`` holds padding only and the caller repeats the step with a larger capacity."""
+
+    def __init__(self, num_atoms: int, r_max: float, cell: torch.Tensor,
+                 pbc: Union[bool, Tuple[bool, bool, bool], torch.Tensor], edge_capacity: int,
+                 shift_dtype: torch.dtype = torch.float32):
+        if cell is None:
+            raise ValueError("a capacity-padded neighbour list needs a cell (its padding edges are lattice images)")
+        if not cell.is_cuda:
+            raise RuntimeError("the `nequip_amd` neighbour list runs on the GPU: the cell must be a CUDA/HIP tensor")
+        if isinstance(pbc, bool):
+            pbc = (pbc,) * 3
+        elif isinstance(pbc, torch.Tensor):
+            pbc = tuple(bool(b) for b in pbc.detach().cpu().view(-1).tolist())
+        self.num_atoms = int(num_atoms)
+        if self.num_atoms < 1:
+            raise ValueError("a capacity-padded neighbour list needs at least one atom")
+        self.r_max = float(r_max)
+        self.edge_capacity = int(edge_capacity) + (int(edge_capacity) & 1)  # (pairs of edges)
+        if not 0 <= self.edge_capacity < 2**31 - 1:
+            raise ValueError("edge capacity outside the int32 index range of the kernels")
+        self.shift_dtype = shift_dtype
+        self.device = cell.device
+        self.pbc = tuple(pbc)
+        lib = _lib.load()
+        self.cell64 = torch.empty(3, 3, dtype=torch.float64, device=self.device)
+        self.set_cell(cell)
+        self._pbc_dev = torch.tensor([int(b) for b in pbc], dtype=torch.int32, device=self.device)
+        self._ws_bytes = lib.nqa_neighbor_list_workspace_bytes(self.num_atoms)
+        self._ws = torch.empty(max(self._ws_bytes, 1), dtype=torch.uint8, device=self.device)
+        self._rowptr = torch.empty(self.num_atoms + 1, dtype=torch.int32, device=self.device)
+        self._status = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._edge_ids = torch.arange(max(self.edge_capacity, 1), dtype=torch.int32, device=self.device)
+        self.last_csr = None
+
+    def set_cell(self, cell: torch.Tensor) -> None:
+        """New lattice vectors (variable-cell dynamics): written into the buffer the captured launches read.  Reads the cell on
+        the host once (completion of missing lattice vectors, as ``_compute_neighborlist_single_frame`` does)."""
+        c = _complete_cell(cell.detach().to(torch.float64).reshape(3, 3).contiguous(), self.pbc)
+        self.cell64.copy_(c)
+
+    def build(self, pos: torch.Tensor):
+        """``(edge_index [2, capacity] int64, edge_cell_shift [capacity, 3], rowptr [N + 1] int32)`` for ``pos``; also leaves
+        the fit flag in ``status_tensor`` (device).  No synchronisation."""
+        if not pos.is_cuda or pos.shape != (self.num_atoms, 3):
+            raise RuntimeError(f"positions must be a CUDA/HIP tensor of shape ({self.num_atoms}, 3)")
+        lib = _lib.load()
+        dev = self.device
+        pos64 = pos.detach().to(torch.float64).contiguous()
+        cap = self.edge_capacity
+        edge_index = torch.empty((2, cap), dtype=torch.int64, device=dev)
+        shifts = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+        rowptr = torch.empty(self.num_atoms + 1, dtype=torch.int32, device=dev)
+        src32 = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            rc = lib.nqa_neighbor_list_count(_ptr(pos64), _ptr(self.cell64), _ptr(self._pbc_dev), self.r_max,
+                                             self.num_atoms, _ptr(self._ws), self._ws_bytes, _ptr(self._rowptr), stream)
+            _lib.check(rc, "nqa_neighbor_list_count")
+            rc = lib.nqa_neighbor_list_fill_padded(_ptr(self._ws), _ptr(self._rowptr), self.num_atoms, cap, _ptr(rowptr),
+                                                   _ptr(edge_index), _ptr(shifts), _ptr(src32), _ptr(self._status), stream)
+            _lib.check(rc, "nqa_neighbor_list_fill_padded")
+        self.last_csr = (rowptr, self._edge_ids, src32)  # the dst-CSR of the list just built (edge ids = 0 .. capacity - 1)
+        return edge_index, shifts.to(self.shift_dtype), rowptr
+
+    @property
+    def status_tensor(self) -> torch.Tensor:
+        """int32[2] on the device: ``[did not fit, E]`` of the last ``build``."""
+        return self._status
+
+    def status(self) -> Tuple[bool, int]:
+        """``(fits, E)`` of the last ``build`` (synchronises)."""
+        bad, e = self._status.cpu().tolist()
+        return bad == 0, int(e)
+
+
+def compute_neighborlist_padded_(data: AtomicDataDict.Type, nl: PaddedNeighborList) -> AtomicDataDict.Type:
+    """``compute_neighborlist_`` for one unbatched frame through a ``PaddedNeighborList``: adds ``edge_index`` and
+    ``edge_cell_shift`` (both ``nl.edge_capacity`` long) in place and hands the row pointer to the topology cache."""
+    K = AtomicDataDict
+    if K.BATCH_KEY in data and K.num_frames(data) != 1:
+        raise ValueError("a capacity-padded neighbour list holds one frame")
+    edge_index, shifts, rowptr = nl.build(data[K.POSITIONS_KEY])
+    data[K.EDGE_INDEX_KEY] = edge_index
+    data[K.EDGE_CELL_SHIFT_KEY] = shifts
+    from ..nn._topology import topology_cache
+
+    topology_cache.hint_sorted(edge_index, rowptr, csr=nl.last_csr)
+    return data
+
+
 def _frame_from_batched(data: AtomicDataDict.Type, idx: int, node_offsets) -> AtomicDataDict.Type:
     K = AtomicDataDict
     lo, hi = int(node_offsets[idx]), int(node_offsets[idx + 1])

@@ -83,8 +83,14 @@ class NequIPCalculator(Calculator):
         energy_units_to_eV: float = 1.0,
         length_units_to_A: float = 1.0,
         transforms: Sequence[Callable] = (),
+        graphed_md: bool = False,
+        graphed_md_headroom: float = 1.02,
         **kwargs,
     ):
+        """``graphed_md=True``: successive calls on the same atoms (same species, same periodicity -- a molecular-dynamics
+        run) replay positions -> neighbour list -> model as one hipGraph (``integrations/graphed_step.py``) instead of
+        launching ~110 kernels per step from Python; any change of the atoms' identity captures anew, a changed cell is
+        written in place.  Needs a cell, an eager ``nequip_amd`` model (not a compiled package) and no ``transforms``."""
         Calculator.__init__(self, **kwargs)
         self.results = {}
         assert not model.training, "make sure to call .eval() on model before building NequIPCalculator"
@@ -96,6 +102,11 @@ class NequIPCalculator(Calculator):
         self.energy_units_to_eV = energy_units_to_eV
         self.length_units_to_A = length_units_to_A
         self.transforms = list(transforms)
+        self.graphed_md = bool(graphed_md)
+        self.graphed_md_headroom = float(graphed_md_headroom)
+        self._graphed = None  # (identity of the atoms, GraphedStep, cell as last written)
+        if self.graphed_md and self.transforms:
+            raise ValueError("graphed_md replays a fixed pipeline: it cannot run user transforms")
         # chemical symbol -> atom type index (`ChemicalSpeciesToAtomTypeMapper`, nequip/data/transforms): a list means
         # "type_names are chemical symbols in this order", a dict maps symbol -> type name
         type_names = list(getattr(model, "type_names", []) or [])
@@ -149,6 +160,35 @@ class NequIPCalculator(Calculator):
     def call_model(self, data: AtomicDataDict.Type) -> AtomicDataDict.Type:
         return self.model(data)
 
+    def _graphed_outputs(self, atoms) -> Optional[AtomicDataDict.Type]:
+        """The replayed step for ``atoms`` (``None``: not applicable -- no periodic direction, i.e. no cell to pad with)."""
+        from .graphed_step import GraphedStep
+
+        K = AtomicDataDict
+        pbc = tuple(bool(b) for b in np.asarray(atoms.get_pbc(), dtype=bool).reshape(3))
+        if not any(pbc):
+            return None
+        symbols = tuple(atoms.get_chemical_symbols())
+        cell = np.asarray(atoms.get_cell(), dtype=np.float64).reshape(3, 3)
+        ident = (symbols, pbc)
+        if self._graphed is None or self._graphed[0] != ident:
+            try:
+                types = np.fromiter((self._type_of_symbol[s] for s in symbols), dtype=np.int64, count=len(symbols))
+            except KeyError as e:
+                raise ValueError(f"chemical species {e.args[0]!r} is not among the model's types "
+                                 f"{sorted(self._type_of_symbol)}") from None
+            step = GraphedStep(
+                self.model, torch.as_tensor(types).to(self.device), torch.as_tensor(cell).to(self.device), pbc, self.r_max,
+                headroom=self.graphed_md_headroom,
+                outputs=(K.TOTAL_ENERGY_KEY, K.PER_ATOM_ENERGY_KEY, K.FORCE_KEY, K.STRESS_KEY, K.VIRIAL_KEY))
+            self._graphed = (ident, step, cell.copy())
+        _, step, last_cell = self._graphed
+        if not np.array_equal(cell, last_cell):
+            step.set_cell(torch.as_tensor(cell).to(self.device))
+            self._graphed = (ident, step, cell.copy())
+        pos = torch.as_tensor(np.asarray(atoms.get_positions(), dtype=np.float64)).to(self.device)
+        return step(pos)
+
     def save_extra_outputs(self, out: AtomicDataDict.Type) -> None:
         """Hook for subclasses (as in the reference)."""
 
@@ -157,7 +197,9 @@ class NequIPCalculator(Calculator):
         Calculator.calculate(self, atoms)
         atoms = atoms if atoms is not None else self.atoms
         K = AtomicDataDict
-        out = self.call_model(self.atoms_to_data(atoms))
+        out = self._graphed_outputs(atoms) if self.graphed_md else None
+        if out is None:
+            out = self.call_model(self.atoms_to_data(atoms))
         self.results = {}
         e2ev, l2a = self.energy_units_to_eV, self.length_units_to_A
         if K.TOTAL_ENERGY_KEY in out:

@@ -32,9 +32,15 @@ class EdgeTopology:
     """CSR views of one edge list.  ``by_dst`` drives forward / edge gradients, ``by_src`` the feature gradient."""
 
     check_indices: bool = False  # set True to validate 0 <= index < num_nodes (costs a device sync)
+    # Deferred pairing verdict (set per instance by a caller that cannot synchronise: a hipGraph capture of a whole MD step,
+    # ``integrations/graphed_step.py``): ``pairing`` launches the kernels and hands out the pairing WITHOUT reading the flag;
+    # ``pairing_ok`` is the device flag the caller reads after the evaluation (0 = the list did not pair up, results void -- the
+    # indices stay in range and the pair-centric kernels get empty lists, ``nqa_pair_owner_lists_guard``).
+    defer_pairing_verdict: bool = False
+    pairing_ok: Optional[torch.Tensor] = None
 
     def __init__(self, edge_dst: torch.Tensor, edge_src: torch.Tensor, num_nodes: int,
-                 rowptr_dst: Optional[torch.Tensor] = None):
+                 rowptr_dst: Optional[torch.Tensor] = None, csr_dst=None):
         if not edge_dst.is_cuda:
             raise RuntimeError(
                 "nequip_amd kernels run on the GPU only (got CPU index tensors); there is no CPU fallback"
@@ -48,12 +54,20 @@ class EdgeTopology:
         self._src = edge_src.contiguous()
         self._by_dst: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._by_src: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
-        if rowptr_dst is not None and rowptr_dst.numel() == self.num_nodes + 1:
+        self._dst_is_identity = False  # the dst-CSR lists the edges in edge order (a list grouped by centre atom)
+        self._side_ready: Optional[torch.cuda.Event] = None  # see prefetch_backward_lists
+        self._pair_ready: Optional[torch.cuda.Event] = None
+        if csr_dst is not None and csr_dst[0].numel() == self.num_nodes + 1:
+            # (the neighbour list handed over its complete dst-CSR: row pointer, edge ids in order, int32 neighbours)
+            self._by_dst = tuple(csr_dst)
+            self._dst_is_identity = True
+        elif rowptr_dst is not None and rowptr_dst.numel() == self.num_nodes + 1:
             # edges already grouped by destination in ascending order (the device neighbour list emits them that way and
             # hands over its row pointer): the dst-CSR is the identity permutation, no sort needed
             eid = torch.arange(max(self.num_edges, 1), dtype=torch.int32, device=self.device)
             oth = self._src.to(torch.int32) if self.num_edges else torch.zeros(1, dtype=torch.int32, device=self.device)
             self._by_dst = (rowptr_dst, eid, oth)
+            self._dst_is_identity = True
 
     def _build(self, key: torch.Tensor, other: torch.Tensor):
         lib = _lib.load()
@@ -94,10 +108,22 @@ class EdgeTopology:
             return
         E = self.num_edges
         if (E == 0 or E % 2 != 0 or os.environ.get("NQA_NO_PAIRED", "") not in ("", "0")
-                or torch.cuda.is_current_stream_capturing()):
+                or torch.cuda.is_current_stream_capturing() or self.defer_pairing_verdict):
             return
+        dev = self.device
+        rows, rep, partner, ok = self._launch_pairing(shifts)
+        with torch.cuda.device(dev):
+            verdict = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            verdict.copy_(ok, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        self._pairing_pending = (key, rows, rep, partner, verdict, done, ok)
+
+    def _launch_pairing(self, shifts: Optional[torch.Tensor], zero_rep: bool = False):
+        """``nqa_edge_pairs`` on the current stream: ``(weight_rows, rep_edge, partner, ok)`` device tensors, nothing read."""
         lib = _lib.load()
         dev = self.device
+        E = self.num_edges
         sh = None
         if shifts is not None:
             sh = shifts.detach()
@@ -106,28 +132,30 @@ class EdgeTopology:
             sh = sh.contiguous()
         rows = torch.empty(E, dtype=torch.int32, device=dev)
         partner = torch.empty(E, dtype=torch.int32, device=dev)
-        rep = torch.empty(E // 2, dtype=torch.int64, device=dev)
-        ok = torch.zeros(1, dtype=torch.int32, device=dev)
+        # (deferred verdict: a pair number the kernels never assign must still name an edge)
+        rep = (torch.zeros if zero_rep else torch.empty)(E // 2, dtype=torch.int64, device=dev)
+        ok = torch.empty(1, dtype=torch.int32, device=dev)  # (initialised by nqa_edge_pairs)
         ws_bytes = lib.nqa_edge_pairs_workspace_bytes(E)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         sdt = _lib.NQA_F32 if (sh is not None and sh.dtype == torch.float32) else _lib.NQA_F64
         rowptr, eid, nbr = self.by_dst  # (the reverse of (i <- j) is looked up in row j of the dst-CSR: no sort)
         with torch.cuda.device(dev):
-            rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, _ptr(rowptr), _ptr(eid), _ptr(nbr),
+            # (edge ids NULL = "in edge order": a list grouped by centre atom, one load less per look-up)
+            rc = lib.nqa_edge_pairs(_ptr(self._dst), _ptr(self._src), _ptr(sh), sdt, _ptr(rowptr),
+                                    _ptr(None if self._dst_is_identity else eid), _ptr(nbr),
                                     E, self.num_nodes, _ptr(ws), ws_bytes, _ptr(rows), _ptr(rep), _ptr(partner),
                                     _ptr(ok), current_stream_ptr(dev))
             _lib.check(rc, "nqa_edge_pairs")
-            verdict = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            verdict.copy_(ok, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(dev))
-        self._pairing_pending = (key, rows, rep, partner, verdict, done, ok)
+        return rows, rep, partner, ok
 
     def pairing_if_known(self, shifts: Optional[torch.Tensor]):
         """``pairing(shifts)`` when its verdict has been read already (no wait, no launch), else ``None``."""
         cached = getattr(self, "_pairing", None)
         if cached is not None and cached[0] == self._shift_key(shifts):
+            self._wait_pair()
             return cached[1]
+        if self.defer_pairing_verdict:  # (nothing to wait for: the flag is read after the evaluation)
+            return self.pairing(shifts)
         return None
 
     def pairing(self, shifts: Optional[torch.Tensor]):
@@ -137,7 +165,20 @@ class EdgeTopology:
         key = self._shift_key(shifts)
         cached = getattr(self, "_pairing", None)
         if cached is not None and cached[0] == key:
+            self._wait_pair()
             return cached[1]
+        if self.defer_pairing_verdict:
+            if (self.num_edges == 0 or self.num_edges % 2 != 0
+                    or os.environ.get("NQA_NO_PAIRED", "") not in ("", "0")):
+                self._pairing = (key, None)
+                return None
+            rows, rep, partner, ok = self._launch_pairing(shifts, zero_rep=True)
+            result = EdgePairing(self, rows, rep)
+            result.partner = partner
+            result.ok_flag = ok
+            self.pairing_ok = ok
+            self._pairing = (key, result)
+            return result
         if torch.cuda.is_current_stream_capturing():
             return None  # reading the verdict needs a synchronisation: not inside a hipGraph capture (not cached)
         self.start_pairing(shifts)
@@ -153,6 +194,38 @@ class EdgeTopology:
         self._pairing = (key, result)
         return result
 
+    def prefetch_backward_lists(self, shifts: Optional[torch.Tensor], side: "torch.cuda.Stream") -> None:
+        """Build what only the backward pass reads -- the by-source CSR, the owner lists of the pair-centric kernels, the
+        weight rows in by-source order -- on ``side`` NOW, next to the forward pass on the current stream, instead of lazily in
+        front of their first consumer (~0.1 ms of small launches at 400 k edges that a new list per step would otherwise pay
+        on the critical path).  Every later access waits for ``side`` on the stream it is made from.  For callers that know
+        the pairing without waiting (a deferred verdict, or a verdict already read)."""
+        if self._side_ready is not None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            # (a deferred verdict: the pairing itself starts here too, next to the edge vectors / type embedding on `cur`)
+            pairing = self.pairing_if_known(shifts)
+            paired = torch.cuda.Event()
+            paired.record(side)
+            self._pair_ready = paired
+            if pairing is not None:
+                self.by_src
+                pairing.owner_csr
+                pairing.slots_src
+                ready = torch.cuda.Event()
+                ready.record(side)
+                self._side_ready = ready
+
+    def _wait_pair(self) -> None:
+        if self._pair_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._pair_ready)
+
+    def _wait_side(self) -> None:
+        if self._side_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._side_ready)
+
     @property
     def by_dst(self):
         if self._by_dst is None:
@@ -161,6 +234,7 @@ class EdgeTopology:
 
     @property
     def by_src(self):
+        self._wait_side()
         if self._by_src is None:
             paired = getattr(self, "_pairing", None)
             if paired is not None and paired[1] is not None and self._by_dst is not None and self.num_edges > 0:
@@ -197,6 +271,11 @@ def owner_lists(topo: "EdgeTopology", pairing: "EdgePairing"):
                                       _ptr(ws), ws_bytes, _ptr(owner_rowptr), _ptr(pair_other), _ptr(pair_row), _ptr(e_in),
                                       _ptr(e_out), _ptr(other_rowptr), _ptr(other_slot), current_stream_ptr(dev))
     _lib.check(rc, "nqa_pair_owner_lists")
+    ok = getattr(pairing, "ok_flag", None)
+    if ok is not None:  # deferred verdict: empty lists for a list that did not pair up
+        with torch.cuda.device(dev):
+            rc = lib.nqa_pair_owner_lists_guard(_ptr(ok), N, _ptr(owner_rowptr), _ptr(other_rowptr), current_stream_ptr(dev))
+        _lib.check(rc, "nqa_pair_owner_lists_guard")
     return owner_rowptr, pair_other, pair_row, e_in, e_out, other_rowptr, other_slot
 
 
@@ -236,6 +315,7 @@ class EdgePairing:
         self.num_pairs = int(rep_edge.numel())
         self._topo = weakref.ref(topo)
         self.partner: Optional[torch.Tensor] = None  # int32 [E]: the reverse edge of every edge
+        self.ok_flag: Optional[torch.Tensor] = None  # deferred verdict only: int32 [1] on the device (see EdgeTopology)
         self._slots_dst: Optional[torch.Tensor] = None
         self._slots_src: Optional[torch.Tensor] = None
         self._owner_csr = None
@@ -243,12 +323,17 @@ class EdgePairing:
     @property
     def slots_dst(self) -> torch.Tensor:
         if self._slots_dst is None:
-            eid = self._topo().by_dst[1][: self.rows.numel()]
-            self._slots_dst = self.rows.index_select(0, eid.to(torch.int64)).contiguous()
+            topo = self._topo()
+            if topo._dst_is_identity:  # slot k of the dst-CSR is edge k
+                self._slots_dst = self.rows
+            else:
+                eid = topo.by_dst[1][: self.rows.numel()]
+                self._slots_dst = self.rows.index_select(0, eid.to(torch.int64)).contiguous()
         return self._slots_dst
 
     @property
     def slots_src(self) -> torch.Tensor:
+        self._topo()._wait_side()
         if self._slots_src is None:
             eid = self._topo().by_src[1][: self.rows.numel()]
             self._slots_src = self.rows.index_select(0, eid.to(torch.int64)).contiguous()
@@ -263,6 +348,7 @@ class EdgePairing:
         Returns int32 device tensors ``(owner_rowptr, pair_other, pair_row, edge_in, edge_out, other_rowptr, other_slot)``.
         Built once per neighbour list from the dst-CSR (``nqa_pair_owner_lists``: counting passes and prefix sums, no sort,
         no synchronisation; slots keep the CSR order)."""
+        self._topo()._wait_side()
         if self._owner_csr is None:
             topo = self._topo()
             self._owner_csr = owner_lists(topo, self)
@@ -304,10 +390,11 @@ class _TopologyCache:
     def _base(t: torch.Tensor) -> torch.Tensor:
         return t._base if t._base is not None else t
 
-    def hint_sorted(self, edge_index: torch.Tensor, rowptr_dst: torch.Tensor) -> None:
+    def hint_sorted(self, edge_index: torch.Tensor, rowptr_dst: torch.Tensor, csr=None) -> None:
         """Called by the device neighbour list: `edge_index` ([2, E], rows = dst, src) is grouped by dst in ascending order
-        and `rowptr_dst` ([N+1] int32) is its row pointer.  Used by the next `get` on views of that very tensor."""
-        self._hint = (weakref.ref(edge_index), edge_index.data_ptr(), edge_index._version, rowptr_dst)
+        and `rowptr_dst` ([N+1] int32) is its row pointer (`csr`: the complete dst-CSR ``(rowptr, edge ids, int32
+        neighbours)`` when the list has it).  Used by the next `get` on views of that very tensor."""
+        self._hint = (weakref.ref(edge_index), edge_index.data_ptr(), edge_index._version, rowptr_dst, csr)
 
     def _rowptr_hint(self, bd: torch.Tensor, edge_dst: torch.Tensor, num_nodes: int):
         hint = getattr(self, "_hint", None)
@@ -317,7 +404,7 @@ class _TopologyCache:
             return None
         if edge_dst.data_ptr() != bd.data_ptr() or hint[3].numel() != num_nodes + 1:
             return None  # not row 0 of the hinted tensor
-        return hint[3]
+        return hint[3] if len(hint) < 5 or hint[4] is None else hint[4]
 
     @staticmethod
     def _checksum(edge_dst: torch.Tensor, edge_src: torch.Tensor) -> int:
@@ -369,11 +456,19 @@ class _TopologyCache:
                 if i != len(self._entries) - 1:
                     self._entries.append(self._entries.pop(i))
                 return topo
-        topo = EdgeTopology(edge_dst, edge_src, num_nodes, rowptr_dst=self._rowptr_hint(bd, edge_dst, num_nodes))
+        hint = self._rowptr_hint(bd, edge_dst, num_nodes)
+        if isinstance(hint, tuple):
+            topo = EdgeTopology(edge_dst, edge_src, num_nodes, csr_dst=hint)
+        else:
+            topo = EdgeTopology(edge_dst, edge_src, num_nodes, rowptr_dst=hint)
         self._entries.append((key, (sd, ss), topo, self._checksum(edge_dst, edge_src) if verify else None))
         while len(self._entries) > self.MAX_ENTRIES:
             self._entries.pop(0)
         return topo
+
+    def forget(self, topo: EdgeTopology) -> None:
+        """Drop one topology from the cross-call cache (its owner keeps it alive: a captured graph)."""
+        self._entries = [e for e in self._entries if e[2] is not topo]
 
     def invalidate(self) -> None:
         """Forget every cached topology (after rewriting an index tensor in place)."""

@@ -131,3 +131,46 @@ def test_calculator_from_compiled_model(device, tmp_path):
     vol = abs(np.linalg.det(np.asarray(cell, dtype=np.float64)))
     so = full_3x3_to_voigt_6_stress(-orc["virial"].numpy().reshape(3, 3) / vol)
     np.testing.assert_allclose(s1, so, rtol=0, atol=5e-4 * max(1e-3, np.abs(so).max()))
+
+
+@pytest.mark.gpu
+def test_graphed_md_calculator_follows_a_trajectory(device):
+    """``graphed_md=True``: the calls of an MD run replay one hipGraph (capacity-padded neighbour list, deferred pairing
+    verdict) and give what the ordinary calculator gives -- along a trajectory, after a change of the cell (written in
+    place), for other atoms (captured anew) and for a molecule (no cell to pad with: the ordinary path)."""
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=4, seed=3)
+    cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
+    model = NequIPGNNModel(seed=1, model_dtype="float32", r_max=4.0, type_names=names, num_layers=2, l_max=2,
+                           parity=False, num_features=16, radial_mlp_depth=1, radial_mlp_width=64,
+                           avg_num_neighbors=20.0).to(device).eval()
+    plain = NequIPCalculator(model, device, r_max=4.0)
+    fast = NequIPCalculator(model, device, r_max=4.0, graphed_md=True)
+    symbols = [names[t] for t in types]
+    rng = np.random.default_rng(0)
+
+    def compare(atoms):
+        e, f, s = fast.get_potential_energy(atoms), fast.get_forces(atoms).copy(), fast.get_stress(atoms).copy()
+        e0, f0, s0 = plain.get_potential_energy(atoms), plain.get_forces(atoms), plain.get_stress(atoms)
+        np.testing.assert_allclose(e, e0, rtol=1e-6, atol=1e-5 * len(pos))
+        np.testing.assert_allclose(f, f0, rtol=0, atol=1e-5 * max(1.0, np.abs(f0).max()))
+        np.testing.assert_allclose(s, s0, rtol=0, atol=1e-5 * max(1e-3, np.abs(s0).max()))
+        np.testing.assert_allclose(fast.results["energies"], plain.results["energies"], rtol=0, atol=1e-5)
+
+    p = pos.copy()
+    for _ in range(4):
+        p = p + 0.03 * rng.normal(size=p.shape)
+        compare(FakeAtoms(symbols, p, cell, pbc=True))
+    step = fast._graphed[1]
+    assert step.num_captures == 1 and step.num_eager_fallbacks == 0
+    compare(FakeAtoms(symbols, 1.01 * p, 1.01 * cell, pbc=True))  # a new cell: same graph
+    assert fast._graphed[1] is step and step.num_captures == 1
+    perm = rng.permutation(len(p))
+    compare(FakeAtoms([symbols[i] for i in perm], p[perm], cell, pbc=True))  # other atoms: a new graph
+    assert fast._graphed[1] is not step
+    mol = FakeAtoms(symbols[:9], pos[:9])
+    np.testing.assert_allclose(fast.get_forces(mol), plain.get_forces(mol), rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        NequIPCalculator(model, device, r_max=4.0, graphed_md=True, transforms=[lambda d: d])

@@ -1,0 +1,288 @@
+"""A molecular-dynamics force evaluation as one hipGraph: capacity-padded device neighbour list (no read-back of the edge count),
+deferred pairing verdict, replayed model (``nequip_amd/integrations/graphed_step.py``, ``PaddedNeighborList``).
+
+* the padding rule restated in numpy (``_pad_reference``) and the claim it rests on, checked on the CPU against the ORACLE's
+  restatement of nequip: padding edges -- self images beyond ``r_max`` -- change neither energy, forces nor virial
+  (``nequip/nn/embedding/cutoffs.py:23-27`` masks them, the radial MLP is bias-free, ``interaction_block.py:119-127``);
+* on the GPU: the padded list IS the plain list plus the rule's padding (indices, shifts, row pointer: exact); a list that does
+  not fit is reported and stays in range; the model on a padded list equals the model on the plain list; replayed steps follow
+  moving atoms and agree with the eager path, a list that outgrows its capacity is captured again; a list that does not pair up
+  under a deferred verdict stays in bounds and reports it.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as omodel
+
+
+def _pad_reference(edge_index, shift, cell, pbc, r_max, num_atoms, capacity):
+    """The rule of ``nqa_neighbor_list_fill_padded`` on the host: edges grouped by centre atom (ascending); atom i gets
+    ``q + (i < rem)`` padding pairs behind its real edges, pair t = ``(i <- i, +-(k0 + t) cells along the shortest periodic
+    lattice vector)``, ``k0 = floor(r_max / |a|) + 1``."""
+    ei = np.asarray(edge_index)
+    sh = np.asarray(shift, dtype=np.float64)
+    E = ei.shape[1]
+    tail = capacity - E
+    assert tail >= 0 and tail % 2 == 0
+    lens = np.linalg.norm(np.asarray(cell, dtype=np.float64).reshape(3, 3), axis=1)
+    cand = [d for d in range(3) if pbc[d]] or [0, 1, 2]
+    axis = min(cand, key=lambda d: (lens[d], d))
+    k0 = int(np.floor(r_max / lens[axis])) + 1
+    q, rem = divmod(tail // 2, num_atoms)
+    out_i, out_j, out_s, rowptr = [], [], [], [0]
+    for i in range(num_atoms):
+        sel = np.nonzero(ei[0] == i)[0]
+        out_i += [i] * len(sel)
+        out_j += ei[1][sel].tolist()
+        out_s += sh[sel].tolist()
+        for t in range(q + (1 if i < rem else 0)):
+            for sgn in (1.0, -1.0):
+                s = [0.0, 0.0, 0.0]
+                s[axis] = sgn * (k0 + t)
+                out_i.append(i)
+                out_j.append(i)
+                out_s.append(s)
+        rowptr.append(len(out_i))
+    return np.array([out_i, out_j], dtype=np.int64), np.array(out_s, dtype=np.float64).reshape(-1, 3), np.array(rowptr)
+
+
+def _cfg(**kw):
+    cfg = dict(r_max=4.0, num_layers=2, l_max=2, parity=True, num_features=8, radial_mlp_depth=1, radial_mlp_width=16,
+               num_bessels=8, polynomial_cutoff_p=6, avg_num_neighbors=14.0, model_dtype="float32")
+    cfg.update(kw)
+    return cfg
+
+
+def _build(cfg, type_names, seed=0):
+    from nequip_amd.model import NequIPGNNModel
+
+    return NequIPGNNModel(
+        seed=seed, model_dtype=cfg["model_dtype"], r_max=cfg["r_max"], type_names=type_names,
+        num_layers=cfg["num_layers"], l_max=cfg["l_max"], parity=cfg["parity"], num_features=cfg["num_features"],
+        radial_mlp_depth=cfg["radial_mlp_depth"], radial_mlp_width=cfg["radial_mlp_width"],
+        num_bessels=cfg["num_bessels"], polynomial_cutoff_p=cfg["polynomial_cutoff_p"],
+        avg_num_neighbors=cfg["avg_num_neighbors"])
+
+
+def _weights(model):
+    return {k.replace("model.func.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def test_padding_edges_carry_no_interaction_in_the_oracle():
+    """The premise of the padded list, on the reference's algorithm as the oracle restates it (float64: exact zeros show)."""
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=2, seed=5)
+    cfg = _cfg(model_dtype="float64")
+    data = syn.make_data(pos, types, cfg["r_max"], cell)
+    order = np.argsort(data["edge_index"][0].numpy(), kind="stable")  # group by centre atom, as the device list is
+    ei = data["edge_index"].numpy()[:, order]
+    sh = data["edge_cell_shift"].numpy()[order]
+    data["edge_index"], data["edge_cell_shift"] = torch.as_tensor(ei), torch.as_tensor(sh)
+    n, E = len(pos), ei.shape[1]
+    pei, psh, rowptr = _pad_reference(ei, sh, cell, (True,) * 3, cfg["r_max"], n, E + 2 * n + 6)
+    assert pei.shape[1] == E + 2 * n + 6 and rowptr[-1] == pei.shape[1]
+    vec = pos[pei[1]] - pos[pei[0]] + psh @ np.asarray(cell).reshape(3, 3)
+    is_pad = np.ones(pei.shape[1], bool)
+    for i in range(n):
+        is_pad[rowptr[i]: rowptr[i] + int((ei[0] == i).sum())] = False
+    assert is_pad.sum() == 2 * n + 6 and np.all(np.linalg.norm(vec[is_pad], axis=1) > cfg["r_max"])
+    padded = dict(data)
+    padded["edge_index"], padded["edge_cell_shift"] = torch.as_tensor(pei), torch.as_tensor(psh)
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        weights = _weights(_build(cfg, names))
+    finally:
+        torch.set_default_dtype(prev)
+    ref = omodel.energy_forces(data, cfg, weights, with_virial=True)
+    out = omodel.energy_forces(padded, cfg, weights, with_virial=True)
+    assert float(ref["forces"].abs().max()) > 1e-3
+    for k in ("total_energy", "forces", "virial"):
+        torch.testing.assert_close(out[k], ref[k], atol=1e-12, rtol=1e-12)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------
+
+
+def _box(seed, n=150, triclinic=True):
+    rng = np.random.default_rng(seed)
+    cell = np.diag([11.0, 9.5, 10.2])
+    if triclinic:
+        cell = cell + rng.uniform(-1.2, 1.2, size=(3, 3))
+    pos = rng.uniform(-0.3, 1.3, size=(n, 3)) @ cell  # (some atoms outside the cell)
+    types = rng.integers(0, 2, size=n)
+    return pos, types, cell
+
+
+def _plain_list(pos, cell, pbc, r_max, device):
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.data._nl import compute_neighborlist_
+
+    d = {K.POSITIONS_KEY: torch.as_tensor(pos, dtype=torch.float64, device=device),
+         K.CELL_KEY: torch.as_tensor(cell, dtype=torch.float64, device=device).view(1, 3, 3),
+         K.PBC_KEY: torch.tensor([list(pbc)], device=device)}
+    d = compute_neighborlist_(d, r_max)
+    return d[K.EDGE_INDEX_KEY].cpu().numpy(), d[K.EDGE_CELL_SHIFT_KEY].cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pbc", [(True, True, True), (True, False, True)])
+@pytest.mark.parametrize("extra", [0, 2, 74, 1000])
+def test_padded_list_is_the_plain_list_plus_the_padding_rule(device, pbc, extra):
+    from nequip_amd.data._nl import PaddedNeighborList
+
+    pos, _, cell = _box(3)
+    r_max = 4.0
+    ei, sh = _plain_list(pos, cell, pbc, r_max, device)
+    E, n = ei.shape[1], len(pos)
+    assert E % 2 == 0 and E > 1000
+    nl = PaddedNeighborList(n, r_max, torch.as_tensor(cell, device=device), pbc, E + extra, shift_dtype=torch.float64)
+    pei, psh, rowptr = nl.build(torch.as_tensor(pos, dtype=torch.float64, device=device))
+    fits, e_real = nl.status()
+    assert fits and e_real == E
+    wi, ws, wr = _pad_reference(ei, sh, cell, pbc, r_max, n, E + extra)
+    assert np.array_equal(pei.cpu().numpy(), wi)
+    assert np.array_equal(psh.cpu().numpy(), ws)
+    assert np.array_equal(rowptr.cpu().numpy(), wr)
+    # the padding is invisible to anything with a cutoff: every padding edge is longer than r_max
+    vec = pos[wi[1]] - pos[wi[0]] + ws @ cell
+    lengths = np.linalg.norm(vec, axis=1)
+    assert int((lengths < r_max).sum()) == E
+
+
+@pytest.mark.gpu
+def test_list_that_does_not_fit_is_reported_and_stays_in_range(device):
+    from nequip_amd.data._nl import PaddedNeighborList
+
+    pos, _, cell = _box(4)
+    r_max, n = 4.0, len(pos)
+    ei, _ = _plain_list(pos, cell, (True,) * 3, r_max, device)
+    E = ei.shape[1]
+    nl = PaddedNeighborList(n, r_max, torch.as_tensor(cell, device=device), True, E - 10, shift_dtype=torch.float64)
+    pei, psh, rowptr = nl.build(torch.as_tensor(pos, dtype=torch.float64, device=device))
+    fits, e_real = nl.status()
+    assert not fits and e_real == E
+    pei, psh, rowptr = pei.cpu().numpy(), psh.cpu().numpy(), rowptr.cpu().numpy()
+    assert rowptr[0] == 0 and rowptr[-1] == E - 10 and np.all(np.diff(rowptr) >= 0)
+    assert np.array_equal(pei[0], pei[1]) and np.array_equal(pei[0], np.repeat(np.arange(n), np.diff(rowptr)))
+    assert np.all(np.linalg.norm(psh @ cell, axis=1) > r_max)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [16, 128])
+def test_model_on_a_padded_list_equals_model_on_the_plain_list(device, width):
+    """(width 128: the matrix-core radial kernels, whose per-row scaling meets all-zero rows here)"""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.data._nl import PaddedNeighborList, compute_neighborlist_, compute_neighborlist_padded_
+
+    pos, types, cell = _box(6, n=200)
+    cfg = _cfg(radial_mlp_width=width, num_features=16 if width == 16 else 64)
+    model = _build(cfg, ["A", "B"]).to(device).eval()
+    base = {K.POSITIONS_KEY: torch.as_tensor(pos, dtype=torch.float32, device=device),
+            K.ATOM_TYPE_KEY: torch.as_tensor(types, device=device),
+            K.CELL_KEY: torch.as_tensor(cell, dtype=torch.float32, device=device).view(1, 3, 3),
+            K.PBC_KEY: torch.tensor([[True, True, True]], device=device)}
+    plain = compute_neighborlist_(dict(base), cfg["r_max"])
+    E = plain[K.EDGE_INDEX_KEY].shape[1]
+    ref = model(plain)
+    nl = PaddedNeighborList(len(pos), cfg["r_max"], base[K.CELL_KEY][0], True, E + 2 * len(pos) + 46)
+    out = model(compute_neighborlist_padded_(dict(base), nl))
+    assert nl.status() == (True, E)
+    fscale = float(ref[K.FORCE_KEY].abs().max())
+    assert fscale > 1e-3
+    torch.testing.assert_close(out[K.TOTAL_ENERGY_KEY], ref[K.TOTAL_ENERGY_KEY], atol=1e-5 * len(pos), rtol=1e-6)
+    torch.testing.assert_close(out[K.FORCE_KEY], ref[K.FORCE_KEY], atol=2e-6 * max(1.0, fscale), rtol=1e-5)
+    assert bool(torch.isfinite(out[K.FORCE_KEY]).all())
+
+
+def _eager(model, pos, types, cell, r_max):
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.data._nl import compute_neighborlist_
+
+    d = {K.POSITIONS_KEY: pos, K.ATOM_TYPE_KEY: types, K.CELL_KEY: cell.view(1, 3, 3),
+         K.PBC_KEY: torch.tensor([[True, True, True]], device=pos.device)}
+    out = model(compute_neighborlist_(d, r_max))
+    return out[K.TOTAL_ENERGY_KEY].detach().clone(), out[K.FORCE_KEY].detach().clone(), d[K.EDGE_INDEX_KEY].shape[1]
+
+
+@pytest.mark.gpu
+def test_replayed_steps_follow_moving_atoms_and_grow_with_the_list(device):
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.integrations.graphed_step import GraphedStep
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=5, seed=2)  # 375 atoms
+    cfg = _cfg(radial_mlp_width=64, num_features=32, r_max=4.5, avg_num_neighbors=38.0)
+    model = _build(cfg, names).to(device).eval()
+    pos_t = torch.as_tensor(pos, dtype=torch.float64, device=device)
+    types_t = torch.as_tensor(types, device=device)
+    cell_t = torch.as_tensor(np.asarray(cell).reshape(3, 3), dtype=torch.float64, device=device)
+    step = GraphedStep(model, types_t, cell_t, True, cfg["r_max"], headroom=1.02)
+    gen = torch.Generator(device=device).manual_seed(1)
+    edges = set()
+    for it in range(6):
+        p = pos_t + 0.05 * it * torch.randn(pos_t.shape, generator=gen, device=device, dtype=pos_t.dtype)
+        out = step(p)
+        e_ref, f_ref, E = _eager(model, p, types_t, cell_t, cfg["r_max"])
+        edges.add(E)
+        assert step.last_num_edges == E
+        fscale = float(f_ref.abs().max())
+        torch.testing.assert_close(out[K.TOTAL_ENERGY_KEY], e_ref, atol=1e-5 * len(pos), rtol=1e-6)
+        torch.testing.assert_close(out[K.FORCE_KEY], f_ref, atol=5e-6 * max(1.0, fscale), rtol=1e-5)
+    assert len(edges) > 1, "degenerate test: the list never changed"
+    assert step.num_captures == 1 and step.num_eager_fallbacks == 0
+    # a list that outgrows its slots: the box and everything in it shrinks by 7 % (more neighbours per atom; also the
+    # variable-cell entry point)
+    p, small = 0.93 * pos_t, 0.93 * cell_t
+    cap = step.edge_capacity
+    step.set_cell(small)
+    out = step(p)
+    e_ref, f_ref, E = _eager(model, p, types_t, small, cfg["r_max"])
+    assert E > cap and step.num_captures == 2 and step.edge_capacity >= E
+    fscale = float(f_ref.abs().max())
+    torch.testing.assert_close(out[K.TOTAL_ENERGY_KEY], e_ref, atol=1e-5 * len(pos), rtol=1e-6)
+    torch.testing.assert_close(out[K.FORCE_KEY], f_ref, atol=5e-6 * max(1.0, fscale), rtol=1e-5)
+    # ... and the new graph keeps serving (back in the original box)
+    step.set_cell(cell_t)
+    out = step(pos_t)
+    e_ref, f_ref, _ = _eager(model, pos_t, types_t, cell_t, cfg["r_max"])
+    torch.testing.assert_close(out[K.FORCE_KEY], f_ref, atol=5e-6 * max(1.0, float(f_ref.abs().max())), rtol=1e-5)
+    assert step.num_captures == 2
+
+
+@pytest.mark.gpu
+def test_deferred_verdict_on_a_list_that_does_not_pair_up_stays_in_bounds(device):
+    """Two directed edges removed from a symmetric list: with the verdict deferred the evaluation runs to the end on clamped
+    rows and empty owner lists, and the flag says so (results void)."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.data._nl import compute_neighborlist_
+    from nequip_amd.nn._topology import topology_cache
+
+    pos, types, cell = _box(8, n=120)
+    cfg = _cfg(radial_mlp_width=64, num_features=32)
+    model = _build(cfg, ["A", "B"]).to(device).eval()
+    d = {K.POSITIONS_KEY: torch.as_tensor(pos, dtype=torch.float32, device=device),
+         K.ATOM_TYPE_KEY: torch.as_tensor(types, device=device),
+         K.CELL_KEY: torch.as_tensor(cell, dtype=torch.float32, device=device).view(1, 3, 3),
+         K.PBC_KEY: torch.tensor([[True, True, True]], device=device)}
+    d = compute_neighborlist_(d, cfg["r_max"])
+    ei, sh = d[K.EDGE_INDEX_KEY], d[K.EDGE_CELL_SHIFT_KEY]
+    E = ei.shape[1]
+    keep = torch.ones(E, dtype=torch.bool, device=device)
+    keep[[5, E // 2 + 3]] = False  # (two edges of different pairs: still an even count)
+    d[K.EDGE_INDEX_KEY], d[K.EDGE_CELL_SHIFT_KEY] = ei[:, keep].contiguous(), sh[keep].contiguous()
+    topology_cache.clear()
+    topo = topology_cache.get(d[K.EDGE_INDEX_KEY][0], d[K.EDGE_INDEX_KEY][1], len(pos))
+    topo.defer_pairing_verdict = True
+    out = model(d)
+    torch.cuda.synchronize()
+    assert topo.pairing_ok is not None and int(topo.pairing_ok.item()) == 0
+    assert out[K.FORCE_KEY].shape == (len(pos), 3)
+    topology_cache.clear()
+    # the same list through the ordinary path (verdict read, per-edge evaluation) is fine
+    ref = model(d)
+    assert bool(torch.isfinite(ref[K.FORCE_KEY]).all())
