@@ -833,6 +833,38 @@ def main():
                 step_eager()
             torch.cuda.synchronize()
 
+    # ---- the molecular-dynamics form of the step: NEW positions and a NEW device neighbour list every step, the whole
+    # evaluation (list -> pairing -> model) replayed as one hipGraph (integrations/graphed_step.py).  Reported next to the
+    # headline, never as `value`: the headline's list is static, as BASELINE.json's metric is.
+    md_step = None
+    if (rank == 0 and world == 1 and use_graph and args.workload == "water10k" and "cell" in data
+            and os.environ.get("NQA_BENCH_NO_MD_STEP", "") in ("", "0")):
+        try:
+            from nequip_amd.integrations.graphed_step import GraphedStep
+
+            gstep = GraphedStep(model, data["atom_types"].view(-1), data["cell"].view(3, 3), True, float(cfg["r_max"]))
+            gen = torch.Generator(device=device).manual_seed(1234)
+            moves = [0.02 * torch.randn(static_pos.shape, generator=gen, device=device, dtype=static_pos.dtype)
+                     for _ in range(8)]
+            for i in range(3):
+                gstep(static_pos + moves[i])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                gstep(static_pos + moves[i % len(moves)])
+            torch.cuda.synchronize()
+            md_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            md_step = {
+                "ms_per_step": md_ms, "atom_steps_per_s": n_atoms / (md_ms * 1e-3),
+                "edge_slots": gstep.edge_capacity, "last_num_edges": gstep.last_num_edges,
+                "captures": gstep.num_captures, "eager_fallbacks": gstep.num_eager_fallbacks,
+                "what": "positions perturbed every step -> device neighbour list (capacity-padded) -> pairing -> "
+                        "energy+forces, one hipGraph replay per step; includes the per-step read of the step's flags",
+            }
+            del gstep
+        except Exception as exc:  # pragma: no cover
+            print(f"[bench] MD-step variant failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+
     # ---- per-kernel HIP-event timing of the hand-written kernels (eager, on the launching stream) ------
     roofline = step_roofline = None
     kernels = {}
@@ -892,6 +924,7 @@ def main():
                                if os.environ.get("NQA_MLP_EXACT_FP32", "") in ("", "0") else
                                "fp32 throughout: GEMMs on the exact-fp32 MFMA pipe (v_mfma_f32_32x32x2_f32)"),
                 "exact_fp32_ms_per_step": exact_ms,
+                "md_step": md_step,
                 "gpu_state": gpu_state,
                 "gpu_clock_mhz": (((gpu_state or {}).get("dpm_sclk_mhz") or (gpu_state or {}).get("sclk_mhz") or {}).get("median")
                                   if gpu_state else None),

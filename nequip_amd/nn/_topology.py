@@ -203,6 +203,8 @@ class EdgeTopology:
         if self._side_ready is not None:
             return
         cur = torch.cuda.current_stream(self.device)
+        if os.environ.get("NQA_PAIR_ON_MAIN", "") not in ("", "0"):  # (experiment: only the backward's lists on `side`)
+            self.pairing_if_known(shifts)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             # (a deferred verdict: the pairing itself starts here too, next to the edge vectors / type embedding on `cur`)

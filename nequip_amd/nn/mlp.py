@@ -4,6 +4,7 @@
 path: on the GPU it runs through the fused MFMA kernel of ``nequip_amd/csrc/radial_mlp.hip`` when available
 for its shape, otherwise through hipBLASLt ``mm``."""
 
+import contextlib
 import os
 from math import sqrt
 from typing import Optional
@@ -266,7 +267,9 @@ class _RadialMLPTrainFn(torch.autograd.Function):
         emb = emb.contiguous()
         out = _launch_fwd(emb, w0.detach(), w1.detach(), alpha0, alpha1, mode, cache)
         ctx.save_for_backward(emb, w0, w1)
-        ctx.args = (alpha0, alpha1, mode, cache)
+        from ..utils import wgrad as _wg
+
+        ctx.args = (alpha0, alpha1, mode, cache, _wg.is_param_side(w1))
         return out
 
     @staticmethod
@@ -287,7 +290,8 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
     training epilogues: there the pieces are composed from ATen ops around the first-order kernels."""
 
     @staticmethod
-    def forward(ctx, emb, w0, w1, g, alpha0: float, alpha1: float, mode: int, cache: _WeightImages):
+    def forward(ctx, emb, w0, w1, g, alpha0: float, alpha1: float, mode: int, cache: _WeightImages,
+                param_side: bool = False):
         from ..utils import wgrad as _wg
 
         g = g.contiguous()
@@ -299,7 +303,10 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
         elif mode == _lib.NQA_MLP_BF16X6:
             g_emb, h, p0 = _launch_bwd_train(emb, w0d, w1d, alpha0, alpha1, g, None, mode, cache)
             g_w0 = p0 * alpha0
-            g_w1 = _launch_wgrad(h, g) * alpha1
+            # (parameter-side weights, first order: the split-K product, its sum and the scaling next to the data chain)
+            side = param_side and not torch.is_grad_enabled()
+            with (_wg.parameter_side(g.device, h, g) if side else contextlib.nullcontext()):
+                g_w1 = _launch_wgrad(h, g) * alpha1
         else:
             g_emb = _launch_bwd(emb, w0d, w1d, alpha0, alpha1, g, mode, cache)
             P = emb @ (w0d * alpha0)
@@ -308,6 +315,7 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
             g_w0 = _launch_wgrad(emb, (g @ (w1d * alpha1).t()) * s1) * alpha0
         ctx.save_for_backward(emb, w0, w1, g)
         ctx.args = (alpha0, alpha1, mode, cache)
+        ctx.param_side = param_side
         ctx.mark_non_differentiable(*[t for t in (g_w0, g_w1) if t is not None])
         return g_emb, g_w0, g_w1
 
@@ -325,10 +333,14 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
             if need_emb or need_w0 or need_w1:
                 d_emb, R, p0 = _launch_bwd_train(emb, w0d, w1d, alpha0, alpha1, g, c, mode, cache)
                 d_w0 = p0 * alpha0 if need_w0 else None
-                d_w1 = _launch_wgrad(R, g) * alpha1 if need_w1 else None
+                if need_w1:
+                    from ..utils import wgrad as _wg
+
+                    with (_wg.parameter_side(g.device, R, g) if ctx.param_side else contextlib.nullcontext()):
+                        d_w1 = _launch_wgrad(R, g) * alpha1
             if need_g:
                 d_g = _launch_fwd_tangent(emb, c, w0d, w1d, alpha0, alpha1, mode, cache)
-            return d_emb, d_w0, d_w1, d_g, None, None, None, None
+            return d_emb, d_w0, d_w1, d_g, None, None, None, None, None
         W0, W1 = w0d * alpha0, w1d * alpha1
         P = emb @ W0
         s1, s2 = _silu_derivs(P)
@@ -342,7 +354,7 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
             d_w1 = _launch_wgrad(R, g) * alpha1
         if need_w0:
             d_w0 = (_launch_wgrad(emb, cotP) + _launch_wgrad(c, G_h * s1)) * alpha0
-        return d_emb, d_w0, d_w1, d_g, None, None, None, None
+        return d_emb, d_w0, d_w1, d_g, None, None, None, None, None
 
 
 class ScalarLinearLayer(torch.nn.Module):
@@ -470,8 +482,18 @@ class ScalarMLPFunction(_WeightCacheMixin, torch.nn.Module):
             cache.validate(self.mlp[2].weight)
             diff = differentiable_parameters(self.training, self.mlp[0].weight, self.mlp[2].weight)
             if diff and os.environ.get("NQA_MLP_TRAIN_ATEN", "") in ("", "0"):
-                return _RadialMLPTrainFn.apply(x, self.mlp[0].weight, self.mlp[2].weight, self._alphas[0],
-                                               self._alphas[1], radial_mlp_mode(), cache)
+                # the parameters enter through views made on the parameter-side stream: the consumers of their gradients --
+                # the views' adjoints, AccumulateGrad -- are then nodes of that stream, and the parameter-gradient launches
+                # of the backward pass run there, next to the data chain (utils/wgrad.py)
+                from ..utils import wgrad as _wg
+
+                w0, w1 = self.mlp[0].weight, self.mlp[2].weight
+                with _wg.parameter_side(x.device) as side:
+                    if side is not None:
+                        w0, w1 = w0.view_as(w0), w1.view_as(w1)
+                if side is not None:
+                    _wg.publish(x.device, w0, w1)
+                return _RadialMLPTrainFn.apply(x, w0, w1, self._alphas[0], self._alphas[1], radial_mlp_mode(), cache)
             if not diff:
                 return _RadialMLPFn.apply(x, self.mlp[0].weight.detach(), self.mlp[2].weight.detach(),
                                           self._alphas[0], self._alphas[1], radial_mlp_mode(), cache)

@@ -10,6 +10,7 @@ Builds the chunk / instruction tables from irreps bookkeeping and wraps the laun
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import struct
@@ -205,6 +206,7 @@ class _NodeLinearFn(torch.autograd.Function):
         out = _launch_linear(x, wp, addend, types, meta, "fwd", scale)
         ctx.save_for_backward(x, wp, types)
         ctx.meta, ctx.scale, ctx.has_addend = meta, scale, addend is not None
+        ctx.param_side = _wgrad.is_param_side(wp)  # the consumers of grad(wp) are nodes of the parameter-side stream
         return out
 
     @staticmethod
@@ -212,12 +214,16 @@ class _NodeLinearFn(torch.autograd.Function):
         x, wp, types = ctx.saved_tensors
         meta: NodeLinearMeta = ctx.meta
         gx = gwp = gadd = None
+        if ctx.needs_input_grad[1] and _wgrad.param_grads_wanted():
+            # first-order parameter gradient of a parameter-side weight tensor: on the parameter-side stream, next to the data
+            # chain (no join here: its consumers are nodes of that stream, utils/wgrad.py)
+            side = ctx.param_side and not torch.is_grad_enabled() and _wgrad.supported(x, g)
+            with (_wgrad.parameter_side(x.device, x, g, types) if side else contextlib.nullcontext()):
+                gwp = _weight_grad(x, g, types, meta, wp.shape[0])
+                if ctx.scale != 1.0:
+                    gwp = gwp * ctx.scale
         if ctx.needs_input_grad[0]:
             gx = _NodeLinearFn.apply(g, meta_transposed_weights(meta, wp), None, types, _transposed(meta), ctx.scale)
-        if ctx.needs_input_grad[1] and _wgrad.param_grads_wanted():
-            gwp = _weight_grad(x, g, types, meta, wp.shape[0])
-            if ctx.scale != 1.0:
-                gwp = gwp * ctx.scale
         if ctx.has_addend and ctx.needs_input_grad[2]:
             gadd = g
         return gx, gwp, gadd, None, None, None
@@ -250,7 +256,12 @@ def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Ten
         hit = getattr(wp, "_nqa_step_transposed", None)
         if hit is not None and hit[0] is meta and (hit[1].requires_grad or not torch.is_grad_enabled()):
             return hit[1]
-        wt = meta.transpose_weights(wp)
+        if _wgrad.is_param_side(wp):  # (the transposed copy of a parameter-side tensor is one too)
+            with _wgrad.parameter_side(wp.device):
+                wt = meta.transpose_weights(wp)
+            _wgrad.publish(wp.device, wt)
+        else:
+            wt = meta.transpose_weights(wp)
         # inside a backward pass that builds no graph this copy does not require grad although it changes every step
         wt._nqa_volatile = True
         wt._nqa_adjoint_src = (_transposed(meta), weakref.ref(wp))

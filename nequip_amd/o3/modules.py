@@ -18,7 +18,7 @@ import torch
 
 from .irreps import Irrep, Irreps
 from ._node_kernels import GateMeta, NodeLinearMeta, gate as _gate_kernel, node_linear as _node_linear
-from ..utils.wgrad import _WeightCacheMixin, differentiable_parameters
+from ..utils.wgrad import _WeightCacheMixin, differentiable_parameters, parameter_side, publish
 
 
 from ..utils.tracing import traceable
@@ -66,7 +66,9 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
             # eval mode: parameter gradients are not produced (inference fast path, as for the radial MLP) unless
             # nequip_amd.utils.wgrad.eval_parameter_gradients(True) asks for the reference's behaviour
             if differentiable_parameters(self.training, self.weight):
-                wp = (self.weight * self._scale_vec).unsqueeze(0)
+                with parameter_side(x.device):  # (utils/wgrad.py: parameter-side work has its own stream in training)
+                    wp = (self.weight * self._scale_vec).unsqueeze(0)
+                publish(x.device, wp)
             else:
                 wp = self.eval_weights(x.device, x.dtype)
             return _node_linear(x, wp, None, self._meta, addend=addend, scale=scale)
@@ -280,7 +282,9 @@ class FullyConnectedTensorProduct(_WeightCacheMixin, torch.nn.Module):
                 return _skinny_mm(table, weight.index_select(0, perm).view(table.shape[1], -1) * scale)
 
             if differentiable_parameters(self.training, self.weight):
-                wp = contract(self.weight, table)
+                with parameter_side(x.device, table):
+                    wp = contract(self.weight, table)
+                publish(x.device, wp)
             else:  # constants in eval mode: contracted once per (weight, table) version
                 wp = self.eval_weights_typed(table, x.dtype)
             return _node_linear(x, wp, types.view(-1).contiguous(), self._meta)

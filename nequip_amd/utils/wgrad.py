@@ -11,6 +11,7 @@ including parameter-gradient outputs that the engine then throws away (built-in 
 
 import contextlib
 import ctypes
+import os
 import struct
 import threading
 from typing import Optional, Sequence, Tuple
@@ -66,6 +67,79 @@ def differentiable_parameters(module_training: bool, *params: torch.Tensor) -> b
     if module_training:
         return True
     return _eval_param_grads and torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
+# ---- parameter-side stream (training) --------------------------------------------------------------------------------------
+# A training step has two kinds of work: the DATA chain (activations forward, their gradients backward: the critical path) and
+# PARAMETER-side work (weights prepared from the parameters in the forward pass; in the backward pass the parameter gradients
+# ``A^T B`` -- ``nqa_wgrad`` launches, their split-K sums, scalings -- the adjoints of the weight preparation and the
+# accumulation into ``.grad``).  Nothing on the data chain waits for a parameter gradient, but on ONE stream they run in line
+# with it: ~1.5 of 7 ms at the cfg-4 shape (``profiles/r5_train_timeline.txt``: one queue, 414 kernels).
+#
+# The autograd engine runs every backward node on the stream its forward ran on, synchronises consumer with producer streams
+# itself and joins all streams at the end of ``backward()``.  So: the weight preparation of a module runs on a per-device side
+# stream in the forward pass (``parameter_side`` + ``publish``; the tensor it yields is marked), and a ``Function.backward``
+# that finds the mark launches its parameter-gradient kernels on that same stream (``parameter_side`` again, no join): their
+# consumers -- the adjoint of the preparation, ``AccumulateGrad`` -- are nodes of that stream, the data chain goes on.
+#
+# MEASURED, AND OFF BY DEFAULT (``NQA_PARAM_STREAM=1`` switches it on).  Same box, cfg-4-shaped step as one hipGraph
+# (``profiles/r5_train_param_stream_ab.txt``): 6.65 ms on one stream, 6.98-7.02 ms with the parameter-side stream; identical
+# losses and parameter gradients (``tests/test_training_step.py`` etc. pass either way).  The ``AccumulateGrad`` nodes of the
+# parameters outlive an iteration (hooks of the DDP wrapper and the optimizer hold them) and keep the stream they were created
+# on, so every parameter gradient is handed back to the main stream the moment it is produced (the engine warns about exactly
+# that): the data chain waits for each split-K product after all, and ~60 cross-stream dependencies per step cost more than
+# the overlap of one ``grad_x`` kernel per site returns.  What would help is keeping parameter gradients out of autograd
+# (accumulated by the side stream into a bucket that is joined once, before the optimizer); not built.
+_param_streams = {}
+
+
+def param_stream(device) -> Optional["torch.cuda.Stream"]:
+    if os.environ.get("NQA_PARAM_STREAM", "0") in ("", "0"):
+        return None
+    device = torch.device(device)
+    if device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _param_streams.get(idx)
+    if s is None:
+        s = _param_streams[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+@contextlib.contextmanager
+def parameter_side(device, *reads):
+    """Body on the parameter-side stream, ordered behind what the current stream has queued; ``reads``: tensors of the current
+    stream that the body reads (kept from being recycled under it).  Yields the stream (``None``: switched off, body runs
+    where it is)."""
+    side = param_stream(device)
+    if side is None:
+        yield None
+        return
+    cur = torch.cuda.current_stream(device)
+    side.wait_stream(cur)
+    for t in reads:
+        if t is not None and t.is_cuda:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        yield side
+
+
+def publish(device, *tensors) -> None:
+    """After parameter-side work whose results the CURRENT stream reads (a forward pass): wait for it, mark the results as
+    parameter-side tensors (``Function.backward`` looks for the mark)."""
+    side = param_stream(device)
+    if side is None:
+        return
+    cur = torch.cuda.current_stream(device)
+    cur.wait_stream(side)
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(cur)
+            t._nqa_param_side = True
+
+
+def is_param_side(t) -> bool:
+    return bool(getattr(t, "_nqa_param_side", False)) and param_stream(t.device) is not None
 
 
 class _WeightCacheMixin:
