@@ -107,6 +107,8 @@ class NequIPCalculator(Calculator):
         self._graphed = None  # (identity of the atoms, GraphedStep, cell as last written)
         if self.graphed_md and self.transforms:
             raise ValueError("graphed_md replays a fixed pipeline: it cannot run user transforms")
+        if self.graphed_md and type(model).__name__ == "DictInputOutputWrapper":
+            raise ValueError("graphed_md needs the eager nequip_amd model: a compiled package's graph is fixed at export time")
         # chemical symbol -> atom type index (`ChemicalSpeciesToAtomTypeMapper`, nequip/data/transforms): a list means
         # "type_names are chemical symbols in this order", a dict maps symbol -> type name
         type_names = list(getattr(model, "type_names", []) or [])

@@ -149,7 +149,7 @@ class GraphedStep:
             if self._capacity is None:
                 self._capacity = int(self._first_capacity() * self.headroom) + 2
             self._capture()
-        while True:
+        for _ in range(4):
             self._graph.replay()
             bad, num_edges, paired = self._flags.cpu().tolist()  # (the step's one synchronisation, with its results)
             self.last_num_edges = int(num_edges)
@@ -158,7 +158,9 @@ class GraphedStep:
                 self._capacity = max(int(num_edges * self.headroom) + 2, self._capacity + 2)
                 self._capture()
                 continue
-            if not paired:
-                self.num_eager_fallbacks += 1
-                return self._evaluate_eager()
-            return self._out
+            if paired:
+                return self._out
+            break
+        # a list that does not pair up (or that no capacity fits: an odd edge count, i.e. not symmetric): the ordinary path
+        self.num_eager_fallbacks += 1
+        return self._evaluate_eager()

@@ -286,3 +286,39 @@ def test_deferred_verdict_on_a_list_that_does_not_pair_up_stays_in_bounds(device
     # the same list through the ordinary path (verdict read, per-edge evaluation) is fine
     ref = model(d)
     assert bool(torch.isfinite(ref[K.FORCE_KEY]).all())
+
+
+@pytest.mark.gpu
+def test_cell_thinner_than_the_cutoff_pads_behind_real_self_images(device):
+    """A two-atom cell of 3.1 A with a 4 A cutoff: real self-image edges (i <- i, S) exist next to the padding ones (longer
+    shifts along the same axis); the padded list still is the plain list plus the rule, pairs up, and replays correctly."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.data._nl import PaddedNeighborList
+    from nequip_amd.integrations.graphed_step import GraphedStep
+
+    cell = np.array([[3.1, 0.0, 0.0], [0.3, 3.3, 0.0], [0.1, -0.2, 3.6]])
+    pos = np.array([[0.1, 0.2, 0.3], [1.6, 1.5, 1.9]])
+    types = np.array([0, 1])
+    r_max = 4.0
+    ei, sh = _plain_list(pos, cell, (True,) * 3, r_max, device)
+    E = ei.shape[1]
+    assert int(((ei[0] == ei[1])).sum()) > 0, "degenerate test: no self images"
+    nl = PaddedNeighborList(2, r_max, torch.as_tensor(cell, device=device), True, E + 10, shift_dtype=torch.float64)
+    pei, psh, rowptr = nl.build(torch.as_tensor(pos, dtype=torch.float64, device=device))
+    assert nl.status() == (True, E)
+    wi, ws, wr = _pad_reference(ei, sh, cell, (True,) * 3, r_max, 2, E + 10)
+    assert np.array_equal(pei.cpu().numpy(), wi) and np.array_equal(psh.cpu().numpy(), ws)
+    assert len({tuple(r) for r in np.concatenate([wi.T, ws], axis=1).tolist()}) == E + 10  # no duplicate (i, j, S)
+    cfg = _cfg(radial_mlp_width=64, num_features=32)
+    model = _build(cfg, ["A", "B"]).to(device).eval()
+    pos_t = torch.as_tensor(pos, dtype=torch.float64, device=device)
+    types_t = torch.as_tensor(types, device=device)
+    cell_t = torch.as_tensor(cell, dtype=torch.float64, device=device)
+    step = GraphedStep(model, types_t, cell_t, True, r_max, headroom=1.1)
+    for shift in (0.0, 0.04):
+        p = pos_t + shift
+        out = step(p)
+        e_ref, f_ref, _ = _eager(model, p, types_t, cell_t, r_max)
+        torch.testing.assert_close(out[K.TOTAL_ENERGY_KEY], e_ref, atol=1e-5, rtol=1e-6)
+        torch.testing.assert_close(out[K.FORCE_KEY], f_ref, atol=5e-6 * max(1.0, float(f_ref.abs().max())), rtol=1e-5)
+    assert step.num_eager_fallbacks == 0
