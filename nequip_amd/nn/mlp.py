@@ -305,8 +305,11 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
             g_w0 = p0 * alpha0
             # (parameter-side weights, first order: the split-K product, its sum and the scaling next to the data chain)
             side = param_side and not torch.is_grad_enabled()
-            with (_wg.parameter_side(g.device, h, g) if side else contextlib.nullcontext()):
-                g_w1 = _launch_wgrad(h, g) * alpha1
+            if w1.is_leaf and w1.requires_grad and _wg.deferring():
+                _wg.defer(w1, lambda: _launch_wgrad(h, g) * alpha1, h, g)  # (deferred parameter gradients, utils/wgrad.py)
+            else:
+                with (_wg.parameter_side(g.device, h, g) if side else contextlib.nullcontext()):
+                    g_w1 = _launch_wgrad(h, g) * alpha1
         else:
             g_emb = _launch_bwd(emb, w0d, w1d, alpha0, alpha1, g, mode, cache)
             P = emb @ (w0d * alpha0)
@@ -336,8 +339,11 @@ class _RadialMLPTrainBwdFn(torch.autograd.Function):
                 if need_w1:
                     from ..utils import wgrad as _wg
 
-                    with (_wg.parameter_side(g.device, R, g) if ctx.param_side else contextlib.nullcontext()):
-                        d_w1 = _launch_wgrad(R, g) * alpha1
+                    if w1.is_leaf and w1.requires_grad and _wg.deferring():
+                        _wg.defer(w1, lambda: _launch_wgrad(R, g) * alpha1, R, g)
+                    else:
+                        with (_wg.parameter_side(g.device, R, g) if ctx.param_side else contextlib.nullcontext()):
+                            d_w1 = _launch_wgrad(R, g) * alpha1
             if need_g:
                 d_g = _launch_fwd_tangent(emb, c, w0d, w1d, alpha0, alpha1, mode, cache)
             return d_emb, d_w0, d_w1, d_g, None, None, None, None, None

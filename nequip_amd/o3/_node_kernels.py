@@ -207,6 +207,7 @@ class _NodeLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, wp, types)
         ctx.meta, ctx.scale, ctx.has_addend = meta, scale, addend is not None
         ctx.param_side = _wgrad.is_param_side(wp)  # the consumers of grad(wp) are nodes of the parameter-side stream
+        ctx.param_link = getattr(wp, "_nqa_param", None)  # (parameter, scale vector, wp is the transposed copy)
         return out
 
     @staticmethod
@@ -214,7 +215,23 @@ class _NodeLinearFn(torch.autograd.Function):
         x, wp, types = ctx.saved_tensors
         meta: NodeLinearMeta = ctx.meta
         gx = gwp = gadd = None
-        if ctx.needs_input_grad[1] and _wgrad.param_grads_wanted():
+        link = ctx.param_link
+        if (ctx.needs_input_grad[1] and link is not None and wp.shape[0] == 1 and _wgrad.deferring()
+                and _wgrad.supported(x, g)):
+            # deferred parameter gradients (utils/wgrad.py): product, sum and scalings on the side stream, straight into the
+            # parameter's bucket; autograd gets nothing for `wp` from this node
+            param, scale_vec, transposed = link
+            scale = ctx.scale
+
+            def make():
+                gw = _weight_grad(x, g, types, meta, 1)
+                if transposed:  # this node ran on the transposed copy: back to the layout of the parameter
+                    gw = meta.transpose_weights(gw)
+                gw = gw.view(-1) * scale_vec
+                return gw * scale if scale != 1.0 else gw
+
+            _wgrad.defer(param, make, x, g)
+        elif ctx.needs_input_grad[1] and _wgrad.param_grads_wanted():
             # first-order parameter gradient of a parameter-side weight tensor: on the parameter-side stream, next to the data
             # chain (no join here: its consumers are nodes of that stream, utils/wgrad.py)
             side = ctx.param_side and not torch.is_grad_enabled() and _wgrad.supported(x, g)
@@ -262,6 +279,9 @@ def meta_transposed_weights(meta: NodeLinearMeta, wp: torch.Tensor) -> torch.Ten
             _wgrad.publish(wp.device, wt)
         else:
             wt = meta.transpose_weights(wp)
+        link = getattr(wp, "_nqa_param", None)
+        if link is not None:
+            wt._nqa_param = (link[0], link[1], not link[2])
         # inside a backward pass that builds no graph this copy does not require grad although it changes every step
         wt._nqa_volatile = True
         wt._nqa_adjoint_src = (_transposed(meta), weakref.ref(wp))

@@ -69,6 +69,8 @@ class Linear(_WeightCacheMixin, torch.nn.Module):
                 with parameter_side(x.device):  # (utils/wgrad.py: parameter-side work has its own stream in training)
                     wp = (self.weight * self._scale_vec).unsqueeze(0)
                 publish(x.device, wp)
+                # (what grad(wp) means for the parameter: lets the backward deliver it outside autograd, utils/wgrad.py)
+                wp._nqa_param = (self.weight, self._scale_vec, False)
             else:
                 wp = self.eval_weights(x.device, x.dtype)
             return _node_linear(x, wp, None, self._meta, addend=addend, scale=scale)

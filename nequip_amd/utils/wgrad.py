@@ -142,6 +142,103 @@ def is_param_side(t) -> bool:
     return bool(getattr(t, "_nqa_param_side", False)) and param_stream(t.device) is not None
 
 
+# ---- deferred parameter gradients (training) --------------------------------------------------------------------------------
+# The way out named above: inside ``with deferred_parameter_gradients():`` (around ``loss.backward()``) the Functions whose
+# weights are a plain function of ONE parameter (``o3.Linear``: ``weight * scale_vec``, also through its transposed copy; the
+# radial MLP's last layer) do not hand their parameter gradient to autograd.  They launch the split-K product, its sum and the
+# scalings on a side stream, add the result into a bucket there and return ``None``; the data chain never waits for them.  On
+# leaving the block the current stream waits for the side stream ONCE and the bucket goes into ``.grad`` (set, or added to what
+# autograd delivered by other routes).  Same kernels as through autograd; the per-parameter sums may be taken in another order
+# (losses agree to 1e-7).  ``NQA_DEFER_PARAM_GRADS=0`` makes the block a no-op.
+#
+# Measured (``profiles/r5_train_deferred_grads_ab.txt``, cfg-4-shaped step as one hipGraph, same box): 6.65-6.69 -> 6.37-6.39 ms
+# -- but ONLY with the side launches trailing by one site (``NQA_DEFER_LAG``, default 1).  Launched at the fork itself the step
+# got SLOWER (6.63 -> 6.9 ms): in a captured graph the first node created behind a fork continues on the parent's queue and
+# later ones move to another; with the side work created first, the data chain hopped queues at every one of ~25 forks (10-40 us
+# of idle time each, ``profiles/r5_train_timeline.txt``'s sibling trace).  Created one site late, the side work is the later
+# child and the data chain stays where it is.
+_deferred = None
+_defer_streams = {}
+
+
+def _defer_stream(device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _defer_streams.get(idx)
+    if s is None:
+        s = _defer_streams[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+@contextlib.contextmanager
+def deferred_parameter_gradients():
+    """Around ``loss.backward()``: see above.  Not re-entrant (an inner block is a no-op); gradients taken with
+    ``torch.autograd.grad(..., parameters)`` inside the block would miss the deferred contributions -- use ``.backward()``."""
+    global _deferred
+    if _deferred is not None or os.environ.get("NQA_DEFER_PARAM_GRADS", "1") in ("0",):
+        yield
+        return
+    bucket = {}
+    _deferred = bucket
+    try:
+        yield
+    finally:
+        _deferred = None
+        _flush_deferred(bucket)
+
+
+def deferring() -> bool:
+    """Inside a ``deferred_parameter_gradients`` block, in a first-order backward pass that wants parameter gradients."""
+    return _deferred is not None and param_grads_wanted() and not torch.is_grad_enabled()
+
+
+def defer(param: torch.Tensor, make, *reads) -> None:
+    """``make()`` -> this backward node's contribution to ``param.grad`` (any shape with ``param.numel()`` elements), evaluated on
+    the side stream behind what the current stream has queued; ``reads``: current-stream tensors it reads."""
+    dev = param.device
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))  # (everything `make` reads has been queued by now)
+    pending = _deferred.setdefault("_pending", [])
+    pending.append((param, make, reads, ready))
+    # The launches of a site go out one site LATE (NQA_DEFER_LAG, default 1): by then the current stream has queued the data
+    # chain's next kernels, so in a captured graph they -- not the side work -- are the first children of the fork.
+    lag = int(os.environ.get("NQA_DEFER_LAG", "1") or 0)
+    while len(pending) > lag:
+        _launch_deferred(_deferred, pending.pop(0))
+
+
+def _launch_deferred(bucket, item) -> None:
+    param, make, reads, ready = item
+    side = _defer_stream(param.device)
+    side.wait_event(ready)
+    for t in reads:
+        if t is not None and t.is_cuda:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        g = make().reshape(param.shape)
+        ent = bucket.get(id(param))
+        if ent is None:
+            bucket[id(param)] = [param, g]
+        else:
+            ent[1].add_(g)
+
+
+def _flush_deferred(bucket) -> None:
+    for item in bucket.pop("_pending", []):
+        _launch_deferred(bucket, item)
+    joined = set()
+    for param, g in bucket.values():
+        dev = param.device
+        cur = torch.cuda.current_stream(dev)
+        if dev not in joined:
+            cur.wait_stream(_defer_stream(dev))
+            joined.add(dev)
+        g.record_stream(cur)
+        if param.grad is None:
+            param.grad = g
+        else:
+            param.grad.add_(g)
+
+
 class _WeightCacheMixin:
     """Modules that cache derived weights in eval mode: the cache goes when the mode changes or a state dict is loaded
     (``p.data.copy_()`` style writes bypass the version counter the cache is keyed on -- call

@@ -82,3 +82,44 @@ def test_training_step_parameter_gradients(device, model_dtype, parity):
         assert p.grad is not None, f"no gradient for {k}"
         r = grads_ref[key]
         torch.testing.assert_close(r, p.grad.cpu(), atol=tol * max(1e-3, float(r.abs().max())), rtol=tol * 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [16, 128])
+def test_deferred_parameter_gradients_equal_autograd(device, width):
+    """``with deferred_parameter_gradients(): loss.backward()`` (parameter gradients of ``o3.Linear`` and the radial MLP's
+    last layer launched on a side stream and delivered outside autograd, ``nequip_amd/utils/wgrad.py``) gives every
+    parameter the gradient plain ``loss.backward()`` gives it -- twice in a row (accumulation into an existing ``.grad``)."""
+    from nequip_amd.data import AtomicDataDict
+    from nequip_amd.model import NequIPGNNModel
+    from nequip_amd.utils import synthetic as syn
+    from nequip_amd.utils import wgrad as wg
+
+    pos, types, cell, names = syn.water_box(n_side=3, seed=7)
+    data = AtomicDataDict.to_device(syn.make_data(pos, types, 4.0, cell), device)
+    model = NequIPGNNModel(seed=5, model_dtype="float32", type_names=names, r_max=4.0, num_layers=3, l_max=2, parity=False,
+                           num_features=32, radial_mlp_depth=1, radial_mlp_width=width, num_bessels=8,
+                           polynomial_cutoff_p=6, avg_num_neighbors=25.0).to(device).train()
+    gen = torch.Generator().manual_seed(0)
+    f_target = torch.randn(len(pos), 3, generator=gen, dtype=torch.float64).to(device)
+
+    def loss_of():
+        out = model(dict(data))
+        return (out["forces"] - f_target).square().mean() + out["total_energy"].square().mean() / len(pos)
+
+    loss_of().backward()
+    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    deferred_any = []
+    for rep in (1, 2):
+        with wg.deferred_parameter_gradients():
+            loss_of().backward()
+            deferred_any.append(len(wg._deferred) + len(wg._deferred.get("_pending", ())))
+        torch.cuda.synchronize()
+        for k, p in model.named_parameters():
+            assert p.grad is not None, f"no gradient for {k}"
+            r = rep * ref[k]
+            torch.testing.assert_close(p.grad, r, atol=2e-6 * rep * max(1e-3, float(r.abs().max())), rtol=2e-5,
+                                       msg=lambda m, k=k: f"{k}: {m}")
+    assert min(deferred_any) >= 6, f"nothing was deferred: {deferred_any}"  # (the o3.Linear weights of three layers at least)
+    assert wg._deferred is None
