@@ -52,6 +52,39 @@ class RadialBackwardQueue:
         self.stream = side_stream(device, 0)
         self.layers = 0
         self.acc = None
+        self.pending = None  # a layer's launch that has not gone out yet (see `submit`)
+
+    @staticmethod
+    def lagged() -> bool:
+        """Launch a layer's radial backward when the NEXT layer's backward begins, not at the fork itself (its place in the
+        stream order -- behind the event recorded at the fork -- is the same).  In a captured hipGraph the first node created
+        behind a fork continues on the parent's queue and later ones move to another queue: created at the fork, the side
+        work stayed and the main chain hopped queues at every fork (~10 us of idle time each in the cfg-3 timeline; the
+        training step's ~25 forks lost more than the overlap gained until its side launches trailed, utils/wgrad.py).
+        ``NQA_RADIAL_LAG=0``: launch at the fork."""
+        return os.environ.get("NQA_RADIAL_LAG", "1") not in ("", "0")
+
+    def flush(self) -> None:
+        item, self.pending = self.pending, None
+        if item is not None:
+            item()
+
+    def submit(self, launch, ready: "torch.cuda.Event", reads, last: bool) -> None:
+        """``launch()`` -> this layer's ``g_emb`` part, to run on the side stream behind ``ready``; ``reads``: tensors of the
+        main stream it reads.  ``last``: nothing follows on the main chain (launch now)."""
+        def item():
+            self.stream.wait_event(ready)
+            with torch.cuda.stream(self.stream):
+                part = launch()
+                self.acc = part if self.acc is None else self.acc.add_(part)
+            for t in reads:  # read on the side stream: the allocator must not recycle them earlier
+                t.record_stream(self.stream)
+
+        self.flush()
+        if last or not self.lagged():
+            item()
+        else:
+            self.pending = item
 
     @staticmethod
     def enabled() -> bool:
@@ -91,6 +124,9 @@ class _PairedRadialTPFn(torch.autograd.Function):
         emb_half, x, y, w_half, w0, w1 = ctx.saved_tensors
         alpha0, alpha1, mode, cache, k, topo, pairing = ctx.args
         need_emb, need_x, need_y = ctx.needs_input_grad[:3]
+        if ctx.queue is not None:
+            # the previous layer's radial backward goes out now: the main chain's kernels since its fork are queued
+            ctx.queue.flush()
         g = g.contiguous()
         P = pairing.num_pairs
         gx = gy = G = None
@@ -120,21 +156,22 @@ class _PairedRadialTPFn(torch.autograd.Function):
         if need_emb and q is not None:
             cur = torch.cuda.current_stream(g.device)
             try:
-                q.stream.wait_stream(cur)  # grad_w is complete
-                with torch.cuda.stream(q.stream):
+                ready = torch.cuda.Event()
+                ready.record(cur)  # grad_w is complete
+                last = q.layers <= 0
+
+                def launch():
                     if folded:
                         # the first layer's backward is the last launch of the queue: the main chain is waiting for it, so
                         # it has the device to itself (the other layers' launches run next to the main chain)
-                        part = _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache, device_idle=q.layers <= 0)
-                    else:
-                        part = _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
-                    q.acc = part if q.acc is None else q.acc.add_(part)
-                for t in (G, emb_half, w0, w1):  # read on the side stream: the allocator must not recycle them earlier
-                    t.record_stream(q.stream)
+                        return _mlp._launch_bwd(emb_half, w0, w1, alpha0, alpha1, G, mode, cache, device_idle=last)
+                    return _mlp._launch_bwd_paired(emb_half, w0, w1, alpha0, alpha1, G[:P], G[P:], mode, cache)
+
+                q.submit(launch, ready, (G, emb_half, w0, w1), last)
             except BaseException:
                 # never leave an un-joined fork behind (it would invalidate a hipGraph capture) nor a stale partial sum
                 cur.wait_stream(q.stream)
-                q.acc, q.layers = None, 0
+                q.acc, q.layers, q.pending = None, 0, None
                 raise
             if q.layers <= 0:  # first layer of the model = last backward of the evaluation: join
                 assert q.acc is not None and q.layers == 0, "radial backward queue out of step with the layers"
