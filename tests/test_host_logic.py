@@ -409,3 +409,42 @@ def test_per_edge_type_cutoff_host_guards():
                            num_features=8, radial_mlp_width=64, avg_num_neighbors=10.0, per_edge_type_cutoff={"A": 3.0})
     with pytest.raises(NotImplementedError, match="per_edge_type_cutoff"):
         aot_export_model(model, {}, "/tmp/x.nequip.pt2")
+
+
+def test_graphed_step_and_padded_list_are_gpu_only():
+    """The MD-step runner and its neighbour list have no CPU path: they say so instead of falling back."""
+    import pytest
+    import torch
+
+    from nequip_amd.data._nl import PaddedNeighborList
+    from nequip_amd.integrations.graphed_step import GraphedStep
+
+    model = torch.nn.Linear(1, 1).eval()
+    with pytest.raises(RuntimeError, match="GPU"):
+        GraphedStep(model, torch.zeros(4, dtype=torch.long), torch.eye(3), True, 4.0)
+    with pytest.raises(RuntimeError, match="GPU"):
+        PaddedNeighborList(4, 4.0, torch.eye(3), True, 64)
+    with pytest.raises(ValueError, match="cell"):
+        PaddedNeighborList(4, 4.0, None, True, 64)
+
+
+def test_deferred_parameter_gradients_block_is_inert_without_the_gpu_kernels():
+    """``deferred_parameter_gradients`` only reroutes gradients that the HIP kernels produce; around a backward pass that has
+    none (CPU tensors) it changes nothing, is not re-entrant-sensitive and leaves no state behind."""
+    import torch
+
+    from nequip_amd.utils import wgrad as wg
+
+    lin = torch.nn.Linear(3, 2)
+    x = torch.randn(5, 3)
+    lin(x).square().sum().backward()
+    ref = [p.grad.clone() for p in lin.parameters()]
+    lin.zero_grad(set_to_none=True)
+    with wg.deferred_parameter_gradients():
+        assert wg._deferred is not None and not wg.deferring()  # (grad mode is on outside a backward node)
+        with wg.deferred_parameter_gradients():  # inner block: no-op
+            lin(x).square().sum().backward()
+        assert wg._deferred is not None
+    assert wg._deferred is None
+    for p, r in zip(lin.parameters(), ref):
+        assert torch.equal(p.grad, r)
