@@ -367,7 +367,9 @@ def roofline_objects(kernels, kernel_steps, ms_per_step, workload, live_pmc, bou
         pmc, source = measure_traffic_live(workload)
     if pmc is None:
         why = source
-        pmc, source = static_traffic()
+        # the committed PMC summaries are of the cfg-3 step: for any other workload a static figure would be another
+        # workload's traffic (BENCH_r05 review: 0.03x / 286x "traffic over algorithmic") -- null instead
+        pmc, source = static_traffic() if workload == "water10k" else ({}, "unavailable (no live PMC pass in this run)")
         if why:
             source += f" [live measurement: {why}]"
     name, s = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])
@@ -476,6 +478,28 @@ class GpuClockSampler:
         return out
 
 
+def gpu_clock_mhz(gpu_state):
+    """One shader-clock figure for the line.  The DPM level in use / hwmon's freq1_input read ~100 MHz on some boxes while the
+    device is busy (BENCH_r05: 113 MHz next to rocm-smi's 2382 MHz): anything below 500 MHz is not a shader clock of a
+    working MI355X, so the `rocm-smi --showclocks` reading taken under load is used instead; None when nothing is sane."""
+    import re
+
+    if not gpu_state:
+        return None
+    cands = []
+    for key in ("dpm_sclk_mhz", "sclk_mhz"):
+        v = (gpu_state.get(key) or {}).get("median")
+        if v is not None:
+            cands.append(float(v))
+    for k, v in (gpu_state.get("rocm_smi") or {}).items():
+        if "sclk" in k.lower():
+            m = re.search(r"(\d+(?:\.\d+)?)\s*mhz", str(v).lower())
+            if m:
+                cands.append(float(m.group(1)))
+    sane = [c for c in cands if 500.0 <= c <= 3500.0]
+    return sane[0] if sane else None
+
+
 def rocm_smi_snapshot():
     """One `rocm-smi` reading (clocks, power cap, temperature) taken while the caller's kernels run; {} when unavailable."""
     import shutil
@@ -529,8 +553,6 @@ def train_bench(args, world, rank, device, distributed):
     from nequip_amd.train import SimpleDDPStrategy
     from nequip_amd.utils import ktimer
     from nequip_amd.utils import synthetic as syn
-    from nequip_amd.utils.wgrad import deferred_parameter_gradients
-
     w = TRAIN_WORKLOADS[args.workload]
     frames = []
     for f in range(w["batch"]):
@@ -558,8 +580,9 @@ def train_bench(args, world, rank, device, distributed):
         opt.zero_grad(set_to_none=True)
         out = model(dict(data))
         loss = (out["forces"] - f_target).square().mean() + (out["total_energy"] - e_target).square().mean()
-        with deferred_parameter_gradients():  # (parameter gradients off the data chain, nequip_amd/utils/wgrad.py)
-            (loss * strategy.world_size).backward()  # nequip/train/lightning.py:259-266
+        # the shipped training step: SimpleDDPStrategy.backward (parameter gradients off the data chain,
+        # nequip_amd/utils/wgrad.py), then the flat all-reduce -- nequip/train/lightning.py:259-266
+        strategy.backward(loss * strategy.world_size)
         strategy.post_backward(loss)
         opt.step()
         return loss
@@ -644,6 +667,43 @@ def train_bench(args, world, rank, device, distributed):
         dist.destroy_process_group()
 
 
+def other_workloads(timeout_s: float = 420.0):
+    """The other BASELINE configs (cfg-1 aspirin batch, cfg-2 si1k, cfg-5 cu100k, cfg-4 training step), each as a short
+    child run of this file on the same device right after the headline measurement, so that the driver's line carries a
+    driver-timed figure for every config.  Per workload: ms_per_step, value + unit, the dominant
+    hand-written kernel region with its share of the HBM roof (boundary-algorithmic bytes / HIP-event time; `traffic` is not
+    measured here: null).  A child that fails or times out is recorded as {"error": ...}, never raised."""
+    import subprocess
+
+    out = {}
+    t_all = time.perf_counter()
+    for wl, steps, warm in (("si1k", 20, 5), ("aspirin5", 20, 5), ("cu100k", 5, 2), ("train256", 10, 3)):
+        left = timeout_s - (time.perf_counter() - t_all)
+        if left < 30:
+            out[wl] = {"error": "skipped: time budget of the other-workload runs used up"}
+            continue
+        env = dict(os.environ, NQA_BENCH_NO_CLOCKS="1", NQA_BENCH_NO_EXACT_FP32="1", NQA_BENCH_NO_MD_STEP="1", NQA_BENCH_NO_OTHER="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(steps), "--warmup", str(warm),
+               "--no-cpu-baseline", "--no-pmc", "--no-other-workloads", "--kernel-steps", "2"]
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left)
+            line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
+            if res.returncode != 0 or line is None:
+                out[wl] = {"error": f"rc {res.returncode}: {(res.stderr or '')[-300:]}"}
+                continue
+            d = json.loads(line)
+            rf = d.get("roofline") or {}
+            out[wl] = {"ms_per_step": d.get("ms_per_step"), "value": d.get("value"), "unit": d.get("unit"),
+                       "metric": d.get("metric"), "n_atoms": (d.get("config") or {}).get("n_atoms"),
+                       "dominant_kernel": rf.get("kernel"), "dominant_avg_launch_ms": rf.get("avg_launch_ms"),
+                       "dominant_frac": rf.get("frac"), "dominant_bound": rf.get("bound"), "traffic": None,
+                       "step_frac": (d.get("step_roofline") or {}).get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as exc:  # pragma: no cover
+            out[wl] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); without a launcher bench.py starts them itself")
@@ -655,6 +715,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind `roofline.traffic`")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # 1 warm-up + 2 eager steps, no output
     ap.add_argument("--kernel-steps", type=int, default=3, help="eager steps instrumented with HIP events for `roofline`")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default run only: skip the short child runs of the other BASELINE configs (`config.other_workloads`)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
@@ -928,8 +990,7 @@ def main():
                 "exact_fp32_ms_per_step": exact_ms,
                 "md_step": md_step,
                 "gpu_state": gpu_state,
-                "gpu_clock_mhz": (((gpu_state or {}).get("dpm_sclk_mhz") or (gpu_state or {}).get("sclk_mhz") or {}).get("median")
-                                  if gpu_state else None),
+                "gpu_clock_mhz": gpu_clock_mhz(gpu_state),
             },
             "roofline": roofline,
             "step_roofline": step_roofline,
@@ -937,6 +998,13 @@ def main():
             "kernels_gbps": {k: v["gbps"] for k, v in kernels.items()},
             "kernels_tflops": {k: v["tflops"] for k, v in kernels.items() if v.get("tflops", 0) > 0},
         }
+        if (world == 1 and args.workload == "water10k" and not args.no_other_workloads
+                and os.environ.get("NQA_BENCH_NO_OTHER", "") in ("", "0")):
+            # free this process's device memory first: cu100k needs most of what the cfg-3 model + graphs hold
+            graph = None
+            topology_cache.clear()
+            torch.cuda.empty_cache()
+            result["config"]["other_workloads"] = other_workloads()
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.workload)
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]

@@ -163,6 +163,9 @@ def _emit(st: Structure) -> str:
     A("namespace nqa {")
     A("namespace {")
     A(f"constexpr int kXD = {XD}, kS = {S}, kOD = {OD}, kNP = {NP};")
+    if os.environ.get("NQA_GEN_PAIR_TIMING", "0") != "0":
+        A("__device__ unsigned long long nqa_lab_tm[8];")
+    A("typedef float f2 __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand: two fp32 values in a register pair")
 
     def decl_x(indent, sfx=""):
         return [f"{indent}T xb{b}{sfx}[{2 * st.in1_ls[b] + 1}];" for b in used_blocks]
@@ -704,6 +707,8 @@ def _emit(st: Structure) -> str:
     # register budget: two grad_out rows, three x rows, the weights.  Measured on cu20k (l_max 3, 269): 298 spilled
     # registers, fused backward 10 -> 70 ms -- the big structures stay with the per-edge kernels
     pair_ok = (2 * OD + 3 * XD + NP) <= 110  # (larger structures spill: l2p_second at 144 spills 127 registers)
+    if os.environ.get("NQA_GEN_PAIR_FORCE_SPLIT", "0") != "0":  # lab: the split-by-input-block form for small structures too
+        pair_ok = False
     pair_occ = os.environ.get("NQA_GEN_PAIR_OCC", "2")
     pair_lb = "__launch_bounds__(256)" if big else f"__launch_bounds__(256, {pair_occ})"
     if pair_ok:
@@ -757,6 +762,10 @@ def _emit(st: Structure) -> str:
         A("  for (int i = 0; i < kXD; ++i) gxO[i] = T(0);")
 
         pair_nohoist = os.environ.get("NQA_GEN_PAIR_NOHOIST", "0") != "0"  # measured: more spills, not fewer
+        # lab only (scripts/micro/pair_lab.hip): ablations that keep every instruction and point a stream at ONE hot row (a
+        # scalar select on a.N < 0, never true): 1: grad_w stores, 2: grad_x row stores, 4: the gathered rows are the
+        # owner's own rows, 8: weight loads, 16: grad_y stores
+        pair_abl = int(os.environ.get("NQA_GEN_PAIR_ABL", "0"))
 
         def pair_path(out, pth, xs, gname, ys, tag_):
             """One path of one directed edge: B{tag}{jj} (-> grad_w, grad_y) and the grad_x terms per input component."""
@@ -788,21 +797,40 @@ def _emit(st: Structure) -> str:
             live = [jj for jj in range(d2) if started[jj]]
             return live, gx_terms
 
-        def pair_loads(sfx, idx, with_g=True):
+        def pair_index_loads(sfx, idx, ind="    "):
+            return [f"{ind}jn{sfx} = spec_uniform(a.nbr[{idx}]); pr{sfx} = spec_uniform(a.wid[{idx}]);",
+                    f"{ind}ei{sfx} = spec_uniform(a.eid[{idx}]); eo{sfx} = spec_uniform(a.eid2[{idx}]);"]
+
+        def pair_y_loads(sfx, ind="    "):
+            return (load_y(ind, f"(a.y + (int64_t)ei{sfx} * kS)", sfx="I" + sfx, decl=False)
+                    + load_y(ind, f"(a.y + (int64_t)eo{sfx} * kS)", sfx="X" + sfx, decl=False))
+
+        def pair_rotate(dst, src, ind="    "):
+            out = [f"{ind}jn{dst} = jn{src}; pr{dst} = pr{src}; ei{dst} = ei{src}; eo{dst} = eo{src};"]
+            for j in used_y:
+                for i in range(2 * st.in2_ls[j] + 1):
+                    out.append(f"{ind}yb{j}I{dst}[{i}] = yb{j}I{src}[{i}]; yb{j}X{dst}[{i}] = yb{j}X{src}[{i}];")
+            return out
+
+        def pair_loads(sfx, idx, with_g=True, scalars=True):
             """Operands of the pair in owner slot `idx` into register set `sfx` (the indices are wave-uniform).  The
-            gathered grad_out row goes to the single array gvJ (with_g) or is requested later by pair_load_g."""
-            out = [f"    {{ jn{sfx} = spec_uniform(a.nbr[{idx}]);",
-                   f"      pr{sfx} = spec_uniform(a.wid[{idx}]); ei{sfx} = spec_uniform(a.eid[{idx}]); eo{sfx} = spec_uniform(a.eid2[{idx}]);",
-                   f"      const T* __restrict__ xr = a.x + (int64_t)jn{sfx} * a.din;",
-                   f"      const T* __restrict__ wr = a.w + (int64_t)pr{sfx} * a.wn;",
+            gathered grad_out row goes to the single array gvJ (with_g) or is requested later by pair_load_g.
+            scalars=False: the indices and the y rows are in place already (scalar prefetch, NQA_GEN_PAIR_SPF)."""
+            out = ["    {"] + (pair_index_loads(sfx, idx, "      ") if scalars else [])
+            if pair_abl & 4:
+                out.append(f"      if (a.N >= 0) jn{sfx} = node;")
+            out += [f"      const T* __restrict__ xr = a.x + (int64_t)jn{sfx} * a.din;",
+                   (f"      const T* __restrict__ wr = a.w + (int64_t)(a.N < 0 ? pr{sfx} : 0) * a.wn;" if pair_abl & 8 else
+                    f"      const T* __restrict__ wr = a.w + (int64_t)pr{sfx} * a.wn;"),
                    f"      const T* __restrict__ yi = a.y + (int64_t)ei{sfx} * kS;",
                    f"      const T* __restrict__ yo = a.y + (int64_t)eo{sfx} * kS;"]
             out += load_w("      ", "wr", sfx=sfx, decl=False)
             out += load_x("      ", "xr", sfx="J" + sfx, decl=False)
             if with_g:
                 out += load_g("      ", f"a.g + (int64_t)jn{sfx} * a.dout", "gvJ")
-            out += load_y("      ", "yi", sfx="I" + sfx, decl=False)
-            out += load_y("      ", "yo", sfx="X" + sfx, decl=False)
+            if scalars:
+                out += load_y("      ", "yi", sfx="I" + sfx, decl=False)
+                out += load_y("      ", "yo", sfx="X" + sfx, decl=False)
             out.append("      if (DUAL && a.w2 != nullptr) {")
             out += load_w("        ", f"(a.w2 + (int64_t)pr{sfx} * a.wn)", sfx="2" + sfx, decl=False)
             out.append("      }")
@@ -823,6 +851,24 @@ def _emit(st: Structure) -> str:
                     + decl_x("  ", "J" + sfx + "2") + decl_y("  ", "I" + sfx + "2") + decl_y("  ", "X" + sfx + "2"))
 
         def pair_compute(sfx, slot):
+            if pair_abl & 32:  # lab: the memory streams of a pair without its arithmetic (every loaded value is consumed once)
+                out = ["    {", "    T s_ = T(0);", "#pragma unroll", "    for (int k = 0; k < kOD; ++k) s_ += gvJ[k] + gvO[k];"]
+                for b in used_blocks:
+                    for i in range(2 * st.in1_ls[b] + 1):
+                        out.append(f"    s_ += xb{b}J{sfx}[{i}] + xb{b}O[{i}];")
+                for j in used_y:
+                    for i in range(2 * st.in2_ls[j] + 1):
+                        out.append(f"    s_ += yb{j}I{sfx}[{i}] + yb{j}X{sfx}[{i}];")
+                out += [f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;",
+                        f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;"]
+                for pth in range(NP):
+                    out.append(f"    {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', f'wv{sfx}[{pth}] + s_')};")
+                for i in range(XD):
+                    out.append(f"    if (GX) {emit_store(f'spec_at(gxr + (unsigned)(mul * {i}), ucb)', 's_')};")
+                    out.append(f"    gxO[{i}] += s_;")
+                out.append(f"    if (lane < kS) {{ a.gy[(int64_t)ei{sfx} * a.gy_stride + chunk * kS + lane] = s_; a.gy[(int64_t)eo{sfx} * a.gy_stride + chunk * kS + lane] = s_; }}")
+                out.append("    }")
+                return out
             out = ["    {"]
             if pair_nohoist:
                 # T_ij = sum_k C_ijk g_k of the owner's grad_out is the same for all its pairs: the compiler hoists those
@@ -831,8 +877,10 @@ def _emit(st: Structure) -> str:
                 out += ["#pragma unroll", "    for (int k = 0; k < kOD; ++k) asm volatile(\"\" : \"+v\"(gvO[k]));"]
             out += ["    T qI[kS], qX[kS], gxa[kXD];", "#pragma unroll",
                    "    for (int j = 0; j < kS; ++j) { qI[j] = T(0); qX[j] = T(0); }",
-                   f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;",
-                   f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;"]
+                   (f"    T* __restrict__ gwr_e = a.gw + (int64_t)(a.N < 0 ? pr{sfx} : 0) * a.wn;" if pair_abl & 1 else
+                    f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;"),
+                   (f"    T* __restrict__ gxr = a.gxe + (int64_t)(a.N < 0 ? ({slot}) : 0) * a.din;" if pair_abl & 2 else
+                    f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;")]
             last_path_of_block = {b_: p_ for p_, (b_, _, _) in enumerate(st.instr)}
             first_path_of_block = {}
             for p_, (b_, _, _) in enumerate(st.instr):
@@ -881,8 +929,9 @@ def _emit(st: Structure) -> str:
                 out.append("      }")
             out.append("      spec_mask_dup<T, kS>(qI, u < mul);")
             out.append("      spec_mask_dup<T, kS>(qX, u < mul);")
-            out.append(f"      spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)ei{sfx} * a.gy_stride + chunk * kS, lane);")
-            out.append(f"      spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eo{sfx} * a.gy_stride + chunk * kS, lane);")
+            gy_i, gy_x = (f"(a.N < 0 ? ei{sfx} : 0)", f"(a.N < 0 ? eo{sfx} : 0)") if pair_abl & 16 else (f"ei{sfx}", f"eo{sfx}")
+            out.append(f"      spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t){gy_i} * a.gy_stride + chunk * kS, lane);")
+            out.append(f"      spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t){gy_x} * a.gy_stride + chunk * kS, lane);")
             out.append("    }")
             return out
 
@@ -917,16 +966,64 @@ def _emit(st: Structure) -> str:
             # NQA_GEN_PAIR_PREFETCH=1: touch the next pair's weight row (the one stream that comes from HBM) while this pair
             # is evaluated -- plain loads into a sink value, so that the row is in the L2 when the real loads ask for it
             pair_prefetch = os.environ.get("NQA_GEN_PAIR_PREFETCH", "1") != "0"  # same-box cfg-3: 2.930 -> 2.912 ms
+            # NQA_GEN_PAIR_SPF=1: the wave-uniform operands (four indices, two y rows) of the NEXT pair and the indices of the
+            # one after it are requested while this pair's rows are in flight -- one dependent scalar round trip less per pair
+            pair_spf = int(os.environ.get("NQA_GEN_PAIR_SPF", "0"))  # 2: the indices only (y rows: 36 more scalar registers)
+            spf_y = pair_spf == 1
             L.extend(pair_decls("A"))
             if pair_prefetch:
                 A("  T pf_sink = T(0);")
+            if pair_spf:
+                L.extend(pair_decls("N"))
+                A("  int jnM = 0, prM = 0, eiM = 0, eoM = 0;")
+                A("  if (idx < end) {")
+                L.extend(pair_index_loads("A", "idx"))
+                if spf_y:
+                    L.extend(pair_y_loads("A"))
+                A("  }")
+                if spf_y:
+                    A("  if (idx + WPN < end) {")
+                    L.extend(pair_index_loads("N", "idx + WPN"))
+                    A("  }")
+            pair_timing = os.environ.get("NQA_GEN_PAIR_TIMING", "0") != "0"  # lab: where a pair's cycles go (s_memtime)
+            if pair_timing:
+                A("  unsigned long long tm_[5] = {0, 0, 0, 0, 0};")
+                A("  const unsigned long long tk0_ = __builtin_amdgcn_s_memtime();")
             A("  for (; idx < end; idx += WPN) {")
-            L.extend(pair_loads("A", "idx"))
+            if pair_timing:
+                A("    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();")
+                A("    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");")
+            L.extend(pair_loads("A", "idx", scalars=not pair_spf))
+            if pair_timing:
+                A("    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");  // indices + y rows are here, the row loads are issued")
+                A("    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();")
+                A("    asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");  // every row has arrived")
+                A("    const unsigned long long t2_ = __builtin_amdgcn_s_memtime();")
+                A("    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");")
+            if pair_spf and not spf_y:
+                L.extend(pair_y_loads("A"))
+                A("    if (idx + WPN < end) {")
+                L.extend(pair_index_loads("N", "idx + WPN", "      "))
+                A("    }")
+            elif pair_spf:
+                A("    if (idx + WPN < end) {")
+                L.extend(pair_y_loads("N", "      "))
+                A("    }")
+                A("    if (idx + 2 * WPN < end) {")
+                L.extend(pair_index_loads("M", "idx + 2 * WPN", "      "))
+                A("    }")
             if pair_prefetch:
                 A("    T pf[kNP];")
                 A("    {")
-                A("      const int nidx_ = idx + WPN < end ? idx + WPN : idx;")
-                A("      const T* __restrict__ wn_ = a.w + (int64_t)spec_uniform(a.wid[nidx_]) * a.wn;")
+                if pair_spf:
+                    A("      const int prn_ = idx + WPN < end ? prN : prA;")
+                else:
+                    A("      const int nidx_ = idx + WPN < end ? idx + WPN : idx;")
+                    A("      const int prn_ = spec_uniform(a.wid[nidx_]);")
+                if pair_abl & 8:
+                    A("      const T* __restrict__ wn_ = a.w + (int64_t)(a.N < 0 ? prn_ : 0) * a.wn;")
+                else:
+                    A("      const T* __restrict__ wn_ = a.w + (int64_t)prn_ * a.wn;")
                 for pth in range(NP):
                     A(f"      pf[{pth}] = *spec_at(wn_ + (unsigned)(mul * {pth}), ucb);")
                 A("    }")
@@ -934,10 +1031,223 @@ def _emit(st: Structure) -> str:
             if pair_prefetch:
                 A("#pragma unroll")
                 A("    for (int p_ = 0; p_ < kNP; ++p_) pf_sink += pf[p_];")
+            if pair_timing:
+                A("    const unsigned long long t3_ = __builtin_amdgcn_s_memtime();")
+                A("    asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");  // the stores have left")
+                A("    const unsigned long long t4_ = __builtin_amdgcn_s_memtime();")
+                A("    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");")
+                A("    tm_[0] += t1_ - t0_; tm_[1] += t2_ - t1_; tm_[2] += t3_ - t2_; tm_[3] += t4_ - t3_; tm_[4] += 1;")
+            if pair_spf and spf_y:
+                L.extend(pair_rotate("A", "N"))
+                A("    jnN = jnM; prN = prM; eiN = eiM; eoN = eoM;")
+            elif pair_spf:
+                A("    jnA = jnN; prA = prN; eiA = eiN; eoA = eoN;")
             A("  }")
             if pair_prefetch:
                 A("  if (pf_sink == T(12345.678)) a.gy[0] = pf_sink;")
+        if not pair_pipe and os.environ.get("NQA_GEN_PAIR_TIMING", "0") != "0":
+            A("  if (lane == 0) { for (int k = 0; k < 5; ++k) atomicAdd(&nqa_lab_tm[k], tm_[k]);")
+            A("    atomicAdd(&nqa_lab_tm[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - tk0_)); atomicAdd(&nqa_lab_tm[6], 1ull); }")
         A("  // grad_x[owner]: the owner-side contributions of all its pairs (the other side arrives through the rows)")
+        A("  if (!GX) return;")
+        A("  if (WPN > 1) {")
+        A("    extern __shared__ __align__(16) unsigned char nqa_smem[];")
+        A("    T* red = reinterpret_cast<T*>(nqa_smem);")
+        A("    if (wsub > 0) {")
+        A("#pragma unroll")
+        A("      for (int k = 0; k < kXD; ++k) red[((wsub - 1) * kXD + k) * 64 + lane] = gxO[k];")
+        A("    }")
+        A("    __syncthreads();")
+        A("    if (wsub > 0) return;")
+        A("#pragma unroll")
+        A("    for (int k = 0; k < kXD; ++k) {")
+        A("#pragma unroll")
+        A("      for (int w2 = 0; w2 < WPN - 1; ++w2) gxO[k] += red[(w2 * kXD + k) * 64 + lane];")
+        A("    }")
+        A("  }")
+        A("  if (act) {")
+        A("    const int uc = u < mul ? u : mul - 1;")
+        A("    T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+        for b in range(NB):
+            d = 2 * st.in1_ls[b] + 1
+            for i in range(d):
+                A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)uc * {d} + {i}] = gxO[{xpre[b] + i}];")
+        A("  }")
+        A("}")
+
+    # ------------------------------------------------------------------ pair-centric backward, PACKED fp32
+    # Round 6.  Counters and ablations of bwd_pair_kernel (profiles/r6_pair_counters.txt, r6_pair_ablations_call1.txt): with
+    # every memory stream pointed at one hot row the kernel still takes 72 % of its time -- it sits on its ~820 vector
+    # instructions per pair (4 cycles each; the vector ALU is busy for half of the kernel's duration at two wavefronts per
+    # SIMD), not on HBM.  gfx950 issues two fp32 operations per lane and instruction as v_pk_{mul,add,fma}_f32 on register
+    # PAIRS, and the two directed edges of a pair run the SAME instruction stream on different operands:
+    #     in  (j -> o):  x = x[j], g = grad_out[o], y = y[e_in]   -> grad_x row of j,  grad_y[e_in]
+    #     out (o -> j):  x = x[o], g = grad_out[j], y = y[e_out]  -> grad_x[o] (registers), grad_y[e_out]
+    # so every value becomes a pair (.x = in, .y = out): G[k] = (g_o[k], g_j[k]), X[i] = (x_j[i], x_o[i]), Y = (y_in, y_out),
+    # the weight is shared.  One packed stream evaluates both edges; the owner-side intermediates T_ij(g_o) that the scalar
+    # kernel hoisted out of the pair loop (~115 registers) are recomputed for free in the .x halves.
+    if pair_ok and os.environ.get("NQA_GEN_PAIR_PK", "1") != "0":
+        pk_occ = os.environ.get("NQA_GEN_PAIR_PK_OCC", "2")
+        pk_prefetch = os.environ.get("NQA_GEN_PAIR_PK_PREFETCH", "0") != "0"
+        A("template <typename T, int WPN, bool FULL, bool GX>")
+        A(f"__global__ __launch_bounds__(256, {pk_occ}) void bwd_pair_pk_kernel(const SpecArgs<T> a) {{")
+        A("  static_assert(sizeof(T) == 4, \"packed fp32 only\");")
+        A("  const int lane = threadIdx.x & 63;")
+        A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+        A("  const int mul = a.mul;")
+        A("  const int nchunk = (mul + 63) >> 6;")
+        A("  const int64_t witem = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+        A("  const int64_t item = witem / WPN;")
+        A("  const int wsub = (int)(witem - item * WPN);")
+        A("  if (item >= (int64_t)a.N * nchunk) return;  // (WPN == 4: the whole workgroup)")
+        A("  const int node = spec_uniform((int)(item / nchunk));")
+        A("  const int chunk = (int)(item - (int64_t)node * nchunk);")
+        A("  const int u = chunk * 64 + lane;")
+        A("  const bool act = FULL || (u < mul);")
+        A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
+        L.extend(lane_offsets("  ", want_x=True, want_g=True))
+        A("  f2 G[kOD], X[kXD];  // .x: the in edge's operand, .y: the out edge's")
+        A("  T gxO[kXD];")
+
+        def pk_load_g(indent, rowexpr, comp):
+            out = [f"{indent}{{ const T* __restrict__ gb = {rowexpr};"]
+            for s_ in range(NS):
+                d3 = 2 * st.out_ls[s_] + 1
+                for k in range(d3):
+                    if slot_coeff[s_] is None:
+                        out.append(f"{indent}  G[{opre[s_] + k}].{comp} = T(0);")
+                    else:
+                        out.append(f"{indent}  G[{opre[s_] + k}].{comp} = spec_at(gb, go{s_})[{k}];")
+            # (the path normalisation sqrt((2 l3 + 1) / n_paths) is folded into the 3j constants below: no multiply per value)
+            out.append(f"{indent}  if (!FULL) {{")
+            for s_ in range(NS):
+                d3 = 2 * st.out_ls[s_] + 1
+                if slot_coeff[s_] is None:
+                    continue
+                for k in range(d3):
+                    out.append(f"{indent}    G[{opre[s_] + k}].{comp} = act ? G[{opre[s_] + k}].{comp} : T(0);")
+            out.append(f"{indent}  }}")
+            out.append(f"{indent}}}")
+            return out
+
+        def pk_load_x(indent, rowexpr, comp):
+            out = []
+            for b in range(NB):
+                d = 2 * st.in1_ls[b] + 1
+                for i in range(d):
+                    if b in used_blocks:
+                        out.append(f"{indent}X[{xpre[b] + i}].{comp} = spec_at({rowexpr}, xo{b})[{i}];")
+                    else:
+                        out.append(f"{indent}X[{xpre[b] + i}].{comp} = T(0);")
+            return out
+
+        L.extend(pk_load_g("  ", "a.g + (int64_t)node * a.dout", "x"))
+        L.extend(pk_load_x("  ", "(a.x + (int64_t)node * a.din)", "y"))
+        A("#pragma unroll")
+        A("  for (int i = 0; i < kXD; ++i) gxO[i] = T(0);")
+        A("  T wv[kNP];")
+        A("  f2 Y[kS];")
+        if pk_prefetch:
+            A("  T pf_sink = T(0);")
+        A("  for (int idx = beg + wsub; idx < end; idx += WPN) {")
+        A("    const int jn_ = spec_uniform(a.nbr[idx]), pr = spec_uniform(a.wid[idx]);")
+        A("    const int ei = spec_uniform(a.eid[idx]), eo = spec_uniform(a.eid2[idx]);")
+        A("    const int jn = " + ("(a.N < 0 ? jn_ : node);" if pair_abl & 4 else "jn_;"))
+        A("    const T* __restrict__ wr = a.w + (int64_t)" + ("(a.N < 0 ? pr : 0)" if pair_abl & 8 else "pr") + " * a.wn;")
+        A("    const T* __restrict__ yi = a.y + (int64_t)ei * kS;")
+        A("    const T* __restrict__ yo = a.y + (int64_t)eo * kS;")
+        for pth in range(NP):
+            A(f"    wv[{pth}] = *spec_at(wr + (unsigned)(mul * {pth}), ucb);")
+        L.extend(pk_load_x("    ", "(a.x + (int64_t)jn * a.din)", "x"))
+        L.extend(pk_load_g("    ", "a.g + (int64_t)jn * a.dout", "y"))
+        for j in used_y:
+            for i in range(2 * st.in2_ls[j] + 1):
+                A(f"    Y[{ypre[j] + i}] = f2{{yi[{ypre[j] + i}], yo[{ypre[j] + i}]}};")
+        if pk_prefetch:
+            A("    T pf[kNP];")
+            A("    {")
+            A("      const int nidx_ = idx + WPN < end ? idx + WPN : idx;")
+            A("      const T* __restrict__ wn_ = a.w + (int64_t)" + ("(a.N < 0 ? spec_uniform(a.wid[nidx_]) : 0)" if pair_abl & 8 else "spec_uniform(a.wid[nidx_])") + " * a.wn;")
+            for pth in range(NP):
+                A(f"      pf[{pth}] = *spec_at(wn_ + (unsigned)(mul * {pth}), ucb);")
+            A("    }")
+        A("    f2 Q[kS];")
+        A("#pragma unroll")
+        A("    for (int j = 0; j < kS; ++j) Q[j] = f2{T(0), T(0)};")
+        A("    T* __restrict__ gwr_e = a.gw + (int64_t)" + ("(a.N < 0 ? pr : 0)" if pair_abl & 1 else "pr") + " * a.wn;")
+        A("    T* __restrict__ gxr = a.gxe + (int64_t)" + ("(a.N < 0 ? idx : 0)" if pair_abl & 2 else "idx") + " * a.din;")
+        pk_last = {b_: p_ for p_, (b_, _, _) in enumerate(st.instr)}
+        pk_first = {}
+        for p_, (b_, _, _) in enumerate(st.instr):
+            pk_first.setdefault(b_, p_)
+        for b in sorted(pk_first):
+            A(f"    f2 ga{b}[{2 * st.in1_ls[b] + 1}];  // sum over the block's paths of w_p A^p_i: .x -> the pair's row, .y -> grad_x[owner]")
+        for pth, (b_, j, s_) in enumerate(st.instr):
+            l1, l2, l3 = st.in1_ls[b_], st.in2_ls[j], st.out_ls[s_]
+            d1, d2, d3 = 2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1
+            C = np.array(wigner_3j(l1, l2, l3), dtype=np.float64)
+            A(f"    {{  // path {pth}: l1 {l1} x l2 {l2} -> l3 {l3}")
+            started = [False] * d2
+            for i in range(d1):
+                a_started = False
+                for jj in range(d2):
+                    ks = [k for k in range(d3) if C[i, jj, k] != 0.0]
+                    if not ks:
+                        continue
+                    expr = " + ".join(f"T({float(C[i, jj, k]) * float(slot_coeff[s_])!r}) * G[{opre[s_] + k}]" for k in ks)
+                    A(f"      const f2 t{i}_{jj} = {expr};")
+                    if started[jj]:
+                        A(f"      B{jj} += X[{xpre[b_] + i}] * t{i}_{jj};")
+                    else:
+                        A(f"      f2 B{jj} = X[{xpre[b_] + i}] * t{i}_{jj};")
+                        started[jj] = True
+                    if a_started:
+                        A(f"      if (GX) A{i} += Y[{ypre[j] + jj}] * t{i}_{jj};")
+                    else:
+                        A(f"      f2 A{i} = Y[{ypre[j] + jj}] * t{i}_{jj};")
+                        a_started = True
+                if a_started:
+                    if pk_first[b_] == pth:
+                        A(f"      if (GX) ga{b_}[{i}] = wv[{pth}] * A{i};")
+                    else:
+                        A(f"      if (GX) ga{b_}[{i}] += wv[{pth}] * A{i};")
+                elif pk_first[b_] == pth:
+                    A(f"      if (GX) ga{b_}[{i}] = f2{{T(0), T(0)}};")
+            live = [jj for jj in range(d2) if started[jj]]
+            if live:
+                terms = " + ".join(f"Y[{ypre[j] + jj}] * B{jj}" for jj in live)
+                A(f"      {{ const f2 r2 = {terms}; const T r_ = r2.x + r2.y; if (act) {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'r_')}; }}")
+            else:
+                A(f"      if (act) {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'T(0)')};")
+            for jj in live:
+                A(f"      Q[{ypre[j] + jj}] += wv[{pth}] * B{jj};")
+            A("    }")
+            if pk_last[b_] == pth:
+                A("    if (GX) {")
+                for i in range(d1):
+                    A(f"      if (act) {emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'ga{b_}[{i}].x')};")
+                    A(f"      gxO[{xpre[b_] + i}] += ga{b_}[{i}].y;")
+                A("    }")
+        pk_unused = [i for b in range(NB) if b not in pk_first for i in range(xpre[b], xpre[b] + 2 * st.in1_ls[b] + 1)]
+        if pk_unused:
+            A("    if (GX && act) {")
+            for i in pk_unused:
+                A(f"      *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
+            A("    }")
+        A("    T qI[kS], qX[kS];")
+        A("#pragma unroll")
+        A("    for (int j = 0; j < kS; ++j) { qI[j] = Q[j].x; qX[j] = Q[j].y; }")
+        A("    spec_mask_dup<T, kS>(qI, u < mul);")
+        A("    spec_mask_dup<T, kS>(qX, u < mul);")
+        gy_i, gy_x = ("(a.N < 0 ? ei : 0)", "(a.N < 0 ? eo : 0)") if pair_abl & 16 else ("ei", "eo")
+        A(f"    spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t){gy_i} * a.gy_stride + chunk * kS, lane);")
+        A(f"    spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t){gy_x} * a.gy_stride + chunk * kS, lane);")
+        if pk_prefetch:
+            A("#pragma unroll")
+            A("    for (int p_ = 0; p_ < kNP; ++p_) pf_sink += pf[p_];")
+        A("  }")
+        if pk_prefetch:
+            A("  if (pf_sink == T(12345.678)) a.gy[0] = pf_sink;")
         A("  if (!GX) return;")
         A("  if (WPN > 1) {")
         A("    extern __shared__ __align__(16) unsigned char nqa_smem[];")
@@ -987,7 +1297,7 @@ def _emit(st: Structure) -> str:
         # grad_y accumulators and up to 49 intermediates per path on top of what `budget` counts (merging l_1 = 0 and 1,
         # budget 102, spilled 82 registers)
         for b_ in sorted(by_block):
-            if part_paths and budget(part_paths[-1] + by_block[b_]) <= 70:
+            if part_paths and budget(part_paths[-1] + by_block[b_]) <= int(os.environ.get("NQA_GEN_SPLIT_MERGE", "70")):
                 part_paths[-1] = part_paths[-1] + by_block[b_]
             else:
                 part_paths.append(list(by_block[b_]))
@@ -1218,6 +1528,8 @@ def _emit(st: Structure) -> str:
     A("}")
 
     # ------------------------------------------------------------------ launchers + registration
+    # (NQA_LAB: scripts/micro/pair_lab.hip includes a generated file and launches single instantiations itself)
+    A("#ifndef NQA_LAB")
     A("template <int WPN>")
     A("static int launch(int which, const SpecArgs<float>& a, hipStream_t stream) {")
     A("  const int nchunk = (a.mul + 63) / 64;")
@@ -1321,6 +1633,7 @@ def _emit(st: Structure) -> str:
     A("  return launch<1>(which, a, stream);")
     A("}")
     A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {pair_parts});')
+    A("#endif  // NQA_LAB")
     A("}  // namespace")
     A("}  // namespace nqa")
     return "\n".join(L) + "\n"

@@ -104,14 +104,49 @@ def _mlp_shape(fn) -> Dict[str, Any]:
         raise NotImplementedError(f"{FULL_MODIFIER_NAME}: hidden layers of different widths {dims}")
     nonlin = None
     layers = getattr(fn, "mlp", None)
-    for m in (layers if layers is not None else []):
-        n = type(m).__name__.lower()
-        if n in ("silu", "tanh", "gelu", "mish", "sigmoid", "softplus"):
-            nonlin = n
-        elif n == "shiftedsoftplus":
-            nonlin = "ssp"
+    if depth > 0:
+        if type(layers).__name__ == "DeepLinearMLP" or not bool(getattr(fn, "is_nonlinear", True)):
+            # nonlinearity=None with hidden layers: the reference evaluates a deep LINEAR net (mlp.py:186-196)
+            raise NotImplementedError(f"{FULL_MODIFIER_NAME}: ScalarMLPFunction without a nonlinearity between its "
+                                      f"{depth + 1} layers (deep linear net) has no mirror here")
+        acts = [m for m in layers if not hasattr(m, "weight") and type(m).__name__ != "ParametrizedScalarLinearLayer"]
+        for m in acts:
+            n = type(m).__name__.lower()
+            if n in ("silu", "tanh", "gelu", "mish", "sigmoid", "softplus"):
+                this = n
+            elif n == "shiftedsoftplus":
+                this = "ssp"
+            else:
+                # nonlinearity "None" / "null" builds torch.nn.Identity modules with is_nonlinear = True (mlp.py:29-36,176-180):
+                # converting that to SiLU would change the function silently
+                raise NotImplementedError(f"{FULL_MODIFIER_NAME}: activation module {type(m).__name__} between the layers "
+                                          "of a ScalarMLPFunction is not one this package mirrors")
+            if nonlin is not None and this != nonlin:
+                raise NotImplementedError(f"{FULL_MODIFIER_NAME}: mixed activations {nonlin} / {this} in one ScalarMLPFunction")
+            nonlin = this
+        if nonlin is None:
+            raise NotImplementedError(f"{FULL_MODIFIER_NAME}: no activation module found in a ScalarMLPFunction of depth {depth}")
     has_bias = bool(getattr(fn, "has_bias", False) or (getattr(fn, "bias", False) is True))
     return dict(depth=depth, width=width, nonlinearity=nonlin if nonlin is not None else "silu", bias=has_bias)
+
+
+def _check_mlp_alphas(new_fn, old_fn, where: str) -> None:
+    """The rebuilt layers recompute ``alpha = gain / sqrt(fan_in)`` from the defaults (``forward_weight_init=True``, no
+    parametrization): compare with what the reference layers actually carry and refuse on any difference (a model built with
+    ``forward_weight_init=False`` or a weight parametrization would otherwise be evaluated with other constants)."""
+    def linears(fn):
+        return [m for m in fn.mlp if hasattr(m, "weight") and hasattr(m, "alpha")]
+
+    if any("parametrizations" in name for name, _ in old_fn.named_modules()):
+        raise NotImplementedError(f"{FULL_MODIFIER_NAME}: {where} uses a weight parametrization")
+    a, b = linears(new_fn), linears(old_fn)
+    if len(a) != len(b):
+        raise RuntimeError(f"{FULL_MODIFIER_NAME}: {where}: {len(b)} reference layers, {len(a)} rebuilt")
+    for k, (m_new, m_old) in enumerate(zip(a, b)):
+        x, y = float(m_new.alpha), float(m_old.alpha)
+        if abs(x - y) > 1e-6 * max(1.0, abs(y)):
+            raise NotImplementedError(f"{FULL_MODIFIER_NAME}: {where} layer {k}: reference alpha {y!r}, rebuilt {x!r} "
+                                      "(forward_weight_init=False or a non-default gain)")
 
 
 def _avg_num_neighbors(norm, type_names):
@@ -225,6 +260,15 @@ def _factories(model) -> Dict[str, Callable]:
                   avg_num_neighbors=_avg_num_neighbors(conv.avg_num_neighbors_norm, names))
         new = ann.ConvNetLayer(irreps_in=_irreps_dict(old.irreps_in), feature_irreps_hidden=str(old.feature_irreps_hidden),
                                convolution_kwargs=kw, resnet=bool(old.resnet), **_gate_kwargs(old.equivariant_nonlin))
+        _check_mlp_alphas(new.conv.edge_mlp, conv.edge_mlp, "the radial MLP of a ConvNetLayer")
+        # the factor itself, not its reconstruction: avg -> 1/sqrt(avg) through the reference's float32 buffer and back is
+        # not the identity in the last bit
+        old_c, new_norm = getattr(conv.avg_num_neighbors_norm, "norm_const", None), new.conv.avg_num_neighbors_norm
+        if old_c is not None and tuple(old_c.shape) == tuple(new_norm.norm_const.shape):
+            with torch.no_grad():
+                new_norm.norm_const.copy_(old_c.detach().to(new_norm.norm_const.dtype))
+            if new_norm.norm_shortcut:
+                new_norm.norm_scalar = float(old_c.detach().reshape(-1)[0])
         if str(new.irreps_out[AtomicDataDict.NODE_FEATURES_KEY]) != str(old.irreps_out[AtomicDataDict.NODE_FEATURES_KEY]):
             raise RuntimeError(f"{FULL_MODIFIER_NAME}: rebuilt ConvNetLayer produces "
                                f"{new.irreps_out[AtomicDataDict.NODE_FEATURES_KEY]}, the reference one "
@@ -233,9 +277,11 @@ def _factories(model) -> Dict[str, Callable]:
 
     def scalar_mlp(old):
         shape = _mlp_shape(old.mlp_module)
-        return ann.ScalarMLP(output_dim=int(old.mlp_module.dims[-1]), hidden_layers_depth=shape["depth"],
-                             hidden_layers_width=shape["width"], nonlinearity=shape["nonlinearity"], bias=shape["bias"],
-                             field=old.field, out_field=old.out_field, irreps_in=_irreps_dict(old.irreps_in))
+        new = ann.ScalarMLP(output_dim=int(old.mlp_module.dims[-1]), hidden_layers_depth=shape["depth"],
+                            hidden_layers_width=shape["width"], nonlinearity=shape["nonlinearity"], bias=shape["bias"],
+                            field=old.field, out_field=old.out_field, irreps_in=_irreps_dict(old.irreps_in))
+        _check_mlp_alphas(new.mlp_module, old.mlp_module, f"ScalarMLP({old.field} -> {old.out_field})")
+        return new
 
     def scale_shift(old):
         def val(t, has):

@@ -220,13 +220,43 @@ class EdgeTopology:
                 ready.record(side)
                 self._side_ready = ready
 
+    def _side_tensors(self):
+        """Everything ``prefetch_backward_lists`` allocated on the side stream (the caching allocator ties a block to the
+        stream it was allocated on: a consumer on another stream has to be recorded, or an evicted topology's lists could be
+        handed out again while that consumer's kernels still read them)."""
+        out = []
+        cached = getattr(self, "_pairing", None)
+        pairing = cached[1] if cached is not None else None
+        if pairing is not None:
+            out += [pairing.rows, pairing.rep_edge, pairing.partner, pairing._slots_src, pairing._slots_dst]
+            if pairing._owner_csr is not None:
+                out += list(pairing._owner_csr)
+        if self._by_src is not None:
+            out += list(self._by_src)
+        return [t for t in out if isinstance(t, torch.Tensor) and t.is_cuda]
+
+    def _record_side(self, cur) -> None:
+        if torch.cuda.is_current_stream_capturing():
+            return  # (inside a capture the graph owns the memory; GraphedStep keeps the topology alive)
+        seen = self.__dict__.setdefault("_side_recorded", set())
+        key = (cur.cuda_stream, self._side_ready is not None)
+        if key in seen:
+            return
+        seen.add(key)
+        for t in self._side_tensors():
+            t.record_stream(cur)
+
     def _wait_pair(self) -> None:
         if self._pair_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._pair_ready)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._pair_ready)
+            self._record_side(cur)
 
     def _wait_side(self) -> None:
         if self._side_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._side_ready)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._side_ready)
+            self._record_side(cur)
 
     @property
     def by_dst(self):

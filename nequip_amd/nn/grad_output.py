@@ -109,6 +109,34 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         """Disable force and stress computation."""
         return replace_submodules(model, cls, lambda old: cls(func=old.func, do_derivatives=False))
 
+    def _energy_seed_allowed(self) -> bool:
+        """True when ``d(total_energy.sum()) / d(per-atom energy) == 1`` follows from the STRUCTURE of ``func``: a sequential
+        chain whose last module is a plain sum ``AtomwiseReduce`` (no constant, no ``avg_num_atoms``) from the per-atom
+        energies to the total energy.  Anything else -- a scaled reduce, a term added to the total energy afterwards, a
+        ``func`` that is not a chain (``enable_NequipAMD_full`` wraps arbitrary reference / third-party chains) -- keeps the
+        reference's ``autograd.grad(total_energy.sum())`` (``nequip/nn/grad_output.py:217-221``).  Decided once per chain
+        (re-decided when the chain's modules change)."""
+        K = AtomicDataDict
+        func = self.func
+        mods = list(func.children()) if isinstance(func, torch.nn.Sequential) else None
+        key = None if mods is None else tuple(id(m) for m in mods)
+        cached = self.__dict__.get("_seed_ok")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        ok = False
+        if mods:
+            last = mods[-1]
+            ok = (type(last).__name__ == "AtomwiseReduce" and getattr(last, "reduce", None) == "sum"
+                  and getattr(last, "field", None) == K.PER_ATOM_ENERGY_KEY
+                  and getattr(last, "out_field", None) == K.TOTAL_ENERGY_KEY
+                  and float(getattr(last, "constant", 1.0)) == 1.0 and not getattr(last, "avg_num_atoms", None))
+            # nothing earlier in the chain may write the total energy either (the reduce would overwrite it, but a module
+            # that READS it could feed another output): the reduce must be the only module that mentions the key
+            ok = ok and not any(getattr(m, "out_field", None) == K.TOTAL_ENERGY_KEY or getattr(m, "field", None) == K.TOTAL_ENERGY_KEY
+                                for m in mods[:-1])
+        self.__dict__["_seed_ok"] = (key, ok)
+        return ok
+
     def _forward_inference(self, data, pos, batch, num_batch: int, has_cell: bool):
         """First-order (eval mode) evaluation of the same quantities without the strain bookkeeping.
 
@@ -142,7 +170,7 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         data[K.EDGE_VECTORS_KEY] = edge_vec
         data = self.func(data)
         with inputs_only_backward():
-            pe = data.get(K.PER_ATOM_ENERGY_KEY)
+            pe = data.get(K.PER_ATOM_ENERGY_KEY) if self._energy_seed_allowed() else None
             if (pe is not None and pe.requires_grad and not tracing and pe.dim() == 2 and pe.shape[1] == 1
                     and os.environ.get("NQA_NO_ENERGY_SEED", "") in ("", "0")):
                 # d(sum of the frames' total energies) / d(per-atom energy) = 1: seed the backward at the per-atom energies

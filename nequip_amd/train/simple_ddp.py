@@ -64,5 +64,18 @@ class SimpleDDPStrategy:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def backward(self, loss: torch.Tensor, defer_parameter_gradients: bool = True, **kwargs) -> None:
+        """``loss.backward()`` the way the shipped training step runs it (``bench.py --workload train256``): parameter
+        gradients of the HIP modules leave the data chain on a side stream (``utils/wgrad.py::deferred_parameter_gradients``;
+        inert on CPU tensors and with ``NQA_DEFER_PARAM_GRADS=0``) and are joined when the block exits -- BEFORE
+        ``post_backward`` reads ``.grad``, which is the order the deferral requires.  Call ``post_backward()`` next."""
+        from ..utils.wgrad import deferred_parameter_gradients
+
+        if defer_parameter_gradients:
+            with deferred_parameter_gradients():
+                loss.backward(**kwargs)
+        else:
+            loss.backward(**kwargs)
+
     def post_backward(self, closure_loss: torch.Tensor = None) -> None:
         all_reduce_gradients(self.model.parameters(), self.group)

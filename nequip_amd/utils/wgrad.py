@@ -172,7 +172,15 @@ def _defer_stream(device) -> "torch.cuda.Stream":
 @contextlib.contextmanager
 def deferred_parameter_gradients():
     """Around ``loss.backward()``: see above.  Not re-entrant (an inner block is a no-op); gradients taken with
-    ``torch.autograd.grad(..., parameters)`` inside the block would miss the deferred contributions -- use ``.backward()``."""
+    ``torch.autograd.grad(..., parameters)`` inside the block would miss the deferred contributions -- use ``.backward()``.
+
+    **Restriction.**  The deferred parameters get ``None`` from autograd and their ``.grad`` is written when the block exits:
+    ``AccumulateGrad``, post-accumulate hooks and the reducer hooks of ``torch.nn.parallel.DistributedDataParallel`` never
+    fire for them.  The block therefore only composes with a gradient synchronisation that runs AFTER it -- this package's
+    ``SimpleDDPStrategy.post_backward`` (one flat all-reduce over ``.grad``, the reference's ``train/simple_ddp.py:26-59``;
+    ``SimpleDDPStrategy.backward`` wraps the block itself) -- and a parameter with gradient hooks raises here instead of
+    silently skipping them.  When the block exits with an exception (a failed backward, an aborted graph capture) nothing is
+    flushed: the side stream is joined and the bucket dropped, ``.grad`` is left as it was."""
     global _deferred
     if _deferred is not None or os.environ.get("NQA_DEFER_PARAM_GRADS", "1") in ("0",):
         yield
@@ -181,7 +189,11 @@ def deferred_parameter_gradients():
     _deferred = bucket
     try:
         yield
-    finally:
+    except BaseException:
+        _deferred = None
+        _drop_deferred(bucket)
+        raise
+    else:
         _deferred = None
         _flush_deferred(bucket)
 
@@ -195,6 +207,7 @@ def defer(param: torch.Tensor, make, *reads) -> None:
     """``make()`` -> this backward node's contribution to ``param.grad`` (any shape with ``param.numel()`` elements), evaluated on
     the side stream behind what the current stream has queued; ``reads``: current-stream tensors it reads."""
     dev = param.device
+    _check_no_grad_hooks(param)
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))  # (everything `make` reads has been queued by now)
     pending = _deferred.setdefault("_pending", [])
@@ -220,6 +233,27 @@ def _launch_deferred(bucket, item) -> None:
             bucket[id(param)] = [param, g]
         else:
             ent[1].add_(g)
+
+
+def _check_no_grad_hooks(param: torch.Tensor) -> None:
+    """A deferred parameter never reaches ``AccumulateGrad``: refuse parameters whose gradient somebody listens to (tensor
+    hooks, post-accumulate-grad hooks).  torch DDP's reducer hooks the grad-accumulator NODE, which cannot be seen from the
+    parameter: that combination is excluded by the docstring of the block, not detected here."""
+    if getattr(param, "_backward_hooks", None) or getattr(param, "_post_accumulate_grad_hooks", None):
+        raise RuntimeError("deferred_parameter_gradients(): a parameter with gradient hooks would never see them fire (its "
+                           "gradient bypasses autograd's accumulation).  Use SimpleDDPStrategy (all-reduce after the block) "
+                           "instead of torch DDP / hooks, or set NQA_DEFER_PARAM_GRADS=0")
+
+
+def _drop_deferred(bucket) -> None:
+    """The block exited with an exception: no launches, no ``.grad`` writes -- only make sure nothing on the side stream is
+    still reading tensors the caller is about to free."""
+    bucket.pop("_pending", None)
+    devs = {param.device for param, _ in bucket.values()}
+    for dev in devs:
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(dev).wait_stream(_defer_stream(dev))
+    bucket.clear()
 
 
 def _flush_deferred(bucket) -> None:

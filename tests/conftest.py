@@ -1,6 +1,9 @@
 import os
 import sys
 
+# Several tests import the reference from /root/reference (read-only): never leave __pycache__/*.pyc behind there.
+sys.dont_write_bytecode = True
+
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))

@@ -12,6 +12,8 @@ containers before saving.  tests/test_converted_reference_model.py (GPU) compare
 """
 import os
 import sys
+
+sys.dont_write_bytecode = True  # (the reference tree is read-only: no __pycache__ under /root/reference)
 import types
 
 import torch

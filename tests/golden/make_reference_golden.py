@@ -27,6 +27,8 @@ import importlib.abc
 import importlib.machinery
 import os
 import sys
+
+sys.dont_write_bytecode = True  # (the reference tree is read-only: no __pycache__ under /root/reference)
 import types
 
 import numpy as np

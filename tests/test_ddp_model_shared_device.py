@@ -6,6 +6,10 @@ multiplied by ``world_size`` before ``backward`` (nequip/train/lightning.py:259-
 (nequip/train/simple_ddp.py:26-59).  Rank 0 then repeats the step single-process on the full batch: the averaged
 gradients and the parameters after one Adam step must agree.
 
+The second parametrisation runs the backward through ``SimpleDDPStrategy.backward`` = ``with deferred_parameter_gradients():
+loss.backward()``: the deferred gradients must be in ``.grad`` before ``post_backward`` reads it, on
+both ranks, and the averaged gradients must still equal the single-process full batch (which uses plain autograd).
+
 What this does NOT cover: RCCL itself with more than one rank (needs two physical GPUs; ``tests/test_ddp_rccl.py``
 covers the one-rank RCCL calls, the driver's ``bench.py --gpus N`` the throughput)."""
 import os
@@ -66,7 +70,18 @@ start = {{k: v.detach().clone() for k, v in model.state_dict().items()}}
 opt = torch.optim.Adam(model.parameters(), lr=1e-2)
 opt.zero_grad(set_to_none=True)
 loss = loss_on(model, list(range(rank, NF, world)))            # frames sharded rank::world
-(loss * strategy.world_size).backward()                         # lightning.py:259-266
+if {deferred!r}:
+    # the shipped training step (bench.py --workload train256): parameter gradients of the HIP modules leave the data chain
+    # on a side stream and land in .grad when the block exits -- BEFORE post_backward all-reduces .grad (utils/wgrad.py)
+    from nequip_amd.utils import wgrad
+    seen = []
+    orig_flush = wgrad._flush_deferred
+    wgrad._flush_deferred = lambda bucket: (seen.append(len([k for k in bucket if k != "_pending"]) + len(bucket.get("_pending", []))), orig_flush(bucket))[1]
+    strategy.backward(loss * strategy.world_size)
+    wgrad._flush_deferred = orig_flush
+    assert seen and seen[0] > 0, "no parameter gradient took the deferred route: the test would not cover the ordering"
+else:
+    (loss * strategy.world_size).backward()                     # lightning.py:259-266
 local = torch.cat([p.grad.detach().view(-1).clone() for p in model.parameters()])
 strategy.post_backward(loss)                                    # flat all-reduce, averaged
 avg = torch.cat([p.grad.detach().view(-1).clone() for p in model.parameters()])
@@ -111,7 +126,8 @@ dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_model_level_ddp_two_ranks_on_one_device(device, tmp_path):
+@pytest.mark.parametrize("deferred", [False, True], ids=["autograd", "deferred_parameter_gradients"])
+def test_model_level_ddp_two_ranks_on_one_device(device, tmp_path, deferred):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -120,7 +136,7 @@ def test_model_level_ddp_two_ranks_on_one_device(device, tmp_path):
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
                 OMP_NUM_THREADS="8")
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
+    script.write_text(_WORKER.format(root=ROOT, deferred=deferred))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []

@@ -448,3 +448,56 @@ def test_deferred_parameter_gradients_block_is_inert_without_the_gpu_kernels():
     assert wg._deferred is None
     for p, r in zip(lin.parameters(), ref):
         assert torch.equal(p.grad, r)
+
+
+def test_energy_seed_shortcut_is_decided_by_the_chain_structure():
+    """the backward may be seeded at the per-atom energies only when total_energy IS their plain sum by
+    construction (last module of a sequential chain = sum AtomwiseReduce of PER_ATOM_ENERGY -> TOTAL_ENERGY); any other
+    ``func`` keeps the reference's autograd.grad(total_energy.sum()) (nequip/nn/grad_output.py:217-221)."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.nn import AtomwiseReduce, ForceStressOutput
+    from nequip_amd.nn._graph_mixin import SequentialGraphNetwork
+
+    class Tail(torch.nn.Module):  # a module behind the reduce (e.g. a pair-potential term added to the total energy)
+        def forward(self, data):
+            return data
+
+    irr = {K.PER_ATOM_ENERGY_KEY: "1x0e"}
+    plain = AtomwiseReduce(irreps_in=irr, reduce="sum", field=K.PER_ATOM_ENERGY_KEY, out_field=K.TOTAL_ENERGY_KEY)
+    seq = torch.nn.Sequential(torch.nn.Identity(), plain)
+    fso = ForceStressOutput.__new__(ForceStressOutput)
+    torch.nn.Module.__init__(fso)
+    fso.func = seq
+    assert fso._energy_seed_allowed()
+    fso.func = torch.nn.Sequential(torch.nn.Identity(), plain, Tail())
+    assert not fso._energy_seed_allowed()  # (re-decided: the chain changed)
+    other = AtomwiseReduce(irreps_in={"x": "1x0e"}, reduce="sum", field="x", out_field=K.TOTAL_ENERGY_KEY)
+    fso.func = torch.nn.Sequential(other)
+    assert not fso._energy_seed_allowed()
+    scaled = AtomwiseReduce(irreps_in=irr, reduce="sum", field=K.PER_ATOM_ENERGY_KEY, out_field=K.TOTAL_ENERGY_KEY)
+    scaled.constant = 0.5  # the reference's normalised reduce (nequip/nn/atomwise.py: constant = 1/sqrt(avg_num_atoms))
+    fso.func = torch.nn.Sequential(scaled)
+    assert not fso._energy_seed_allowed()
+    fso.func = Tail()  # not a chain at all
+    assert not fso._energy_seed_allowed()
+
+
+def test_deferred_parameter_gradients_refuse_hooks_and_drop_on_exceptions():
+    """a deferred parameter bypasses AccumulateGrad, so gradient hooks on it are an error; a block that exits
+    with an exception writes no ``.grad``."""
+    from nequip_amd.utils import wgrad
+
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.register_hook(lambda g: g)
+    with pytest.raises(RuntimeError, match="gradient hooks"):
+        wgrad._check_no_grad_hooks(p)
+    q = torch.nn.Parameter(torch.zeros(3))
+    q.register_post_accumulate_grad_hook(lambda t: None)
+    with pytest.raises(RuntimeError, match="gradient hooks"):
+        wgrad._check_no_grad_hooks(q)
+    wgrad._check_no_grad_hooks(torch.nn.Parameter(torch.zeros(3)))
+    with pytest.raises(ValueError):
+        with wgrad.deferred_parameter_gradients():
+            assert wgrad._deferred is not None
+            raise ValueError("backward failed")
+    assert wgrad._deferred is None  # (the block is closed, nothing was flushed)
