@@ -766,6 +766,9 @@ def _emit(st: Structure) -> str:
         # scalar select on a.N < 0, never true): 1: grad_w stores, 2: grad_x row stores, 4: the gathered rows are the
         # owner's own rows, 8: weight loads, 16: grad_y stores
         pair_abl = int(os.environ.get("NQA_GEN_PAIR_ABL", "0"))
+        # lab: the other node's grad_x contribution as atomic adds into a [N, dim_in1] accumulator (a.gxe, zeroed by the
+        # caller, lane-contiguous component rows) instead of one row per pair -- no [P, dim_in1] round trip through HBM
+        pair_gx_atomic = os.environ.get("NQA_GEN_PAIR_GX_ATOMIC", "0") != "0"
 
         def pair_path(out, pth, xs, gname, ys, tag_):
             """One path of one directed edge: B{tag}{jj} (-> grad_w, grad_y) and the grad_x terms per input component."""
@@ -859,8 +862,10 @@ def _emit(st: Structure) -> str:
                 for j in used_y:
                     for i in range(2 * st.in2_ls[j] + 1):
                         out.append(f"    s_ += yb{j}I{sfx}[{i}] + yb{j}X{sfx}[{i}];")
-                out += [f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;",
-                        f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;"]
+                out += [(f"    T* __restrict__ gwr_e = a.gw + (int64_t)(a.N < 0 ? pr{sfx} : 0) * a.wn;" if pair_abl & 1 else
+                         f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;"),
+                        (f"    T* __restrict__ gxr = a.gxe + (int64_t)(a.N < 0 ? ({slot}) : 0) * a.din;" if pair_abl & 2 else
+                         f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;")]
                 for pth in range(NP):
                     out.append(f"    {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', f'wv{sfx}[{pth}] + s_')};")
                 for i in range(XD):
@@ -880,6 +885,7 @@ def _emit(st: Structure) -> str:
                    (f"    T* __restrict__ gwr_e = a.gw + (int64_t)(a.N < 0 ? pr{sfx} : 0) * a.wn;" if pair_abl & 1 else
                     f"    T* __restrict__ gwr_e = a.gw + (int64_t)pr{sfx} * a.wn;"),
                    (f"    T* __restrict__ gxr = a.gxe + (int64_t)(a.N < 0 ? ({slot}) : 0) * a.din;" if pair_abl & 2 else
+                    f"    T* __restrict__ gxr = a.gxe + (int64_t)jn{sfx} * a.din;" if pair_gx_atomic else
                     f"    T* __restrict__ gxr = a.gxe + (int64_t)({slot}) * a.din;")]
             last_path_of_block = {b_: p_ for p_, (b_, _, _) in enumerate(st.instr)}
             first_path_of_block = {}
@@ -919,10 +925,13 @@ def _emit(st: Structure) -> str:
                 if last_path_of_block[b_] == pth:
                     out.append("      if (GX && act) {")
                     for i in range(d1):
-                        out.append(f"        {emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')};")
+                        if pair_gx_atomic:
+                            out.append(f"        unsafeAtomicAdd(spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb), gxa[{xpre[b_] + i}]);")
+                        else:
+                            out.append(f"        {emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')};")
                     out.append("      }")
             unused = [i for b in range(NB) if b not in first_path_of_block for i in range(xpre[b], xpre[b] + 2 * st.in1_ls[b] + 1)]
-            if unused:
+            if unused and not pair_gx_atomic:
                 out.append("      if (GX && act) {")
                 for i in unused:
                     out.append(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
@@ -1086,7 +1095,7 @@ def _emit(st: Structure) -> str:
     # so every value becomes a pair (.x = in, .y = out): G[k] = (g_o[k], g_j[k]), X[i] = (x_j[i], x_o[i]), Y = (y_in, y_out),
     # the weight is shared.  One packed stream evaluates both edges; the owner-side intermediates T_ij(g_o) that the scalar
     # kernel hoisted out of the pair loop (~115 registers) are recomputed for free in the .x halves.
-    if pair_ok and os.environ.get("NQA_GEN_PAIR_PK", "1") != "0":
+    if pair_ok and os.environ.get("NQA_GEN_PAIR_PK", "0") != "0":
         pk_occ = os.environ.get("NQA_GEN_PAIR_PK_OCC", "2")
         pk_prefetch = os.environ.get("NQA_GEN_PAIR_PK_PREFETCH", "0") != "0"
         A("template <typename T, int WPN, bool FULL, bool GX>")
@@ -1272,6 +1281,402 @@ def _emit(st: Structure) -> str:
             for i in range(d):
                 A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)uc * {d} + {i}] = gxO[{xpre[b] + i}];")
         A("  }")
+        A("}")
+
+    # ------------------------------------------------------------------ pair-centric backward, LDS ring (round 6)
+    # What held bwd_pair_kernel at half of the HBM roof (profiles/r6_pair_*.txt, r6_memonly_*.txt): one pair in flight per
+    # wavefront at two wavefronts per SIMD.  The same loop WITHOUT its arithmetic takes 85 % of the kernel's time, with every
+    # stream pointed at cache-hot rows still 42 % -- it is the serial chain indices -> row loads -> arithmetic -> stores of
+    # each pair, 8 of them per CU, not bandwidth and not the vector ALU; a second operand set in registers spills (254 used).
+    # Here the rows of the NEXT pair travel global -> LDS by LDS-DMA (no registers) while the current pair is evaluated out
+    # of the LDS: every wavefront owns a ring of kRingSlots slots in the CU's 160 KB (20 KB per wavefront at two per SIMD);
+    # a pair's rows (w, x[other], grad_out[other], the two y rows: 14 KB for the l_max = 2 middle layer) are cut into
+    # kRingChunks = kRingSlots - 1 chunks in the order the paths consume them, so that one whole pair is always in flight
+    # behind the one being evaluated.  After chunk q is evaluated its slot is refilled with chunk q + kRingSlots.  The copies
+    # are 16 bytes per lane (dword-per-lane reads reach 4.0 TB/s on this part, 16-byte ones 6.7: scripts/micro/store_bw.hip);
+    # lane l of an instruction lands at slot + 16 l, the LDS image of a segment is the 64 channels' values in row order, and
+    # the evaluation reads its operands with ds_read (4 u + component) right where it uses them -- no operand arrays in
+    # registers.  Ordering: the issuing wavefront's counted s_waitcnt vmcnt(N), N = the copies and stores issued since
+    # (static: one pair's worth of each in the steady state, tp_spec.h spec_wait_vm); the first pair of a wavefront counts
+    # its own shorter history, the last one waits for everything.  scripts/check_ring_waits.py re-counts N in the ISA.
+    ring_ok = pair_ok and os.environ.get("NQA_GEN_PAIR_RING", "1") != "0"
+    if ring_ok:
+        import itertools
+        RING_WAVE = int(os.environ.get("NQA_GEN_RING_WAVE_BYTES", "20480"))
+        U = 16  # bytes per lane of a copy
+        # sizes per 64-channel chunk, in 16-byte units (64 channels x 4 B = 16 units per component)
+        w_units = 16
+        yrow_units = (S * 4 + U - 1) // U
+        first_path_of_block_r = {}
+        last_path_of_block_r = {}
+        for p_, (b_, _, _) in enumerate(st.instr):
+            first_path_of_block_r.setdefault(b_, p_)
+            last_path_of_block_r[b_] = p_
+        path_units = [w_units + 16 * (2 * st.out_ls[s_] + 1) for (_, _, s_) in st.instr]
+        xblk_units = {b_: 16 * (2 * st.in1_ls[b_] + 1) for b_ in used_blocks}
+
+        def ring_partition(C):
+            """Contiguous path ranges + the chunk of every x block (not later than its first use): minimal largest chunk."""
+            best = None
+            for cuts in itertools.combinations(range(1, NP), C - 1):
+                bounds = [0] + list(cuts) + [NP]
+                chunk_of_path = [0] * NP
+                for c_ in range(C):
+                    for p_ in range(bounds[c_], bounds[c_ + 1]):
+                        chunk_of_path[p_] = c_
+                base = [sum(path_units[bounds[c_]:bounds[c_ + 1]]) for c_ in range(C)]
+                base[0] += 2 * yrow_units
+                choices = [range(chunk_of_path[first_path_of_block_r[b_]] + 1) for b_ in used_blocks]
+                for place in itertools.product(*choices):
+                    tot = list(base)
+                    for b_, c_ in zip(used_blocks, place):
+                        tot[c_] += xblk_units[b_]
+                    key = (max(tot), sum(place))
+                    if best is None or key < best[0]:
+                        best = (key, bounds, dict(zip(used_blocks, place)))
+            return best
+
+        ring_plan = None
+        for C in range(1, min(NP, 6) + 1):
+            cand = ring_partition(C) if NP >= C else None
+            if cand is None:
+                continue
+            slot_bytes = cand[0][0] * U
+            if RING_WAVE // slot_bytes >= C + 1:
+                ring_plan = (C, slot_bytes, cand[1], cand[2])
+                break
+        if ring_plan is None:
+            ring_ok = False
+    if ring_ok:
+        # lab only: 1 = no result stores (never-true guard), 2 = no copies (stale LDS), 4 = no arithmetic (operands summed)
+        ring_abl = int(os.environ.get("NQA_GEN_RING_ABL", "0"))
+        # kinds of copies that are non-temporal (w, x, g): the weight rows are read once (lab: 545 -> 533 us; x / g too: slower)
+        ring_nt = set(os.environ.get("NQA_GEN_RING_NT", "w").replace("+", ",").split(","))
+        RC, RSLOT, rbounds, xplace = ring_plan
+        RN = RC + 1
+        # chunk images: [w segments][x segments][g segments][y_in][y_out]; a segment = (kind, id, units)
+        chunk_paths = [list(range(rbounds[c_], rbounds[c_ + 1])) for c_ in range(RC)]
+        img = []      # per chunk: dict kind -> list of (id, start_unit_in_stream, units)
+        lds_off = []  # per chunk: dict (kind, id) -> byte offset inside the slot
+        dma = []      # per chunk: list of (kind, lds_byte_off, nlanes, [(lane_lo, lane_hi, id, unit_in_segment_at_lane_lo)])
+        for c_ in range(RC):
+            streams = {"w": [(p_, w_units) for p_ in chunk_paths[c_]],
+                       "x": [(b_, xblk_units[b_]) for b_ in used_blocks if xplace[b_] == c_],
+                       "g": [(st.instr[p_][2], 16 * (2 * st.out_ls[st.instr[p_][2]] + 1)) for p_ in chunk_paths[c_]]}
+            offs, ins, pos = {}, [], 0
+            for kind in ("w", "x", "g"):
+                segs, start = [], 0
+                for ident, units in streams[kind]:
+                    offs[(kind, ident)] = (pos + start) * U
+                    segs.append((ident, start, units))
+                    start += units
+                for i0 in range(0, start, 64):
+                    nl = min(64, start - i0)
+                    pieces = []
+                    for ident, sstart, units in segs:
+                        lo, hi = max(sstart, i0), min(sstart + units, i0 + nl)
+                        if lo < hi:
+                            pieces.append((lo - i0, hi - i0, ident, lo - sstart))
+                    ins.append((kind, (pos + i0) * U, nl, pieces))
+                pos += start
+            if c_ == 0:
+                offs[("y", "I")] = pos * U
+                ins.append(("yI", pos * U, S, None))
+                pos += yrow_units
+                offs[("y", "X")] = pos * U
+                ins.append(("yX", pos * U, S, None))
+                pos += yrow_units
+            assert pos * U <= RSLOT, (st.name, c_, pos * U, RSLOT)
+            lds_off.append(offs)
+            dma.append(ins)
+        STG = "if (a.N < 0) " if ring_abl & 1 else ""
+        D_chunk = [len(ins) for ins in dma]
+        D_pair = sum(D_chunk)
+        # stores a chunk is certain to issue (grad_w per path, the grad_x row components of the blocks that end in it); the two
+        # grad_y stores of the last chunk are not counted (an under-count only shortens the look-ahead by two operations)
+        Sgw = [len(chunk_paths[c_]) for c_ in range(RC)]
+        Sgx = [sum(2 * st.in1_ls[b_] + 1 for b_ in used_blocks if rbounds[c_] <= last_path_of_block_r[b_] < rbounds[c_ + 1])
+               for c_ in range(RC)]
+        unused_r = [i for b in range(NB) if b not in first_path_of_block_r for i in range(xpre[b], xpre[b] + 2 * st.in1_ls[b] + 1)]
+        Sgx_atom = list(Sgx)  # (ATOM: the components no path writes are not touched at all)
+        Sgx[RC - 1] += len(unused_r)
+        if ring_abl & 1:
+            Sgw, Sgx, Sgx_atom = [0] * RC, [0] * RC, [0] * RC
+        assert sum(Sgw) + sum(Sgx) + D_pair < 64, "vmcnt range"
+
+        def src_base(kind, ident):
+            if kind == "w":
+                return f"(unsigned)(mul * {ident} + chunk * 64) * 4u"
+            if kind == "x":
+                return f"(unsigned)(mul * {xpre[ident]} + chunk * {64 * (2 * st.in1_ls[ident] + 1)}) * 4u"
+            return f"(unsigned)(mul * {opre[ident]} + chunk * {64 * (2 * st.out_ls[ident] + 1)}) * 4u"
+
+        A(f"constexpr int kRingChunks = {RC}, kRingSlots = {RN}, kRingSlotBytes = {RSLOT}, kRingWaveBytes = {RN * RSLOT};")
+        A("// ring chunks: " + "; ".join(
+            f"{c_}: paths {chunk_paths[c_][0]}-{chunk_paths[c_][-1]}" + "".join(f" +x{b_}" for b_ in used_blocks if xplace[b_] == c_)
+            + f", {D_chunk[c_]} copies, {Sgw[c_]}+{Sgx[c_]} stores" for c_ in range(RC)))
+        A("// ATOM: the other node's grad_x contribution goes into a zeroed [N, dim_in1] accumulator (a.gxe, component rows of 64")
+        A("// channels as the per-pair rows) by floating-point atomics instead of one row per pair: no [P, dim_in1] round trip")
+        A("// through HBM and no row sum -- gx_acc_finish_kernel folds the accumulator into a.out.  (Sums in arrival order: the")
+        A("// low bits of grad_x differ from run to run; ATOM = false keeps the fixed-order rows.)")
+        A("template <int WPN, bool GX, bool ATOM>")
+        A("__global__ __launch_bounds__(256, 2) void bwd_pair_ring_kernel(const SpecArgs<float> a) {")
+        A("  typedef float T;")
+        A("  extern __shared__ __align__(16) unsigned char nqa_smem[];")
+        A("  const int lane = threadIdx.x & 63;")
+        A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+        A("  const int mul = a.mul;  // a multiple of 64 (the launcher sends other multiplicities to bwd_pair_kernel)")
+        A("  const int nchunk = mul >> 6;")
+        A("  const int64_t witem = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+        A("  const int64_t item = witem / WPN;")
+        A("  const int wsub = (int)(witem - item * WPN);")
+        A("  const bool valid = item < (int64_t)a.N * nchunk;  // (WPN < 4: the last workgroup may hold idle wavefronts)")
+        A("  const int node = spec_uniform(valid ? (int)(item / nchunk) : 0);")
+        A("  const int chunk = valid ? (int)(item - (int64_t)node * nchunk) : 0;")
+        A("  const int u = chunk * 64 + lane;")
+        A("  constexpr bool act = true, DUAL = false;")
+        A("  const int beg = a.rowptr[node], end = valid ? a.rowptr[node + 1] : beg;")
+        L.extend(lane_offsets("  ", want_x=True, want_g=True))
+        A("  const unsigned wbase = (unsigned)wid * (unsigned)kRingWaveBytes;  // this wavefront's ring (LDS byte address)")
+        A("  const unsigned l4 = (unsigned)lane * 4u, l16 = (unsigned)lane * 16u;")
+        A("  // per-lane source offsets of the copies (bytes from the row base; lane l moves 16 bytes)")
+        for c_ in range(RC):
+            for i_, (kind, loff, nl, pieces) in enumerate(dma[c_]):
+                if pieces is None or len(pieces) == 1:
+                    continue  # (one segment: its uniform offset goes into the scalar base, the lanes share l16)
+                expr = None
+                for lo, hi, ident, seg_unit in reversed(pieces):
+                    e_ = f"{src_base(kind, ident)} + (unsigned)({(seg_unit - lo) * U})"
+                    expr = e_ if expr is None else f"(lane < {hi} ? {e_} : {expr})"
+                A(f"  const unsigned ro{c_}_{i_} = ({expr}) + l16;")
+        A("  T gvO[kOD], gxO[kXD];")
+        L.extend(load_g("  ", "a.g + (int64_t)node * a.dout", "gvO"))
+        L.extend(load_x("  ", "(a.x + (int64_t)node * a.din)", sfx="O"))
+        A("#pragma unroll")
+        A("  for (int i = 0; i < kXD; ++i) gxO[i] = T(0);")
+
+        def ring_issue(ind, c_, sfx, slotexpr, lgkm=True):
+            """Copies of chunk c_ of the pair whose indices are in jn{sfx} / pr{sfx} / ei{sfx} / eo{sfx} into LDS slot `slotexpr`."""
+            if ring_abl & 2:
+                return []
+            out = [f"{ind}{{ const unsigned sb_ = wbase + (unsigned)({slotexpr}) * (unsigned)kRingSlotBytes;"]
+            if lgkm:
+                out.append(f"{ind}  spec_wait_lgkm();  // the slot's last reads have returned")
+            kinds = {k_ for k_, _, _, _ in dma[c_]}
+            if "w" in kinds:
+                out.append(f"{ind}  const T* __restrict__ wr_ = a.w + (int64_t)pr{sfx} * a.wn;")
+            if "x" in kinds:
+                out.append(f"{ind}  const T* __restrict__ xr_ = a.x + (int64_t)jn{sfx} * a.din;")
+            if "g" in kinds:
+                out.append(f"{ind}  const T* __restrict__ gr_ = a.g + (int64_t)jn{sfx} * a.dout;")
+            for i_, (kind, loff, nl, pieces) in enumerate(dma[c_]):
+                if kind == "yI":
+                    out.append(f"{ind}  spec_glds4<{nl}>(sb_ + {loff}u, a.y + (int64_t)ei{sfx} * kS, l4);")
+                elif kind == "yX":
+                    out.append(f"{ind}  spec_glds4<{nl}>(sb_ + {loff}u, a.y + (int64_t)eo{sfx} * kS, l4);")
+                else:
+                    nt_ = ", true" if kind in ring_nt else ""
+                    if len(pieces) == 1:
+                        lo_, _, ident_, seg_unit_ = pieces[0]
+                        uoff = f"{src_base(kind, ident_)} + (unsigned)({(seg_unit_ - lo_) * U})"
+                        out.append(f"{ind}  spec_glds16<{nl}{nt_}>(sb_ + {loff}u, reinterpret_cast<const char*>({kind}r_) + ({uoff}), l16);")
+                    else:
+                        out.append(f"{ind}  spec_glds16<{nl}{nt_}>(sb_ + {loff}u, {kind}r_, ro{c_}_{i_});")
+            out.append(f"{ind}}}")
+            return out
+
+        # The pair indices (other node, weight row, the two edges) of up to 64 of this wavefront's pairs sit in four vector
+        # registers, lane l = the wavefront's l-th pair, fetched by ONE vector load per list before the loop; a pair's
+        # indices are then a v_readlane away.  (Per-pair scalar loads, as bwd_pair_kernel has them, are not available here:
+        # behind the "memory" clobbers of the copy / wait statements hipcc turns them into vector loads followed by vmcnt(0).)
+        def ring_block_load(ind, first_pair):
+            return [f"{ind}{{ const int i_ = beg + wsub + (({first_pair}) + lane) * WPN; const int ic_ = i_ < end ? i_ : end - 1;",
+                    f"{ind}  jnV = a.nbr[ic_]; prV = a.wid[ic_]; eiV = a.eid[ic_]; eoV = a.eid2[ic_]; }}"]
+
+        def ring_index_get(sfx, k, ind="    "):
+            return [f"{ind}jn{sfx} = __builtin_amdgcn_readlane(jnV, ({k}) & 63); pr{sfx} = __builtin_amdgcn_readlane(prV, ({k}) & 63);",
+                    f"{ind}ei{sfx} = __builtin_amdgcn_readlane(eiV, ({k}) & 63); eo{sfx} = __builtin_amdgcn_readlane(eoV, ({k}) & 63);"]
+
+        A("  int idx = beg + wsub;")
+        A("  int kk = 0;  // this wavefront's pair counter: pair kk sits in owner slot beg + wsub + kk * WPN")
+        A("  int jnA = 0, prA = 0, eiA = 0, eoA = 0, jnB = 0, prB = 0, eiB = 0, eoB = 0, jnC = 0, prC = 0, eiC = 0, eoC = 0;")
+        A("  int jnV = 0, prV = 0, eiV = 0, eoV = 0;")
+        A("  bool hasA = idx < end, hasB = idx + WPN < end, hasC = false;")
+        A("  if (hasA) {")
+        L.extend(ring_block_load("    ", "0"))
+        L.extend(ring_index_get("A", "0"))
+        L.extend(ring_index_get("B", "1"))
+        A("  }")
+        A("  // prologue: the whole first pair and the first chunk of the second fill the ring")
+        A("  if (hasA) {")
+        for c_ in range(RC):
+            L.extend(ring_issue("    ", c_, "A", str(c_), lgkm=False))
+        A("  }")
+        A("  if (hasB) {")
+        L.extend(ring_issue("    ", 0, "B", str(RC), lgkm=False))
+        A("  }")
+        A("  // the owner's rows are in their registers before the loop starts: hipcc, which does not see the copies, would")
+        A("  // otherwise wait for them inside the loop with a small vmcnt(n) of ITS count -- every iteration, draining the ring")
+        A("#pragma unroll")
+        A("  for (int k = 0; k < kOD; ++k) asm volatile(\"\" : \"+v\"(gvO[k]));")
+        for b in used_blocks:
+            for i in range(2 * st.in1_ls[b] + 1):
+                A(f"  asm volatile(\"\" : \"+v\"(xb{b}O[{i}]));")
+        A("  int rot = 0;       // slot of chunk 0 of pair A")
+        A("  bool first = true;")
+        A("  T qI[kS], qX[kS], gxa[kXD], gvJ[kOD];")
+        L.extend(decl_y("  ", "I") + decl_y("  ", "X") + decl_x("  ", "J"))
+        L.extend(decl_x("  ", "J2") + decl_x("  ", "O2"))  # (names the shared path emitter mentions under DUAL, never read)
+        A("  while (hasA) {")
+        A("    hasC = idx + 2 * WPN < end;")
+        A("    if (hasC) {")
+        A("      if (((kk + 2) & 63) == 0) {  // (a wavefront with more than 64 pairs: the next block of indices)")
+        L.extend(ring_block_load("        ", "kk + 2"))
+        A("      }")
+        L.extend(ring_index_get("C", "kk + 2", "      "))
+        A("    }")
+        A("    T* __restrict__ gwr_e = a.gw + (int64_t)prA * a.wn;")
+        A("    T* __restrict__ gxr = a.gxe + (int64_t)(ATOM ? jnA : idx) * a.din;")
+        A("#pragma unroll")
+        A("    for (int j = 0; j < kS; ++j) { qI[j] = T(0); qX[j] = T(0); }")
+        for c_ in range(RC):
+            lo = lds_off[c_]
+            nfirst = D_pair + sum(Sgw[:c_])
+            nfirst_gx = f"(ATOM ? {nfirst + sum(Sgx_atom[:c_])} : {nfirst + sum(Sgx[:c_])})"
+            nsteady = D_pair + sum(Sgw)
+            nsteady_gx = f"(ATOM ? {nsteady + sum(Sgx_atom)} : {nsteady + sum(Sgx)})"
+            A(f"    {{  // ---- chunk {c_}: paths {chunk_paths[c_][0]}..{chunk_paths[c_][-1]}")
+            A(f"      int s_ = rot + {c_}; s_ = s_ >= kRingSlots ? s_ - kRingSlots : s_;")
+            A("      const unsigned sb = wbase + (unsigned)s_ * (unsigned)kRingSlotBytes;")
+            A("      const unsigned char* __restrict__ cb = nqa_smem + sb;")
+            if not (ring_abl & 2):
+                A("      if (!hasB) spec_wait_vm<0>();")
+                A(f"      else if (first) spec_wait_vm<GX ? {nfirst_gx} : {nfirst}>();")
+                A(f"      else spec_wait_vm<GX ? {nsteady_gx} : {nsteady}>();")
+            if c_ == 0:
+                for j in used_y:
+                    for i in range(2 * st.in2_ls[j] + 1):
+                        A(f"      yb{j}I[{i}] = *reinterpret_cast<const T*>(cb + {lo[('y', 'I')] + 4 * (ypre[j] + i)});")
+                        A(f"      yb{j}X[{i}] = *reinterpret_cast<const T*>(cb + {lo[('y', 'X')] + 4 * (ypre[j] + i)});")
+            for b_ in used_blocks:
+                if xplace[b_] == c_:
+                    d1 = 2 * st.in1_ls[b_] + 1
+                    for i in range(d1):
+                        A(f"      xb{b_}J[{i}] = *reinterpret_cast<const T*>(cb + {lo[('x', b_)]} + l4 * {d1}u + {4 * i});")
+            for pth in chunk_paths[c_]:
+                b_, j, s_ = st.instr[pth]
+                d1, d3 = 2 * st.in1_ls[b_] + 1, 2 * st.out_ls[s_] + 1
+                if first_path_of_block_r[b_] == pth:
+                    for i in range(d1):
+                        A(f"      gxa[{xpre[b_] + i}] = T(0);")
+                A(f"      {{  // path {pth}")
+                A(f"        const T wv_ = *reinterpret_cast<const T*>(cb + {lo[('w', pth)]} + l4);")
+                for k in range(d3):
+                    A(f"        gvJ[{opre[s_] + k}] = T({slot_coeff[s_]!r}) * *reinterpret_cast<const T*>(cb + {lo[('g', s_)]} + l4 * {d3}u + {4 * k});")
+                if ring_abl & 4:
+                    A("        T s_ = wv_;")
+                    for k in range(d3):
+                        A(f"        s_ += gvJ[{opre[s_] + k}] + gvO[{opre[s_] + k}];")
+                    for i in range(d1):
+                        A(f"        s_ += xb{b_}J[{i}] + xb{b_}O[{i}];")
+                    for jj in range(2 * st.in2_ls[j] + 1):
+                        A(f"        s_ += yb{j}I[{jj}] + yb{j}X[{jj}];")
+                    for i in range(d1):
+                        A(f"        gxa[{xpre[b_] + i}] += s_; gxO[{xpre[b_] + i}] += s_;")
+                    A(f"        qI[{ypre[j]}] += s_; qX[{ypre[j]}] += s_;")
+                    A(f"        {STG}{{ {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 's_')}; }}")
+                    A("      }")
+                    if last_path_of_block_r[b_] == pth:
+                        A(f"      if (GX{' && a.N < 0' if ring_abl & 1 else ''}) {{")
+                        for i in range(d1):
+                            A(f"        {emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')};")
+                        A("      }")
+                    continue
+                body = []
+                live_i, gx_i = pair_path(body, pth, "J", "gvO", "I", "i")
+                for comp, expr in gx_i:
+                    if expr:
+                        body.append(f"        if (GX) gxa[{comp}] += wv_ * ({expr});")
+                live_x, gx_x = pair_path(body, pth, "O", "gvJ", "X", "x")
+                for comp, expr in gx_x:
+                    if expr:
+                        body.append(f"        if (GX) gxO[{comp}] += wv_ * ({expr});")
+                L.extend(body)
+                terms = [f"yb{j}I[{jj}] * Bi{jj}" for jj in live_i] + [f"yb{j}X[{jj}] * Bx{jj}" for jj in live_x]
+                gw_expr = " + ".join(terms) if terms else "T(0)"
+                A(f"        {STG}{{ const T r_ = {gw_expr}; {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'r_')}; }}")
+                for jj in live_i:
+                    A(f"        qI[{ypre[j] + jj}] += wv_ * Bi{jj};")
+                for jj in live_x:
+                    A(f"        qX[{ypre[j] + jj}] += wv_ * Bx{jj};")
+                A("      }")
+                if last_path_of_block_r[b_] == pth:
+                    A(f"      if (GX{' && a.N < 0' if ring_abl & 1 else ''}) {{")
+                    for i in range(d1):
+                        st_ = emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')
+                        A(f"        if (ATOM) unsafeAtomicAdd(spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb), gxa[{xpre[b_] + i}]); else {st_};")
+                    A("      }")
+            if c_ == RC - 1:
+                if unused_r:
+                    A("      if (GX && !ATOM) {")
+                    for i in unused_r:
+                        A(f"        *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
+                    A("      }")
+                A("      // refill this slot with chunk 0 of the pair after next")
+                A("      if (hasC) {")
+                L.extend(ring_issue("        ", 0, "C", "s_"))
+                A("      }")
+                A(f"      {STG}spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)eiA * a.gy_stride + chunk * kS, lane);")
+                A(f"      {STG}spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eoA * a.gy_stride + chunk * kS, lane);")
+            else:
+                A(f"      // refill this slot with chunk {c_ + 1} of the next pair")
+                A("      if (hasB) {")
+                L.extend(ring_issue("        ", c_ + 1, "B", "s_"))
+                A("      }")
+            A("    }")
+        A("    jnA = jnB; prA = prB; eiA = eiB; eoA = eoB; jnB = jnC; prB = prC; eiB = eiC; eoB = eoC;")
+        A("    hasA = hasB; hasB = hasC; idx += WPN; ++kk; first = false;")
+        A(f"    rot += {RC}; rot = rot >= kRingSlots ? rot - kRingSlots : rot;")
+        A("  }")
+        A("  if (!GX) return;")
+        A("  // grad_x[owner]: the owner-side contributions of all its pairs (the other side arrives through the rows)")
+        A("  if (WPN > 1) {")
+        A("    T* red = reinterpret_cast<T*>(nqa_smem);  // (the rings are idle: every copy was waited for)")
+        A("    __syncthreads();")
+        A("    if (wsub > 0) {")
+        A("#pragma unroll")
+        A("      for (int k = 0; k < kXD; ++k) red[(((wid / WPN) * (WPN - 1) + wsub - 1) * kXD + k) * 64 + lane] = gxO[k];")
+        A("    }")
+        A("    __syncthreads();")
+        A("    if (wsub > 0) return;")
+        A("#pragma unroll")
+        A("    for (int k = 0; k < kXD; ++k) {")
+        A("#pragma unroll")
+        A("      for (int w2 = 0; w2 < WPN - 1; ++w2) gxO[k] += red[(((wid / WPN) * (WPN - 1) + w2) * kXD + k) * 64 + lane];")
+        A("    }")
+        A("  }")
+        A("  if (valid) {")
+        A("    T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+        for b in range(NB):
+            d = 2 * st.in1_ls[b] + 1
+            for i in range(d):
+                A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = gxO[{xpre[b] + i}];")
+        A("  }")
+        A("}")
+        A("// a.out[n] += the accumulator row of n (ATOM), re-ordered from component rows to the irreps layout")
+        A("__global__ __launch_bounds__(256) void gx_acc_finish_kernel(const SpecArgs<float> a) {")
+        A("  const int mul = a.mul;")
+        A("  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (node, channel)")
+        A("  if (t >= (int64_t)a.N * mul) return;")
+        A("  const int64_t node = t / mul;")
+        A("  const int u = (int)(t - node * mul);")
+        A("  const float* __restrict__ acc = a.gxe + node * a.din + u;")
+        A("  float* __restrict__ ob = a.out + node * a.din;")
+        for b in range(NB):
+            d = 2 * st.in1_ls[b] + 1
+            if b in first_path_of_block_r:
+                for i in range(d):
+                    A(f"  ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] += acc[(int64_t)mul * {xpre[b] + i}];")
         A("}")
 
     # ------------------------------------------------------------------ pair-centric backward, split by input block
@@ -1564,6 +1969,27 @@ def _emit(st: Structure) -> str:
     A("  if (which == 4) {  // pair-centric backward (owner CSR in rowptr / nbr / wid / eid / eid2)")
     if pair_ok:
         A("    if (a.gw == nullptr || a.gy == nullptr || a.eid2 == nullptr || (a.out != nullptr && a.gxe == nullptr)) return 1;")
+        if ring_ok:
+            A("    // LDS-ring kernel (round 6): multiples of 64 channels; one wavefront per (node, chunk) when that fills the chip")
+            A("    // (read at every launch: the tests switch kernels within one process)")
+            A("    const bool ring_ = [] { const char* v = std::getenv(\"NQA_PAIR_RING\"); return v == nullptr || v[0] != '0'; }();")
+            A("    if (ring_ && (a.mul & 63) == 0) {")
+            A("      const int rw = items >= 6144 ? 1 : (items >= 3072 ? 2 : 4);")
+            A("      const size_t rsmem = (size_t)4 * kRingWaveBytes;")
+            A("      const dim3 rgrid((unsigned)((items * rw + 3) / 4)), rblk(256);")
+            A("#define NQA_RING_LAUNCH(W, GX_, AT_) do { \\")
+            A("        static const bool once_ = [] { return hipFuncSetAttribute((const void*)bwd_pair_ring_kernel<W, GX_, AT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kRingWaveBytes) == hipSuccess; }(); \\")
+            A("        if (!once_) return 1; \\")
+            A("        hipLaunchKernelGGL((bwd_pair_ring_kernel<W, GX_, AT_>), rgrid, rblk, rsmem, stream, a); } while (0)")
+            A("#define NQA_RING_WPN(GX_, AT_) do { if (rw == 1) NQA_RING_LAUNCH(1, GX_, AT_); else if (rw == 2) NQA_RING_LAUNCH(2, GX_, AT_); else NQA_RING_LAUNCH(4, GX_, AT_); } while (0)")
+            A("      if (a.out == nullptr) NQA_RING_WPN(false, false);")
+            A("      else if (a.gx_atomic) NQA_RING_WPN(true, true);")
+            A("      else NQA_RING_WPN(true, false);")
+            A("#undef NQA_RING_WPN")
+            A("#undef NQA_RING_LAUNCH")
+            A("      return 0;")
+            A("    }")
+        A("    if (a.gx_atomic) return 1;  // (the caller asked for the accumulator form, which only the ring kernel has)")
         A("    const int64_t blocks = (items * WPN + 3) / 4;")
         A("    const size_t smem = WPN > 1 ? (size_t)(WPN - 1) * kXD * 64 * sizeof(float) : 0;")
         A("    const dim3 grid((unsigned)blocks), blk(256);")
@@ -1613,6 +2039,14 @@ def _emit(st: Structure) -> str:
     else:
         A("    return 1;")
     A("  }")
+    A("  if (which == 9) {  // grad_x += the accumulator rows of the atomic form of the ring kernel")
+    if ring_ok:
+        A("    const int64_t threads = (int64_t)a.N * a.mul;")
+        A("    hipLaunchKernelGGL(gx_acc_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);")
+        A("    return 0;")
+    else:
+        A("    return 1;")
+    A("  }")
     A("  if (which == 5) {  // grad_x += rows of the pairs in which the node is not the owner")
     A("    hipLaunchKernelGGL((gx_rows_sum_kernel<float, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, a);")
     A("    return 0;")
@@ -1632,7 +2066,7 @@ def _emit(st: Structure) -> str:
     A("  if (wpn >= 4 && kOD <= 64) return launch<4>(which, a, stream);")
     A("  return launch<1>(which, a, stream);")
     A("}")
-    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {pair_parts});')
+    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {pair_parts}, {1 if ring_ok else 0});')
     A("#endif  // NQA_LAB")
     A("}  // namespace")
     A("}  // namespace nqa")

@@ -798,6 +798,18 @@ int64_t nqa_tp_bwd_pairs_workspace_bytes(const nqa_plan* plan, int32_t dtype, in
   return ((ypart + 255) & ~(int64_t)255) + (num_edges / 2) * (int64_t)plan->dim_in1 * 4;
 }
 
+// The ring kernel's atomic grad_x form (round 6): one zeroed [N, dim_in1] accumulator instead of a row per pair.  On by
+// default where the structure has the ring kernel; NQA_PAIR_GX_ATOMIC=0 keeps the rows (sums in a fixed order: results
+// reproducible to the bit), NQA_PAIR_RING=0 the register kernel.
+static bool pair_gx_atomic(const nqa_plan* plan, int64_t num_nodes, int64_t num_edges) {
+  const char* ea = std::getenv("NQA_PAIR_GX_ATOMIC");  // (read at every call: the tests switch forms within one process)
+  const char* er = std::getenv("NQA_PAIR_RING");
+  const bool on = (ea == nullptr || ea[0] != '0') && (er == nullptr || er[0] != '0');
+  // (the accumulator lives in the rows' workspace: [P, dim_in1] holds [N, dim_in1] whenever there are at least as many pairs
+  // as nodes -- every list this is worth running on)
+  return on && plan->spec->ring && (plan->uniform_mul & 63) == 0 && num_edges / 2 >= num_nodes;
+}
+
 int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
                              const void* w, const void* grad_out, const int32_t* owner_rowptr,
                              const int32_t* pair_other, const int32_t* pair_row, const int32_t* pair_edge_in,
@@ -841,6 +853,14 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
   a.eid = pair_edge_in;
   a.eid2 = pair_edge_out;
   a.wP = 2147483647;
+  const bool atomic = grad_x != nullptr && pair_gx_atomic(plan, num_nodes, num_edges);
+  if (atomic) {
+    a.gx_atomic = 1;
+    if (hipMemsetAsync(gxe, 0, (size_t)num_nodes * plan->dim_in1 * 4, s) != hipSuccess) {
+      set_error("nqa_tp_scatter_bwd_pairs: hipMemsetAsync of the grad_x accumulator failed");
+      return NQA_ERR_LAUNCH;
+    }
+  }
   if (nchunk == 1) {
     a.gy = static_cast<float*>(grad_y);
     a.gy_stride = plan->dim_in2;
@@ -866,6 +886,13 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
   spec_fill(b, plan, num_nodes);
   b.gxe = gxe;
   b.out = static_cast<float*>(grad_x);
+  if (atomic) {
+    if (plan->spec->launch(9, 1, b, s) != 0) {
+      set_error("nqa_tp_scatter_bwd_pairs: this structure has no accumulator kernel");
+      return NQA_ERR_UNSUPPORTED;
+    }
+    return check_launch("nqa_tp_scatter_bwd_pairs(accumulator)");
+  }
   b.rowptr = other_rowptr;
   b.eid = other_slot;
   if (plan->spec->launch(5, 1, b, s) != 0) {

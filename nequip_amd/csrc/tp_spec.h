@@ -34,10 +34,12 @@ struct SpecArgs {
   int32_t mul;
   int32_t din, dout, wn;
   int32_t gy_stride;
+  int32_t gx_atomic;  // which = 4: the other node's grad_x goes into the zeroed accumulator gxe [N, din] by atomics (ring kernel)
 };
 
 // which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows,
-// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows, 6 = dual pair-centric edge gradients, 7 = forward JVP, 8 = dual bwd_x;  wpn: requested wavefronts per (node, chunk)
+// 4 = pair-centric backward (owner CSR), 5 = out += per-node sum of the pair rows, 6 = dual pair-centric edge gradients, 7 = forward JVP, 8 = dual bwd_x,
+// 9 = out += accumulator rows (a.gx_atomic form of 4);  wpn: requested wavefronts per (node, chunk)
 using SpecLaunchFn = int (*)(int which, int wpn, const SpecArgs<float>& a, hipStream_t stream);
 
 struct SpecEntry {
@@ -46,6 +48,7 @@ struct SpecEntry {
   int xd, s, od, np;
   int pair;  // pair-centric backward (which = 4 / 5): 0 not generated, 1 one wavefront per (node, chunk), n > 1 split
              // over n wavefronts by input block (grad_y partials: nchunk * n per edge)
+  int ring;  // the LDS-ring pair kernel (and its atomic grad_x form, which = 9) exists for multiples of 64 channels
   SpecEntry* next;
 };
 
@@ -54,7 +57,7 @@ const SpecEntry* find_spec(const std::string& key);
 
 struct SpecRegistrar {
   SpecEntry entry;
-  SpecRegistrar(const char* key, SpecLaunchFn fn, int xd, int s, int od, int np, int pair) {
+  SpecRegistrar(const char* key, SpecLaunchFn fn, int xd, int s, int od, int np, int pair, int ring = 0) {
     entry.key = key;
     entry.launch = fn;
     entry.xd = xd;
@@ -62,6 +65,7 @@ struct SpecRegistrar {
     entry.od = od;
     entry.np = np;
     entry.pair = pair;
+    entry.ring = ring;
     entry.next = spec_registry_head();
     spec_registry_head() = &entry;
   }
@@ -100,6 +104,49 @@ template <typename T>
 __device__ __forceinline__ int spec_wrow(const SpecArgs<T>& a, int slot) {
   return spec_wrow_of(a, spec_gwrow(a, slot));
 }
+
+// ---- LDS-DMA (global -> LDS without registers) ------------------------------------------------------------------
+// One instruction moves 64 lanes x 16 (or 4) bytes: lane l's bytes come from `base + lane_off` (wave-uniform 64-bit base in
+// scalar registers, per-lane 32-bit byte offset) and land at LDS byte address `lds + 16 l` (`lds + 4 l`), `lds` wave-uniform
+// (M0).  Checked on the device by scripts/micro/glds_test.hip: M0 addresses beyond 64 KiB work, lanes outside EXEC write
+// nothing, an instruction offset would advance the global AND the LDS address (not used here), and the issuing wavefront's
+// `s_waitcnt vmcnt(N)` -- counted in order together with its stores -- is what orders its own ds_read behind the copy.
+// hipcc does not know these instructions exist: no wait is inserted for them (the point: a counted vmcnt(N) instead of the
+// vmcnt(0) the builtin draws before the next LDS read), so EVERY read of the copied bytes must follow a spec_wait_vm.
+// NL < 64: only lanes 0..NL-1 copy (EXEC is narrowed inside the statement and restored; the callers run with all lanes on).
+// NT: non-temporal (streamed rows that nobody reads again should not displace the gathered node rows in the L2)
+template <int NL, bool NT = false>
+__device__ __forceinline__ void spec_glds16(unsigned lds, const void* base, unsigned lane_off) {
+  if constexpr (NL >= 64) {
+    if constexpr (NT)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+    else
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(lane_off), "s"(base) : "memory");
+  } else {
+    unsigned long long keep;
+    if constexpr (NT)
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 m0, %1\n\ts_bfm_b64 exec, %4, 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b64 exec, %0"
+                   : "=&s"(keep) : "s"(lds), "v"(lane_off), "s"(base), "n"(NL) : "memory");
+    else
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 m0, %1\n\ts_bfm_b64 exec, %4, 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                   : "=&s"(keep) : "s"(lds), "v"(lane_off), "s"(base), "n"(NL) : "memory");
+  }
+}
+template <int NL>
+__device__ __forceinline__ void spec_glds4(unsigned lds, const void* base, unsigned lane_off) {
+  static_assert(NL < 64, "partial rows only");
+  unsigned long long keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 m0, %1\n\ts_bfm_b64 exec, %4, 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b64 exec, %0"
+               : "=&s"(keep) : "s"(lds), "v"(lane_off), "s"(base), "n"(NL) : "memory");
+}
+// all but the N most recently issued vector-memory operations of this wavefront (copies AND stores, in order) have completed
+template <int N>
+__device__ __forceinline__ void spec_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// every LDS read (and scalar load) of this wavefront has returned: a slot may be refilled
+__device__ __forceinline__ void spec_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---- wave64 reductions -------------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wavefront with DPP row operations (no LDS traffic):

@@ -3,6 +3,9 @@
 //
 //   pair_lab <topology dump (scripts/micro/dump_topo.py)> [reps] [mul] [relabel: 0 none | 1 morton | 2 random] [wpn] [mode] [morton cell] [extra LDS KiB]
 //
+// further positional arguments: [pair rows: 0 as built | 1 numbered in owner-slot order (w / grad_w walked sequentially)]
+//   [grad_x of the other node: 0 one row per pair + row sum | 1 atomic adds into a zeroed [N, dim_in1] accumulator (needs a
+//   generator variant with NQA_GEN_PAIR_GX_ATOMIC=1, or the ring kernel) + the row sum over ONE row per node]
 // mode 0: pair kernel + row sum (what nqa_tp_scatter_bwd_pairs launches); 1: pair kernel only; 2: row sum only
 // Prints the average duration of each kernel (HIP events, one kernel per event pair) and checksums of the results, so that
 // variants built from differently generated files can be compared for speed AND for equality of what they compute.
@@ -86,6 +89,38 @@ int main(int argc, char** argv) {
   if (fread(pos.data(), 8, pos.size(), f) != pos.size() || fread(cell.data(), 8, 9, f) != 9) { fprintf(stderr, "short read (pos)\n"); return 1; }
   fclose(f);
 
+  const int prid = argc > 9 ? atoi(argv[9]) : 0;
+  const int gxat = argc > 10 ? atoi(argv[10]) : 0;
+  {
+    double d = 0;
+    for (int s = 0; s < P; ++s) d += std::abs((double)prow[s] - s);
+    fprintf(stderr, "mean |pair_row - owner slot| = %.0f rows of %d\n", d / P, P);
+  }
+  const int own_rule = argc > 11 ? atoi(argv[11]) : 0;  // 0 as built (balanced parity rule) | 1 the smaller index owns | 2 the larger
+  if (own_rule) {
+    struct Rec { int o, j, row, ein, eout; };
+    std::vector<Rec> recs(P);
+    for (int n = 0; n < N; ++n)
+      for (int s = orow[n]; s < orow[n + 1]; ++s) {
+        Rec r{n, oth[s], prow[s], ein[s], eout[s]};
+        const bool swap = own_rule == 1 ? r.j < r.o : r.j > r.o;
+        if (swap) r = Rec{r.j, r.o, r.row, r.eout, r.ein};
+        recs[s] = r;
+      }
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.o != b.o ? a.o < b.o : a.j < b.j; });
+    std::fill(orow.begin(), orow.end(), 0);
+    for (int s = 0; s < P; ++s) { orow[recs[s].o + 1]++; oth[s] = recs[s].j; prow[s] = recs[s].row; ein[s] = recs[s].ein; eout[s] = recs[s].eout; }
+    for (int n = 0; n < N; ++n) orow[n + 1] += orow[n];
+    std::fill(trow.begin(), trow.end(), 0);
+    for (int s = 0; s < P; ++s) trow[oth[s] + 1]++;
+    for (int n = 0; n < N; ++n) trow[n + 1] += trow[n];
+    std::vector<int> fillp(trow.begin(), trow.end() - 1);
+    for (int s = 0; s < P; ++s) tslot[fillp[oth[s]]++] = s;
+    int mx = 0; for (int n = 0; n < N; ++n) mx = std::max(mx, orow[n + 1] - orow[n]);
+    fprintf(stderr, "ownership rule %d: most pairs of one owner %d (mean %.1f)\n", own_rule, mx, (double)P / N);
+  }
+  if (prid)
+    for (int s = 0; s < P; ++s) prow[s] = s;
   if (relabel) {  // renumber the nodes (what the lists would be had the atoms arrived in that order)
     std::vector<int> order(N);  // order[new] = old
     std::iota(order.begin(), order.end(), 0);
@@ -142,12 +177,17 @@ int main(int argc, char** argv) {
   float *gw, *gy, *gxe, *out;
   CK(hipMalloc(&gw, (size_t)P * wn * 4));
   CK(hipMalloc(&gy, (size_t)E * kS * gyn * 4));
-  CK(hipMalloc(&gxe, (size_t)P * din * 4));
+  const size_t gxe_n = gxat == 2 ? (size_t)8 * N * din : (size_t)P * din;  // gxat 2: one accumulator per XCD
+  CK(hipMalloc(&gxe, gxe_n * 4));
   CK(hipMalloc(&out, (size_t)N * din * 4));
   CK(hipMemset(gw, 0, (size_t)P * wn * 4));
   CK(hipMemset(gy, 0, (size_t)E * kS * gyn * 4));
-  CK(hipMemset(gxe, 0, (size_t)P * din * 4));
+  CK(hipMemset(gxe, 0, gxe_n * 4));
   CK(hipMemset(out, 0, (size_t)N * din * 4));
+  if (gxat) {  // one accumulator row per node: the "row sum" walks exactly that row
+    trow.resize(N + 1); tslot.resize(N);
+    std::iota(trow.begin(), trow.end(), 0); std::iota(tslot.begin(), tslot.end(), 0);
+  }
   int *d_orow = to_dev(orow), *d_oth = to_dev(oth), *d_prow = to_dev(prow), *d_ein = to_dev(ein), *d_eout = to_dev(eout),
       *d_trow = to_dev(trow), *d_tslot = to_dev(tslot);
 
@@ -165,6 +205,16 @@ int main(int argc, char** argv) {
     const int64_t witems = items * kPairParts;
     hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true>), dim3((unsigned)((witems + 3) / 4)), dim3(256), 0, 0, a);
 #else
+#ifdef LAB_RING
+    {
+      const unsigned blocks = (unsigned)((items * wpn + 3) / 4);
+      const size_t smem = (size_t)4 * kRingWaveBytes + extra_lds;
+#define LAB_RING_GO(W) do { if (gxat) hipLaunchKernelGGL((bwd_pair_ring_kernel<W, true, true>), dim3(blocks), dim3(256), smem, 0, a); \
+                         else hipLaunchKernelGGL((bwd_pair_ring_kernel<W, true, false>), dim3(blocks), dim3(256), smem, 0, a); } while (0)
+      if (wpn >= 4) LAB_RING_GO(4); else if (wpn == 2) LAB_RING_GO(2); else LAB_RING_GO(1);
+      return;
+    }
+#endif
 #ifdef LAB_PK
 #define LAB_PAIR_KERNEL bwd_pair_pk_kernel
 #else
@@ -180,11 +230,17 @@ int main(int argc, char** argv) {
   auto launch_sum = [&]() {
     hipLaunchKernelGGL((gx_rows_sum_kernel<float, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, 0, b);
   };
+#ifdef LAB_RING
+  const int ring_lds = 4 * kRingWaveBytes + (int)extra_lds;
+#define LAB_RING_ATTR(W, AT) CK(hipFuncSetAttribute((const void*)bwd_pair_ring_kernel<W, true, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds))
+  LAB_RING_ATTR(4, true); LAB_RING_ATTR(2, true); LAB_RING_ATTR(1, true); LAB_RING_ATTR(4, false); LAB_RING_ATTR(2, false); LAB_RING_ATTR(1, false);
+#endif
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   double tp = 0, ts = 0;
   for (int r = -3; r < reps; ++r) {
     CK(hipEventRecord(e0, 0));
+    if (gxat) CK(hipMemsetAsync(gxe, 0, (gxat == 2 ? (size_t)8 : (size_t)1) * N * din * 4, 0));
     if (mode != 2) launch_pair();
     CK(hipEventRecord(e1, 0));
     if (mode != 1) launch_sum();
@@ -197,7 +253,26 @@ int main(int argc, char** argv) {
     if (r >= 0) { tp += m1; ts += m2; }
   }
   // checksums after ONE clean evaluation (the row sum accumulates into `out`, which the pair kernel overwrites first)
+  if (gxat) CK(hipMemsetAsync(gxe, 0, (gxat == 2 ? (size_t)8 : (size_t)1) * N * din * 4, 0));
   launch_pair();
+  if (gxat == 2) {  // fold the eight per-XCD accumulators into the first (host; checksum only) and count the rows each one holds
+    CK(hipDeviceSynchronize());
+    std::vector<float> h((size_t)8 * N * din);
+    CK(hipMemcpy(h.data(), gxe, h.size() * 4, hipMemcpyDeviceToHost));
+    size_t touched = 0;
+    for (int x = 0; x < 8; ++x)
+      for (int n = 0; n < N; ++n) {
+        bool t = false;
+        for (int i = 0; i < din; ++i) {
+          const float v = h[((size_t)x * N + n) * din + i];
+          if (v != 0.f) t = true;
+          if (x) h[(size_t)n * din + i] += v;
+        }
+        touched += t;
+      }
+    fprintf(stderr, "per-XCD accumulators: %zu (XCD, node) rows hold something = %.2f per node\n", touched, (double)touched / N);
+    CK(hipMemcpy(gxe, h.data(), (size_t)N * din * 4, hipMemcpyHostToDevice));
+  }
   launch_sum();
   CK(hipDeviceSynchronize());
   const double c_gw = checksum(gw, (size_t)P * wn), c_out = checksum(out, (size_t)N * din);

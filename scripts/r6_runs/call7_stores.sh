@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 6, call 7: write bandwidth by store shape; the memory-only loop with the store streams pointed at one row
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r6_call7; rm -rf $OUT; mkdir -p $OUT
+python scripts/micro/dump_topo.py water /tmp/topo_water.bin > $OUT/dump.log 2>&1
+L=scripts/micro/lab
+{
+$L/store_bw.out 1024
+for v in mo_nopf mo_a1 mo_a2 mo_a3 mo_a11 mo_a15 mo_a31; do
+  printf "%-10s " $v; timeout 120 $L/$v.out /tmp/topo_water.bin 20 64 0 4 2>/dev/null
+done
+} > $OUT/lab_times.txt 2>&1
+cat $OUT/lab_times.txt

@@ -211,16 +211,32 @@ def test_spec_kernels_large_degree_and_wave_split(device, mul):
     _close(rgy, fy, "fused gy")
 
 
+# the three forms of the pair-centric backward for multiples of 64 channels (round 6; both switches are read at every call):
+# the LDS-ring kernel with the other node's grad_x in an atomically summed accumulator (default), the ring kernel with one
+# row per pair + the fixed-order row sum, and the register kernel of rounds 3-5
+PAIR_FORMS = {"ring_atomic": {}, "ring_rows": {"NQA_PAIR_GX_ATOMIC": "0"}, "registers": {"NQA_PAIR_RING": "0"}}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("system", ["si_small_cell", "water", "cu_l3"])
-def test_pair_backward_equals_per_edge_backward(device, system):
+@pytest.mark.parametrize("form", list(PAIR_FORMS))
+@pytest.mark.parametrize("system", ["si_small_cell", "water", "water_two_chunks", "water_wide", "cu_l3"])
+def test_pair_backward_equals_per_edge_backward(device, system, form, monkeypatch):
     """`nqa_tp_scatter_bwd_pairs` against `nqa_tp_scatter_bwd_fused_paired` on real neighbour lists: a cell thinner than
     2 r_max (several images of one (i, j), self images: owner == other), a water box large enough for one wavefront per
-    node and for four, and the l_max = 3 / 128-feature structure (two channel chunks, grad_y through the partial buffer)."""
+    node and for four, the same with 128 channels (two chunks per node, grad_y through the partial buffer) and with the
+    narrow first / last layer structures, and the l_max = 3 / 128-feature structure (split kernel)."""
     from nequip_amd.nn._topology import EdgeTopology
     from nequip_amd.utils import synthetic as syn
 
-    if system == "si_small_cell":
+    for k_, v_ in PAIR_FORMS[form].items():
+        monkeypatch.setenv(k_, v_)
+    if system == "water_two_chunks":
+        pos, types, cell, names = syn.water_box(n_side=4, seed=1)
+        sname, mul = "l2n_mid", 128
+    elif system == "water_wide":
+        pos, types, cell, names = syn.water_box(n_side=13, seed=4)  # 6591 atoms: one wavefront per node in the ring kernel
+        sname, mul = "l2n_last", 64
+    elif system == "si_small_cell":
         pos, types, cell, names = syn.silicon_box(reps=1, seed=2)
         sname, mul = "l2n_mid", 64
     elif system == "water":
@@ -255,6 +271,40 @@ def test_pair_backward_equals_per_edge_backward(device, system):
     assert float((per_owner - per_node / 2).abs().max()) <= 0.25 * float(per_node.max()) + 2  # balanced halves
 
     g = torch.Generator().manual_seed(11)
+    d = lambda t: t.to(device)  # noqa: E731
+    x, y = d(torch.randn(N, k.dim_in1, generator=g)), d(torch.randn(E, k.dim_in2, generator=g))
+    w, go = d(torch.randn(P, k.weight_numel, generator=g) / 4), d(torch.randn(N, k.dim_out, generator=g))
+    fx, fw, fy = k.bwd_fused(x, y, w, go, topo, pairing=pr)
+    px, pw, py = k.bwd_pairs(x, y, w, go, topo, pr)
+    _close(fx.cpu(), px, "gx")
+    _close((fw[:P] + fw[P:]).cpu(), pw, "gw (summed over the pair)")
+    _close(fy.cpu(), py, "gy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["ring_atomic", "ring_rows"])
+def test_ring_kernel_more_than_64_pairs_per_wavefront(device, form, monkeypatch):
+    """One wavefront of the ring kernel keeps the indices of 64 of its pairs in registers and fetches the next block when it
+    runs out: a random pairable graph with ~170 neighbours per node (85 owned pairs) on enough nodes for the one-wavefront-
+    per-node launch shape, against the per-edge fused backward."""
+    from nequip_amd.nn._topology import EdgeTopology
+
+    for k_, v_ in PAIR_FORMS[form].items():
+        monkeypatch.setenv(k_, v_)
+    name, f_in_1x, lmax, f_out_1x = next(s for s in STRUCTS if s[0] == "l2n_mid")
+    tps, f_in, e_at, mid_s, instructions = _module(f_in_1x, lmax, f_out_1x, 64, device)
+    k = tps._get_kernels()
+    N = 6400
+    dst, src = _big_graph(N, N * 86, seed=5)
+    dst, src = dst.to(device), src.to(device)
+    E = dst.numel()
+    topo = EdgeTopology(dst, src, N)
+    pr = topo.pairing(None)
+    assert pr is not None
+    orow = pr.owner_csr[0].cpu().long()
+    assert int((orow[1:] - orow[:-1]).max()) > 64, "the graph must exercise the second index block"
+    P = pr.num_pairs
+    g = torch.Generator().manual_seed(12)
     d = lambda t: t.to(device)  # noqa: E731
     x, y = d(torch.randn(N, k.dim_in1, generator=g)), d(torch.randn(E, k.dim_in2, generator=g))
     w, go = d(torch.randn(P, k.weight_numel, generator=g) / 4), d(torch.randn(N, k.dim_out, generator=g))
