@@ -1301,6 +1301,14 @@ def _emit(st: Structure) -> str:
     # its own shorter history, the last one waits for everything.  scripts/check_ring_waits.py re-counts N in the ISA.
     ring_ok = pair_ok and os.environ.get("NQA_GEN_PAIR_RING", "1") != "0"
     if ring_ok:
+        # register budget at two wavefronts per SIMD: the owner's grad_out row and the products of it the compiler hoists out
+        # of the pair loop, both y rows and both grad_y accumulators, the owner's x row / its gradient / one block's row
+        # gradient (l2n_mid: 177 -> 247 registers; l3n_mid_k2: 192 -> 27 spilled, whose scratch loads draw hipcc's own
+        # vmcnt waits into the loop -- scripts/check_ring_waits.py).  Structures beyond it keep bwd_pair_kernel.
+        n_hoist = sum(int((np.abs(np.array(wigner_3j(st.in1_ls[b_], st.in2_ls[j_], st.out_ls[s_]))).sum(axis=2) > 0).sum())
+                      for (b_, j_, s_) in st.instr)
+        ring_ok = OD + n_hoist + 4 * S + 3 * XD <= 180
+    if ring_ok:
         import itertools
         RING_WAVE = int(os.environ.get("NQA_GEN_RING_WAVE_BYTES", "20480"))
         U = 16  # bytes per lane of a copy
