@@ -1671,21 +1671,6 @@ def _emit(st: Structure) -> str:
                 A(f"    ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = gxO[{xpre[b] + i}];")
         A("  }")
         A("}")
-        A("// a.out[n] += the accumulator row of n (ATOM), re-ordered from component rows to the irreps layout")
-        A("__global__ __launch_bounds__(256) void gx_acc_finish_kernel(const SpecArgs<float> a) {")
-        A("  const int mul = a.mul;")
-        A("  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (node, channel)")
-        A("  if (t >= (int64_t)a.N * mul) return;")
-        A("  const int64_t node = t / mul;")
-        A("  const int u = (int)(t - node * mul);")
-        A("  const float* __restrict__ acc = a.gxe + node * a.din + u;")
-        A("  float* __restrict__ ob = a.out + node * a.din;")
-        for b in range(NB):
-            d = 2 * st.in1_ls[b] + 1
-            if b in first_path_of_block_r:
-                for i in range(d):
-                    A(f"  ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] += acc[(int64_t)mul * {xpre[b] + i}];")
-        A("}")
 
     # ------------------------------------------------------------------ pair-centric backward, split by input block
     # Structures whose two grad_out rows do not fit one wavefront's registers (l_max = 3: 99 values each): every input
@@ -1721,7 +1706,9 @@ def _emit(st: Structure) -> str:
     if pair_parts > 1:
         PS = pair_parts
         A(f"constexpr int kPairParts = {PS};")
-        A("template <typename T, bool FULL, bool GX>")
+        A("// ATOM (multiples of 64 channels): the other node's grad_x by atomics into the zeroed [N, dim_in1] accumulator a.gxe")
+        A("// (see bwd_pair_ring_kernel) instead of one row per pair")
+        A("template <typename T, bool FULL, bool GX, bool ATOM = false>")
         A("__global__ __launch_bounds__(256, 2) void bwd_pair_split_kernel(const SpecArgs<T> a) {")
         A("  const int lane = threadIdx.x & 63;")
         A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
@@ -1829,7 +1816,7 @@ def _emit(st: Structure) -> str:
             A("#pragma unroll")
             A("        for (int j = 0; j < kS; ++j) { qI[j] = T(0); qX[j] = T(0); }")
             A("        T* __restrict__ gwr_e = a.gw + (int64_t)pr * a.wn;")
-            A("        T* __restrict__ gxr = a.gxe + (int64_t)idx * a.din;")
+            A("        T* __restrict__ gxr = a.gxe + (int64_t)(ATOM ? j_ : idx) * a.din;")
             last_of = {st.instr[p_][0]: p_ for p_ in paths}
             first_of = {}
             for p_ in paths:
@@ -1862,10 +1849,11 @@ def _emit(st: Structure) -> str:
                 if last_of[b_] == pth:
                     A("        if (GX && act) {")
                     for i in range(d1):
-                        A(f"          {emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')};")
+                        st_ = emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')
+                        A(f"          if (ATOM) unsafeAtomicAdd(spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb), gxa[{xpre[b_] + i}]); else {st_};")
                     A("        }")
             if part_i == 0 and unused_comps:
-                A("        if (GX && act) {")
+                A("        if (GX && act && !ATOM) {")
                 for i in unused_comps:
                     A(f"          *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
                 A("        }")
@@ -1891,6 +1879,23 @@ def _emit(st: Structure) -> str:
             A("    } break;")
         A("    default: break;")
         A("  }")
+        A("}")
+
+    # ------------------------------------------------------------------ accumulator form of grad_x (ATOM), last step
+    if pair_ok or pair_parts > 1:
+        A("// a.out[n] += the accumulator row of n (ATOM forms of the pair kernels), re-ordered from component rows to the irreps layout")
+        A("__global__ __launch_bounds__(256) void gx_acc_finish_kernel(const SpecArgs<float> a) {")
+        A("  const int mul = a.mul;")
+        A("  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (node, channel)")
+        A("  if (t >= (int64_t)a.N * mul) return;")
+        A("  const int64_t node = t / mul;")
+        A("  const int u = (int)(t - node * mul);")
+        A("  const float* __restrict__ acc = a.gxe + node * a.din + u;")
+        A("  float* __restrict__ ob = a.out + node * a.din;")
+        for b in used_blocks:
+            d = 2 * st.in1_ls[b] + 1
+            for i in range(d):
+                A(f"  ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] += acc[(int64_t)mul * {xpre[b] + i}];")
         A("}")
 
     # ------------------------------------------------------------------ per-source-node sum of the fused rows
@@ -2014,7 +2019,9 @@ def _emit(st: Structure) -> str:
         A("    const int64_t witems = items * kPairParts;  // one wavefront per (node, chunk, part)")
         A("    const dim3 grid((unsigned)((witems + 3) / 4)), blk(256);")
         A("    if (a.out != nullptr) {")
-        A("      if (full) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true>), grid, blk, 0, stream, a);")
+        A("      if (a.gx_atomic && (a.mul & 63) != 0) return 1;")
+        A("      if (a.gx_atomic) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true, true>), grid, blk, 0, stream, a);")
+        A("      else if (full) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true>), grid, blk, 0, stream, a);")
         A("      else hipLaunchKernelGGL((bwd_pair_split_kernel<float, false, true>), grid, blk, 0, stream, a);")
         A("    } else {")
         A("      if (full) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, false>), grid, blk, 0, stream, a);")
@@ -2047,8 +2054,8 @@ def _emit(st: Structure) -> str:
     else:
         A("    return 1;")
     A("  }")
-    A("  if (which == 9) {  // grad_x += the accumulator rows of the atomic form of the ring kernel")
-    if ring_ok:
+    A("  if (which == 9) {  // grad_x += the accumulator rows of the atomic form of the pair kernels")
+    if pair_ok or pair_parts > 1:
         A("    const int64_t threads = (int64_t)a.N * a.mul;")
         A("    hipLaunchKernelGGL(gx_acc_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);")
         A("    return 0;")
@@ -2074,7 +2081,7 @@ def _emit(st: Structure) -> str:
     A("  if (wpn >= 4 && kOD <= 64) return launch<4>(which, a, stream);")
     A("  return launch<1>(which, a, stream);")
     A("}")
-    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {pair_parts}, {1 if ring_ok else 0});')
+    A(f'static SpecRegistrar reg_{tag}("{st.key()}", &launch_any, kXD, kS, kOD, kNP, {pair_parts}, {2 if pair_parts > 1 else (1 if ring_ok else 0)});')
     A("#endif  // NQA_LAB")
     A("}  // namespace")
     A("}  // namespace nqa")

@@ -804,7 +804,8 @@ int64_t nqa_tp_bwd_pairs_workspace_bytes(const nqa_plan* plan, int32_t dtype, in
 static bool pair_gx_atomic(const nqa_plan* plan, int64_t num_nodes, int64_t num_edges) {
   const char* ea = std::getenv("NQA_PAIR_GX_ATOMIC");  // (read at every call: the tests switch forms within one process)
   const char* er = std::getenv("NQA_PAIR_RING");
-  const bool on = (ea == nullptr || ea[0] != '0') && (er == nullptr || er[0] != '0');
+  // (the split kernel of the l_max = 3 structures has the accumulator form itself: spec->ring == 2)
+  const bool on = (ea == nullptr || ea[0] != '0') && (plan->spec->ring == 2 || er == nullptr || er[0] != '0');
   // (the accumulator lives in the rows' workspace: [P, dim_in1] holds [N, dim_in1] whenever there are at least as many pairs
   // as nodes -- every list this is worth running on)
   return on && plan->spec->ring && (plan->uniform_mul & 63) == 0 && num_edges / 2 >= num_nodes;

@@ -48,7 +48,8 @@ struct SpecEntry {
   int xd, s, od, np;
   int pair;  // pair-centric backward (which = 4 / 5): 0 not generated, 1 one wavefront per (node, chunk), n > 1 split
              // over n wavefronts by input block (grad_y partials: nchunk * n per edge)
-  int ring;  // the LDS-ring pair kernel (and its atomic grad_x form, which = 9) exists for multiples of 64 channels
+  int ring;  // the accumulator (atomic) form of the pair kernel's grad_x and its last step (which = 9) exist for multiples of
+             // 64 channels: 1 = in the LDS-ring kernel, 2 = in the split kernel; 0 = rows only
   SpecEntry* next;
 };
 

@@ -38,18 +38,22 @@ def plain(*subs):
 
 # bench.py region name -> (predicates identifying the main kernel family, predicates of helper kernels that run once
 # per launch).  Template layouts (generated_spec/*.hip): bwd_edge_kernel<T, WPN, FUSED, GW, GY, FULL>,
-# bwd_pair_kernel<T, WPN, FULL, GX, DUAL>, bwd_pair_split_kernel<T, FULL, GX>.
+# bwd_pair_kernel<T, WPN, FULL, GX, DUAL>, bwd_pair_split_kernel<T, FULL, GX, ATOM>, bwd_pair_ring_kernel<WPN, GX, ATOM>.
 REGIONS = {
     "tp_fwd": ([plain("::fwd_kernel<", "tp_fwd_kernel")], []),
     "tp_bwd_edge": ([lambda k: arg_is(k, "bwd_edge_kernel", 2, "false"), plain("tp_bwd_edge_kernel"),
                      lambda k: arg_is(k, "bwd_pair_kernel", 3, "false"),
-                     lambda k: arg_is(k, "bwd_pair_split_kernel", 2, "false")],
+                     lambda k: arg_is(k, "bwd_pair_split_kernel", 2, "false"),
+                     lambda k: arg_is(k, "bwd_pair_ring_kernel", 1, "false")],
                     [plain("spec_gy_reduce_kernel", "tp_ypart_reduce_kernel")]),
     "tp_bwd_x": ([plain("::bwd_x_kernel<", "tp_bwd_x_kernel")], []),
     "tp_bwd_fused": ([lambda k: arg_is(k, "bwd_edge_kernel", 2, "true"),
                       lambda k: arg_is(k, "bwd_pair_kernel", 3, "true"),
-                      lambda k: arg_is(k, "bwd_pair_split_kernel", 2, "true")],
-                     [plain("gx_rows_sum_kernel")]),
+                      lambda k: arg_is(k, "bwd_pair_split_kernel", 2, "true"),
+                      lambda k: arg_is(k, "bwd_pair_ring_kernel", 1, "true")],
+                     # (the accumulator form's hipMemsetAsync of [N, dim_in1] -- a runtime fill kernel, 23 MB written in cfg-3 --
+                     # has no name of its own and is not counted)
+                     [plain("gx_rows_sum_kernel", "gx_acc_finish_kernel")]),
     "radial_mlp_fwd": ([lambda k: re.search(r"radial_mlp_fwd\w*_kernel", k) is not None],
                        [plain("radial_mlp_split_w1_fwd_kernel", "radial_mlp_split_w1_fwd_f16_kernel")]),
     "radial_mlp_bwd": ([lambda k: re.search(r"radial_mlp_bwd\w*_kernel", k) is not None],
@@ -77,7 +81,7 @@ def factors_for(kernel: str, calib: dict):
     """(FETCH_SIZE factor, WRITE_SIZE factor) of a GPU kernel by its access pattern: the tensor-product kernels read and
     write 4 B per lane (lane = channel, one 256 B row segment per wave access, nontemporal result stores); the radial MLP,
     node and embedding kernels move 16 B per lane."""
-    tp = any(s in kernel for s in ("::fwd_kernel<", "bwd_edge_kernel", "bwd_pair", "bwd_x_kernel", "gx_rows_sum", "tp_fwd_kernel",
+    tp = any(s in kernel for s in ("::fwd_kernel<", "bwd_edge_kernel", "bwd_pair", "bwd_x_kernel", "gx_rows_sum", "gx_acc_finish", "tp_fwd_kernel",
                                     "tp_bwd", "spec_gy_reduce"))
     if tp:
         return (calib.get("fetch_4B_per_lane_rows") or 2.0, calib.get("write_4B_per_lane_rows_nontemporal") or 1.0)

@@ -107,6 +107,12 @@ def test_profile_summariser_classifies_every_generated_kernel():
         name = "void nqa::(anonymous namespace)::" + inst + "(nqa::SpecArgs<float>)"
         region, _ = sp.region_of(name)
         assert region in want[base], (inst, region)
+    # round 6: the LDS-ring pair kernel <WPN, GX, ATOM> (launched through a macro: not seen by the scan above) and its last step
+    assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_ring_kernel<1, true, true>(nqa::SpecArgs<float>)") == ("tp_bwd_fused", "main")
+    assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_ring_kernel<4, true, false>(nqa::SpecArgs<float>)") == ("tp_bwd_fused", "main")
+    assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_ring_kernel<2, false, false>(nqa::SpecArgs<float>)") == ("tp_bwd_edge", "main")
+    assert sp.region_of("nqa::(anonymous namespace)::gx_acc_finish_kernel(nqa::SpecArgs<float>)") == ("tp_bwd_fused", "helper")
+    assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_split_kernel<float, true, true, true>(x)")[0] == "tp_bwd_fused"
     # the round-2 regression: a fifth template argument must not change the classification
     assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_kernel<float, 4, true, true, false>(x)")[0] == "tp_bwd_fused"
     assert sp.region_of("void nqa::(anonymous namespace)::bwd_pair_kernel<float, 4, true, false, true, 7>(x)")[0] == "tp_bwd_edge"
