@@ -1881,6 +1881,327 @@ def _emit(st: Structure) -> str:
         A("  }")
         A("}")
 
+    # ------------------------------------------------------------------ split pair kernel on the LDS ring (round 6)
+    # The l_max = 3 structures' pair kernel (one wavefront per (node, chunk, input block)) walked its pairs with a plain loop:
+    # indices -> rows -> arithmetic -> stores, nothing of the next pair requested (the registers hold two grad_out slices).
+    # The same ring as bwd_pair_ring_kernel, per part: the part's slice of w / x[other] / grad_out[other] and the two y rows
+    # of the NEXT pair travel by LDS-DMA while this pair is evaluated out of the LDS.
+    split_ring_ok = pair_parts > 1 and os.environ.get("NQA_GEN_SPLIT_RING", "1") != "0"
+    if split_ring_ok:
+        import itertools as _it
+        SR_WAVE, SU = 20480, 16
+        sr_yrow_units = (S * 4 + SU - 1) // SU
+
+        def sr_plan(paths, blocks):
+            n_ = len(paths)
+            units = [16 + 16 * (2 * st.out_ls[st.instr[p_][2]] + 1) for p_ in paths]
+            xunits = {b_: 16 * (2 * st.in1_ls[b_] + 1) for b_ in blocks}
+            first_of = {}
+            for k_, p_ in enumerate(paths):
+                first_of.setdefault(st.instr[p_][0], k_)
+            for C in range(1, min(n_, 6) + 1):
+                best = None
+                for cuts in _it.combinations(range(1, n_), C - 1):
+                    bounds = [0] + list(cuts) + [n_]
+                    chunk_of = [0] * n_
+                    for c_ in range(C):
+                        for k_ in range(bounds[c_], bounds[c_ + 1]):
+                            chunk_of[k_] = c_
+                    base = [sum(units[bounds[c_]:bounds[c_ + 1]]) for c_ in range(C)]
+                    base[0] += 2 * sr_yrow_units
+                    for place in _it.product(*[range(chunk_of[first_of[b_]] + 1) for b_ in blocks]):
+                        tot = list(base)
+                        for b_, c_ in zip(blocks, place):
+                            tot[c_] += xunits[b_]
+                        key = (max(tot), sum(place))
+                        if best is None or key < best[0]:
+                            best = (key, bounds, dict(zip(blocks, place)))
+                slot_bytes = best[0][0] * SU
+                if SR_WAVE // slot_bytes >= C + 1:
+                    return C, slot_bytes, best[1], best[2]
+            return None
+
+        sr_plans = []
+        for paths in part_paths:
+            sr_plans.append(sr_plan(paths, sorted({st.instr[p_][0] for p_ in paths})))
+        if any(pl is None for pl in sr_plans):
+            split_ring_ok = False
+    if split_ring_ok:
+        sr_nt = set(os.environ.get("NQA_GEN_RING_NT", "w").replace("+", ",").split(","))
+
+        def sr_src_base(kind, ident):
+            if kind == "w":
+                return f"(unsigned)(mul * {ident} + chunk * 64) * 4u"
+            if kind == "x":
+                return f"(unsigned)(mul * {xpre[ident]} + chunk * {64 * (2 * st.in1_ls[ident] + 1)}) * 4u"
+            return f"(unsigned)(mul * {opre[ident]} + chunk * {64 * (2 * st.out_ls[ident] + 1)}) * 4u"
+
+        A("// (see bwd_pair_ring_kernel for the ring, the counted waits and ATOM; parts as in bwd_pair_split_kernel)")
+        A("template <bool GX, bool ATOM>")
+        A("__global__ __launch_bounds__(256, 2) void bwd_pair_split_ring_kernel(const SpecArgs<float> a) {")
+        A("  typedef float T;")
+        A("  extern __shared__ __align__(16) unsigned char nqa_smem[];")
+        A("  const int lane = threadIdx.x & 63;")
+        A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
+        A("  const int mul = a.mul;  // a multiple of 64")
+        A("  const int nchunk = mul >> 6;")
+        A("  const int64_t item = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+        A("  if (item >= (int64_t)a.N * nchunk * kPairParts) return;")
+        A("  const int node = spec_uniform((int)(item / (nchunk * kPairParts)));")
+        A("  const int rem = (int)(item - (int64_t)node * (nchunk * kPairParts));")
+        A("  const int chunk = spec_uniform(rem / kPairParts);")
+        A("  const int part = spec_uniform(rem - chunk * kPairParts);")
+        A("  const int u = chunk * 64 + lane;")
+        A("  constexpr bool act = true;")
+        A("  const int beg = a.rowptr[node], end = a.rowptr[node + 1];")
+        L.extend(lane_offsets("  ", want_x=True, want_g=True))
+        A(f"  const unsigned wbase = (unsigned)wid * {SR_WAVE}u;  // this wavefront's ring (LDS byte address)")
+        A("  const unsigned l4 = (unsigned)lane * 4u, l16 = (unsigned)lane * 16u;")
+        A("  switch (part) {")
+        for part_i, paths in enumerate(part_paths):
+            blocks = sorted({st.instr[p_][0] for p_ in paths})
+            slots = sorted({st.instr[p_][2] for p_ in paths})
+            ys = sorted({st.instr[p_][1] for p_ in paths})
+            RC, RSLOT, rb, xplace = sr_plans[part_i]
+            RN = RC + 1
+            cpaths = [[paths[k_] for k_ in range(rb[c_], rb[c_ + 1])] for c_ in range(RC)]
+            first_pb, last_pb = {}, {}
+            for p_ in paths:
+                first_pb.setdefault(st.instr[p_][0], p_)
+                last_pb[st.instr[p_][0]] = p_
+            lds_off, dma = [], []
+            for c_ in range(RC):
+                streams = {"w": [(p_, 16) for p_ in cpaths[c_]],
+                           "x": [(b_, 16 * (2 * st.in1_ls[b_] + 1)) for b_ in blocks if xplace[b_] == c_],
+                           "g": [(st.instr[p_][2], 16 * (2 * st.out_ls[st.instr[p_][2]] + 1)) for p_ in cpaths[c_]]}
+                offs, ins, pos = {}, [], 0
+                for kind in ("w", "x", "g"):
+                    segs, start = [], 0
+                    for ident, units in streams[kind]:
+                        offs[(kind, ident)] = (pos + start) * SU
+                        segs.append((ident, start, units))
+                        start += units
+                    for i0 in range(0, start, 64):
+                        nl = min(64, start - i0)
+                        pieces = []
+                        for ident, sstart, units in segs:
+                            lo, hi = max(sstart, i0), min(sstart + units, i0 + nl)
+                            if lo < hi:
+                                pieces.append((lo - i0, hi - i0, ident, lo - sstart))
+                        ins.append((kind, (pos + i0) * SU, nl, pieces))
+                    pos += start
+                if c_ == 0:
+                    offs[("y", "I")] = pos * SU
+                    ins.append(("yI", pos * SU, S, None))
+                    pos += sr_yrow_units
+                    offs[("y", "X")] = pos * SU
+                    ins.append(("yX", pos * SU, S, None))
+                    pos += sr_yrow_units
+                assert pos * SU <= RSLOT
+                lds_off.append(offs)
+                dma.append(ins)
+            D_pair = sum(len(i_) for i_ in dma)
+            Sgw = [len(cpaths[c_]) for c_ in range(RC)]
+            Sgx = [sum(2 * st.in1_ls[b_] + 1 for b_ in blocks if last_pb[b_] in cpaths[c_]) for c_ in range(RC)]
+            Sgx_atom = list(Sgx)
+            if part_i == 0:
+                Sgx[RC - 1] += len(unused_comps)
+            assert sum(Sgw) + sum(Sgx) + D_pair < 64, "vmcnt range"
+            pfx = f"p{part_i}"
+
+            def issue(ind, c_, sfx, slotexpr, lgkm=True):
+                out = [f"{ind}{{ const unsigned sb_ = wbase + (unsigned)({slotexpr}) * {RSLOT}u;"]
+                if lgkm:
+                    out.append(f"{ind}  spec_wait_lgkm();")
+                kinds = {k_ for k_, _, _, _ in dma[c_]}
+                if "w" in kinds:
+                    out.append(f"{ind}  const T* __restrict__ wr_ = a.w + (int64_t)pr{sfx} * a.wn;")
+                if "x" in kinds:
+                    out.append(f"{ind}  const T* __restrict__ xr_ = a.x + (int64_t)jn{sfx} * a.din;")
+                if "g" in kinds:
+                    out.append(f"{ind}  const T* __restrict__ gr_ = a.g + (int64_t)jn{sfx} * a.dout;")
+                for i_, (kind, loff, nl, pieces) in enumerate(dma[c_]):
+                    if kind == "yI":
+                        out.append(f"{ind}  spec_glds4<{nl}>(sb_ + {loff}u, a.y + (int64_t)ei{sfx} * kS, l4);")
+                    elif kind == "yX":
+                        out.append(f"{ind}  spec_glds4<{nl}>(sb_ + {loff}u, a.y + (int64_t)eo{sfx} * kS, l4);")
+                    else:
+                        nt_ = ", true" if kind in sr_nt else ""
+                        if len(pieces) == 1:
+                            lo_, _, ident_, su_ = pieces[0]
+                            uoff = f"{sr_src_base(kind, ident_)} + (unsigned)({(su_ - lo_) * SU})"
+                            out.append(f"{ind}  spec_glds16<{nl}{nt_}>(sb_ + {loff}u, reinterpret_cast<const char*>({kind}r_) + ({uoff}), l16);")
+                        else:
+                            out.append(f"{ind}  spec_glds16<{nl}{nt_}>(sb_ + {loff}u, {kind}r_, {pfx}ro{c_}_{i_});")
+                out.append(f"{ind}}}")
+                return out
+
+            def blk_load(ind, first_pair):
+                return [f"{ind}{{ const int i_ = beg + ({first_pair}) + lane; const int ic_ = i_ < end ? i_ : end - 1;",
+                        f"{ind}  jnV = a.nbr[ic_]; prV = a.wid[ic_]; eiV = a.eid[ic_]; eoV = a.eid2[ic_]; }}"]
+
+            def idx_get(sfx, k, ind):
+                return [f"{ind}jn{sfx} = __builtin_amdgcn_readlane(jnV, ({k}) & 63); pr{sfx} = __builtin_amdgcn_readlane(prV, ({k}) & 63);",
+                        f"{ind}ei{sfx} = __builtin_amdgcn_readlane(eiV, ({k}) & 63); eo{sfx} = __builtin_amdgcn_readlane(eoV, ({k}) & 63);"]
+
+            A(f"    case {part_i}: {{  // input blocks {blocks}: paths {paths}; ring of {RN} slots of {RSLOT} bytes, {RC} chunk(s) per pair, {D_pair} copies")
+            for c_ in range(RC):
+                for i_, (kind, loff, nl, pieces) in enumerate(dma[c_]):
+                    if pieces is None or len(pieces) == 1:
+                        continue
+                    expr = None
+                    for lo, hi, ident, su_ in reversed(pieces):
+                        e_ = f"{sr_src_base(kind, ident)} + (unsigned)({(su_ - lo) * SU})"
+                        expr = e_ if expr is None else f"(lane < {hi} ? {e_} : {expr})"
+                    A(f"      const unsigned {pfx}ro{c_}_{i_} = ({expr}) + l16;")
+            A("      T gvO[kOD], gvJ[kOD], gxO[kXD], qI[kS], qX[kS], gxa[kXD];")
+            for b in blocks:
+                A(f"      T xb{b}O[{2 * st.in1_ls[b] + 1}], xb{b}J[{2 * st.in1_ls[b] + 1}];")
+            for j in ys:
+                A(f"      T yb{j}I[{2 * st.in2_ls[j] + 1}], yb{j}X[{2 * st.in2_ls[j] + 1}];")
+            L.extend(sp_load_g("      ", "a.g + (int64_t)node * a.dout", "gvO", slots))
+            L.extend(sp_load_x("      ", "(a.x + (int64_t)node * a.din)", "O", blocks))
+            for b in blocks:
+                for i in range(2 * st.in1_ls[b] + 1):
+                    A(f"      gxO[{xpre[b] + i}] = T(0);")
+            A("      int idx = beg, kk = 0;")
+            A("      int jnA = 0, prA = 0, eiA = 0, eoA = 0, jnB = 0, prB = 0, eiB = 0, eoB = 0, jnC = 0, prC = 0, eiC = 0, eoC = 0;")
+            A("      int jnV = 0, prV = 0, eiV = 0, eoV = 0;")
+            A("      bool hasA = idx < end, hasB = idx + 1 < end, hasC = false;")
+            A("      if (hasA) {")
+            L.extend(blk_load("        ", "0"))
+            L.extend(idx_get("A", "0", "        "))
+            L.extend(idx_get("B", "1", "        "))
+            for c_ in range(RC):
+                L.extend(issue("        ", c_, "A", str(c_), lgkm=False))
+            A("      }")
+            A("      if (hasB) {")
+            L.extend(issue("        ", 0, "B", str(RC), lgkm=False))
+            A("      }")
+            A("      // (the owner's rows are in their registers before the loop starts: see bwd_pair_ring_kernel)")
+            for s_ in slots:
+                for k in range(2 * st.out_ls[s_] + 1):
+                    A(f"      asm volatile(\"\" : \"+v\"(gvO[{opre[s_] + k}]));")
+            for b in blocks:
+                for i in range(2 * st.in1_ls[b] + 1):
+                    A(f"      asm volatile(\"\" : \"+v\"(xb{b}O[{i}]));")
+            n_t = 0
+            for p_ in paths:
+                b2, j2, s2 = st.instr[p_]
+                n_t += int((np.abs(np.array(wigner_3j(st.in1_ls[b2], st.in2_ls[j2], st.out_ls[s2]))).sum(axis=2) != 0).sum())
+            nohoist = n_t > int(os.environ.get("NQA_GEN_SPLIT_NOHOIST", "64"))
+            A("      int rot = 0;")
+            A("      bool first = true;")
+            A("      while (hasA) {")
+            A("        hasC = idx + 2 < end;")
+            A("        if (hasC) {")
+            A("          if (((kk + 2) & 63) == 0) {")
+            L.extend(blk_load("            ", "kk + 2"))
+            A("          }")
+            L.extend(idx_get("C", "kk + 2", "          "))
+            A("        }")
+            A("        T* __restrict__ gwr_e = a.gw + (int64_t)prA * a.wn;")
+            A("        T* __restrict__ gxr = a.gxe + (int64_t)(ATOM ? jnA : idx) * a.din;")
+            A("#pragma unroll")
+            A("        for (int j = 0; j < kS; ++j) { qI[j] = T(0); qX[j] = T(0); }")
+            if nohoist:
+                for s_ in slots:
+                    for k in range(2 * st.out_ls[s_] + 1):
+                        A(f"        asm volatile(\"\" : \"+v\"(gvO[{opre[s_] + k}]));")
+            for c_ in range(RC):
+                lo = lds_off[c_]
+                nfirst = D_pair + sum(Sgw[:c_])
+                nfirst_gx = f"(ATOM ? {nfirst + sum(Sgx_atom[:c_])} : {nfirst + sum(Sgx[:c_])})"
+                nsteady = D_pair + sum(Sgw)
+                nsteady_gx = f"(ATOM ? {nsteady + sum(Sgx_atom)} : {nsteady + sum(Sgx)})"
+                A(f"        {{  // ---- chunk {c_}: paths {cpaths[c_]}")
+                A(f"          int s_ = rot + {c_}; s_ = s_ >= {RN} ? s_ - {RN} : s_;")
+                A(f"          const unsigned char* __restrict__ cb = nqa_smem + (wbase + (unsigned)s_ * {RSLOT}u);")
+                A("          if (!hasB) spec_wait_vm<0>();")
+                A(f"          else if (first) spec_wait_vm<GX ? {nfirst_gx} : {nfirst}>();")
+                A(f"          else spec_wait_vm<GX ? {nsteady_gx} : {nsteady}>();")
+                if c_ == 0:
+                    for j in ys:
+                        for i in range(2 * st.in2_ls[j] + 1):
+                            A(f"          yb{j}I[{i}] = *reinterpret_cast<const T*>(cb + {lo[('y', 'I')] + 4 * (ypre[j] + i)});")
+                            A(f"          yb{j}X[{i}] = *reinterpret_cast<const T*>(cb + {lo[('y', 'X')] + 4 * (ypre[j] + i)});")
+                for b_ in blocks:
+                    if xplace[b_] == c_:
+                        d1 = 2 * st.in1_ls[b_] + 1
+                        for i in range(d1):
+                            A(f"          xb{b_}J[{i}] = *reinterpret_cast<const T*>(cb + {lo[('x', b_)]} + l4 * {d1}u + {4 * i});")
+                for pth in cpaths[c_]:
+                    b_, j, s_ = st.instr[pth]
+                    d1, d3 = 2 * st.in1_ls[b_] + 1, 2 * st.out_ls[s_] + 1
+                    if first_pb[b_] == pth:
+                        for i in range(d1):
+                            A(f"          gxa[{xpre[b_] + i}] = T(0);")
+                    A(f"        {{  // path {pth}")
+                    A(f"          const T wv_ = *reinterpret_cast<const T*>(cb + {lo[('w', pth)]} + l4);")
+                    for k in range(d3):
+                        A(f"          gvJ[{opre[s_] + k}] = T({slot_coeff[s_]!r}) * *reinterpret_cast<const T*>(cb + {lo[('g', s_)]} + l4 * {d3}u + {4 * k});")
+                    body = []
+                    live_i, gx_i = sp_path(body, pth, "J", "gvO", "I", "i")
+                    for comp, expr in gx_i:
+                        if expr:
+                            body.append(f"          if (GX) gxa[{comp}] += wv_ * ({expr});")
+                    live_x, gx_x = sp_path(body, pth, "O", "gvJ", "X", "x")
+                    for comp, expr in gx_x:
+                        if expr:
+                            body.append(f"          if (GX) gxO[{comp}] += wv_ * ({expr});")
+                    L.extend(body)
+                    terms = [f"yb{j}I[{jj}] * Bi{jj}" for jj in live_i] + [f"yb{j}X[{jj}] * Bx{jj}" for jj in live_x]
+                    gw_expr = " + ".join(terms) if terms else "T(0)"
+                    A(f"          {{ const T r_ = {gw_expr}; {emit_store(f'spec_at(gwr_e + (unsigned)(mul * {pth}), ucb)', 'r_')}; }}")
+                    for jj in live_i:
+                        A(f"          qI[{ypre[j] + jj}] += wv_ * Bi{jj};")
+                    for jj in live_x:
+                        A(f"          qX[{ypre[j] + jj}] += wv_ * Bx{jj};")
+                    A("        }")
+                    if last_pb[b_] == pth:
+                        A("          if (GX) {")
+                        for i in range(d1):
+                            st_ = emit_store(f'spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb)', f'gxa[{xpre[b_] + i}]')
+                            A(f"            if (ATOM) unsafeAtomicAdd(spec_at(gxr + (unsigned)(mul * {xpre[b_] + i}), ucb), gxa[{xpre[b_] + i}]); else {st_};")
+                        A("          }")
+                if c_ == RC - 1:
+                    if part_i == 0 and unused_comps:
+                        A("          if (GX && !ATOM) {")
+                        for i in unused_comps:
+                            A(f"            *spec_at(gxr + (unsigned)(mul * {i}), ucb) = T(0);")
+                        A("          }")
+                    A("          if (hasC) {")
+                    L.extend(issue("            ", 0, "C", "s_"))
+                    A("          }")
+                    A(f"          spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)eiA * a.gy_stride + (chunk * kPairParts + {part_i}) * kS, lane);")
+                    A(f"          spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eoA * a.gy_stride + (chunk * kPairParts + {part_i}) * kS, lane);")
+                else:
+                    A("          if (hasB) {")
+                    L.extend(issue("            ", c_ + 1, "B", "s_"))
+                    A("          }")
+                A("        }")
+            A("        jnA = jnB; prA = prB; eiA = eiB; eoA = eoB; jnB = jnC; prB = prC; eiB = eiC; eoB = eoC;")
+            A("        hasA = hasB; hasB = hasC; ++idx; ++kk; first = false;")
+            A(f"        rot += {RC}; rot = rot >= {RN} ? rot - {RN} : rot;")
+            A("      }")
+            A("      if (GX) {")
+            A("        T* __restrict__ ob = a.out + (int64_t)node * a.din;")
+            for b in blocks:
+                d = 2 * st.in1_ls[b] + 1
+                for i in range(d):
+                    A(f"        ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = gxO[{xpre[b] + i}];")
+            if part_i == 0:
+                for b in range(NB):
+                    if b not in used_any:
+                        d = 2 * st.in1_ls[b] + 1
+                        for i in range(d):
+                            A(f"        ob[(int64_t)mul * {xpre[b]} + (int64_t)u * {d} + {i}] = T(0);")
+            A("      }")
+            A("    } break;")
+        A("    default: break;")
+        A("  }")
+        A("}")
+
     # ------------------------------------------------------------------ accumulator form of grad_x (ATOM), last step
     if pair_ok or pair_parts > 1:
         A("// a.out[n] += the accumulator row of n (ATOM forms of the pair kernels), re-ordered from component rows to the irreps layout")
@@ -2019,6 +2340,19 @@ def _emit(st: Structure) -> str:
         A("    const int64_t witems = items * kPairParts;  // one wavefront per (node, chunk, part)")
         A("    const dim3 grid((unsigned)((witems + 3) / 4)), blk(256);")
         A("    if (a.out != nullptr) {")
+        if split_ring_ok:
+            A("      // LDS-ring form (round 6): multiples of 64 channels; NQA_PAIR_RING=0 keeps the plain loop")
+            A("      const bool sring_ = [] { const char* v = std::getenv(\"NQA_PAIR_RING\"); return v == nullptr || v[0] != '0'; }();")
+            A("      if (sring_ && (a.mul & 63) == 0) {")
+            A(f"        const size_t rsmem = (size_t)4 * {SR_WAVE};")
+            A("#define NQA_SRING_LAUNCH(GX_, AT_) do { \\")
+            A("          static const bool once_ = [] { return hipFuncSetAttribute((const void*)bwd_pair_split_ring_kernel<GX_, AT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * " + str(20480) + ")) == hipSuccess; }(); \\")
+            A("          if (!once_) return 1; \\")
+            A("          hipLaunchKernelGGL((bwd_pair_split_ring_kernel<GX_, AT_>), grid, blk, rsmem, stream, a); } while (0)")
+            A("        if (a.gx_atomic) NQA_SRING_LAUNCH(true, true); else NQA_SRING_LAUNCH(true, false);")
+            A("#undef NQA_SRING_LAUNCH")
+            A("        return 0;")
+            A("      }")
         A("      if (a.gx_atomic && (a.mul & 63) != 0) return 1;")
         A("      if (a.gx_atomic) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true, true>), grid, blk, 0, stream, a);")
         A("      else if (full) hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true>), grid, blk, 0, stream, a);")

@@ -201,6 +201,14 @@ int main(int argc, char** argv) {
 
   const int64_t items = (int64_t)N * nchunk;
   auto launch_pair = [&]() {
+#ifdef LAB_SRING
+    {
+      const int64_t witems = items * kPairParts;
+      if (gxat) hipLaunchKernelGGL((bwd_pair_split_ring_kernel<true, true>), dim3((unsigned)((witems + 3) / 4)), dim3(256), (size_t)81920, 0, a);
+      else hipLaunchKernelGGL((bwd_pair_split_ring_kernel<true, false>), dim3((unsigned)((witems + 3) / 4)), dim3(256), (size_t)81920, 0, a);
+      return;
+    }
+#endif
 #ifdef LAB_SPLIT
     const int64_t witems = items * kPairParts;
     hipLaunchKernelGGL((bwd_pair_split_kernel<float, true, true>), dim3((unsigned)((witems + 3) / 4)), dim3(256), 0, 0, a);
@@ -230,6 +238,10 @@ int main(int argc, char** argv) {
   auto launch_sum = [&]() {
     hipLaunchKernelGGL((gx_rows_sum_kernel<float, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, 0, b);
   };
+#ifdef LAB_SRING
+  CK(hipFuncSetAttribute((const void*)bwd_pair_split_ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+  CK(hipFuncSetAttribute((const void*)bwd_pair_split_ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+#endif
 #ifdef LAB_RING
   const int ring_lds = 4 * kRingWaveBytes + (int)extra_lds;
 #define LAB_RING_ATTR(W, AT) CK(hipFuncSetAttribute((const void*)bwd_pair_ring_kernel<W, true, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds))
