@@ -563,6 +563,11 @@ int nqa_tp_scatter_bwd_x_paired(const nqa_plan* plan, const void* plan_image, in
  *   grad_y [E, dim_in2] per directed edge, grad_x [N, dim_in1] or NULL (grad_w and grad_y only: other_rowptr /
  *   other_slot are then not read).  float32 structure-specialised plans whose register
  *   budget allows it: nqa_tp_bwd_pairs_workspace_bytes returns -1 otherwise (use the per-edge entry points).
+ *   Round 6: for multiples of 64 channels (and at least as many pairs as nodes) the other node's grad_x contributions are
+ *   summed by floating-point atomics into a zeroed [N, dim_in1] accumulator inside the same workspace instead of one row per
+ *   pair + a row sum (other_rowptr / other_slot are then not read): grad_x is equal within fp32 rounding but NOT bit-identical
+ *   from call to call (sums in arrival order).  NQA_PAIR_GX_ATOMIC=0 in the environment keeps the fixed-order rows,
+ *   NQA_PAIR_RING=0 the register / plain-loop kernels of rounds 3-5 (both read at every call).
  * ------------------------------------------------------------------------------------------- */
 int64_t nqa_tp_bwd_pairs_workspace_bytes(const nqa_plan* plan, int32_t dtype, int64_t num_edges);
 int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32_t dtype, const void* x, const void* y,
