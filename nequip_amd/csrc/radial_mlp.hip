@@ -1592,7 +1592,7 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
                          hidden, out_features, wf, ts);
     // round 5: outputs of complete 32-column tiles run on the issue-scheduled kernel (radial_mlp_pipe.h; NQA_MLP_PIPE=0:
     // the general kernel)
-    static const bool pipe = [] {
+    const bool pipe = [] {  // (read at every call: the tests switch kernels within one process)
       const char* v = std::getenv("NQA_MLP_PIPE");
       return v == nullptr || v[0] != '0';
     }();
@@ -1604,7 +1604,7 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
       // tile epilogue: through the wave-private LDS transpose (default: 128-133 us for the cfg-3 middle layer, 48 us for the
       // first / last one) or straight from the accumulators with the MFMA operands swapped (NQA_MLP_PIPE_DIRECT=1: 134-161
       // / 50 us at 244 registers) -- profiles/r5_mlp_fwd_kernel_trace.txt; the round-4 kernel: 149-161 / 60 us
-      static const bool via_lds = [] {
+      const bool via_lds = [] {
         const char* v = std::getenv("NQA_MLP_PIPE_DIRECT");
         return !(v != nullptr && v[0] == '1');
       }();
@@ -1650,7 +1650,7 @@ static int mlp_fwd_impl(int32_t dtype, int32_t mode, const void* edge_embedding,
     }
     // default: balanced work-unit ranges over a fixed grid of two workgroups per CU (NQA_MLP_FWD_BALANCED=0 or any
     // ablation bit: one workgroup per 128-row block)
-    static const bool balanced = [] {
+    const bool balanced = [] {
       const char* v = std::getenv("NQA_MLP_FWD_BALANCED");
       return v == nullptr || v[0] != '0';
     }();
@@ -1766,19 +1766,19 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
     // and a persistent launch that holds two workgroups on every CU for its whole duration costs those more than it saves
     // (same-box A/B of the whole step, profiles/r5_step_ab_mlp.txt: 2.37-2.39 ms with the general backward kernel, 2.48-2.49 ms
     // with the coalesced persistent one, both with the new forward).
-    static const bool pipe = [] {
+    const bool pipe = [] {
       const char* v = std::getenv("NQA_MLP_PIPE");
       return v == nullptr || v[0] != '0';
     }();
-    static const bool coal = [] {
+    const bool coal = [] {
       const char* v = std::getenv("NQA_MLP_BWD_COAL");
       return v != nullptr && v[0] == '1';
     }();
-    static const bool balanced = [] {
+    const bool balanced = [] {
       const char* v = std::getenv("NQA_MLP_BWD_BALANCED");
       return v != nullptr && v[0] == '1';
     }();
-    static const int pf = [] {
+    const int pf = [] {
       const char* v = std::getenv("NQA_MLP_BWD_PF");
       return v ? std::atoi(v) : 2;
     }();
@@ -1792,7 +1792,7 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
     // registers (radial_mlp_bwd_small_kernel: alone 96 -> 76 us at cfg-3's W = 192, inside the step 87 -> 72 us for the
     // first layer's launch -- and yet the step as a whole comes out 2 % SLOWER in four of four same-box repetitions, with
     // the hint and without (profiles/r5_mlp_bwd_small.txt); opt-in: NQA_MLP_BWD_SMALL=1 with the hint, 2 always)
-    static const int small_mode = [] {  // NQA_MLP_BWD_SMALL: 0 never (default), 1 with the hint, 2 whenever the shape fits
+    const int small_mode = [] {  // NQA_MLP_BWD_SMALL: 0 never (default), 1 with the hint, 2 whenever the shape fits
       const char* v = std::getenv("NQA_MLP_BWD_SMALL");
       return v ? std::atoi(v) : 0;
     }();
@@ -1819,7 +1819,7 @@ static int mlp_bwd_impl(int32_t dtype, int32_t mode, int tm, const void* edge_em
     const bool use_coal = coal && hidden == 128 && out_features % 64 == 0 && dbg == 0;
     const bool use_bal = (balanced || dbg != 0) && out_features % 32 == 0;
     if (pipe && tm == 0 && g2 == nullptr && (use_coal || use_bal)) {
-      static const int wgs_per_cu = [] {  // NQA_MLP_BWD_WGS_PER_CU=1: half the chip for the (side-stream) persistent launch
+      const int wgs_per_cu = [] {  // NQA_MLP_BWD_WGS_PER_CU=1: half the chip for the (side-stream) persistent launch
         const char* v = std::getenv("NQA_MLP_BWD_WGS_PER_CU");
         const int n = v ? std::atoi(v) : 2;
         return n >= 1 && n <= 2 ? n : 2;

@@ -171,8 +171,12 @@ CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stage_loop", ["default", "one_wait_per_stage"])
 @pytest.mark.parametrize("hidden,n_types,n_atoms", CASES)
-def test_fused_stage_matches_separate_launches_and_float64(device, hidden, n_types, n_atoms):
+def test_fused_stage_matches_separate_launches_and_float64(device, hidden, n_types, n_atoms, stage_loop, monkeypatch):
+    # `one_wait_per_stage`: the opt-in stage loop of node_fused_kernel<true> / node_linear_pipe_kernel (NQA_NODE_PIPE=1, read
+    # at every launch; measured no faster) has to give the default's results
+    monkeypatch.setenv("NQA_NODE_PIPE", "1" if stage_loop == "one_wait_per_stage" else "0")
     torch.manual_seed(1)
     gate, lin1, sc = _layer(hidden)
     gate, lin1, sc = gate.eval(), lin1.eval(), sc.eval()

@@ -289,3 +289,44 @@ def test_radial_mlp_zero_edges_first_then_real_graph(device, depth):
     (ge,) = torch.autograd.grad(out, e_dev, g.to(device))
     torch.testing.assert_close(ref.detach(), out.detach().cpu(), atol=1e-5 * float(ref.abs().max()), rtol=1e-5)
     torch.testing.assert_close(ge_ref, ge.cpu(), atol=2e-5 * float(ge_ref.abs().max()), rtol=2e-5)
+
+
+# Kernel variants that are not the default (measured slower in the step) but stay selectable: every one
+# of them has to give the default's results.  The switches are read at every call.
+MLP_VARIANTS = {
+    "general_fwd_bwd": {"NQA_MLP_PIPE": "0"},
+    "fwd_direct_epilogue": {"NQA_MLP_PIPE_DIRECT": "1"},
+    "fwd_one_workgroup_per_block": {"NQA_MLP_FWD_BALANCED": "0"},
+    "bwd_coalesced_rows": {"NQA_MLP_BWD_COAL": "1"},
+    "bwd_balanced_ranges": {"NQA_MLP_BWD_BALANCED": "1"},
+    "bwd_balanced_prefetch4": {"NQA_MLP_BWD_BALANCED": "1", "NQA_MLP_BWD_PF": "4"},
+    "bwd_small_lds_resident": {"NQA_MLP_BWD_SMALL": "2"},
+    "bwd_half_chip": {"NQA_MLP_BWD_COAL": "1", "NQA_MLP_BWD_WGS_PER_CU": "1"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", list(MLP_VARIANTS))
+@pytest.mark.parametrize("E,W", [(4133, 704), (70001, 192), (513, 64)])
+def test_radial_mlp_opt_in_kernels_match_the_default(device, monkeypatch, variant, E, W):
+    from nequip_amd.nn.mlp import ScalarMLPFunction
+
+    _set_mode(monkeypatch, "f16x3")
+    torch.manual_seed(E + W)
+    mlp = ScalarMLPFunction(input_dim=8, output_dim=W, hidden_layers_depth=1, hidden_layers_width=128).eval().to(device)
+    emb = (torch.randn(E, 8) * 0.7).to(device)
+    g = torch.randn(E, W).to(device)
+
+    def run():
+        e = emb.clone().requires_grad_(True)
+        out = mlp(e)
+        (ge,) = torch.autograd.grad(out, e, g)
+        return out.detach(), ge
+
+    ref_out, ref_ge = run()
+    for k_, v_ in MLP_VARIANTS[variant].items():
+        monkeypatch.setenv(k_, v_)
+    out, ge = run()
+    # (different summation orders of the same split products: equal at the fp32 rounding level)
+    torch.testing.assert_close(out, ref_out, atol=2e-6 * float(ref_out.abs().max()), rtol=2e-6)
+    torch.testing.assert_close(ge, ref_ge, atol=5e-6 * float(ref_ge.abs().max()), rtol=5e-6)
