@@ -695,7 +695,7 @@ def other_workloads(timeout_s: float = 420.0):
             d = json.loads(line)
             rf = d.get("roofline") or {}
             out[wl] = {"ms_per_step": d.get("ms_per_step"), "value": d.get("value"), "unit": d.get("unit"),
-                       "metric": d.get("metric"), "n_atoms": (d.get("config") or {}).get("n_atoms"),
+                       "metric": d.get("metric"), "workload": (d.get("config") or {}).get("workload"),
                        "dominant_kernel": rf.get("kernel"), "dominant_avg_launch_ms": rf.get("avg_launch_ms"),
                        "dominant_frac": rf.get("frac"), "dominant_bound": rf.get("bound"), "traffic": None,
                        "step_frac": (d.get("step_roofline") or {}).get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
