@@ -102,34 +102,41 @@ __global__ __launch_bounds__(256) void edge_vectors_bwd_kernel(const double* __r
 
 // One workgroup per frame: m = sum over the frame's atoms of part[n] (ordered tree reduction), virial = -sym(m),
 // stress = sym(m) / |det cell|.  Replaces the tail of ForceStressOutput.forward (nequip/nn/grad_output.py:222-271).
-__global__ __launch_bounds__(256) void virial_finalize_kernel(const double* __restrict__ part,
-                                                              const int64_t* __restrict__ batch,
-                                                              const double* __restrict__ cell, int64_t N,
-                                                              double* __restrict__ virial,
-                                                              double* __restrict__ stress) {
-  __shared__ double red[9][256];
+// (round 6: 1024 threads per frame -- the 10 125-atom box kept one 256-thread workgroup busy for 19 us at the very end of
+// the step -- wavefront sums by DPP-free shuffles in a fixed order, then 16 partial rows through LDS: deterministic)
+__global__ __launch_bounds__(1024) void virial_finalize_kernel(const double* __restrict__ part,
+                                                               const int64_t* __restrict__ batch,
+                                                               const double* __restrict__ cell, int64_t N,
+                                                               double* __restrict__ virial,
+                                                               double* __restrict__ stress) {
+  __shared__ double red[9][16];
   const int f = blockIdx.x, tid = threadIdx.x;
   double m[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) m[i] = 0.0;
-  for (int64_t n = tid; n < N; n += 256) {
+  for (int64_t n = tid; n < N; n += 1024) {
     if (batch != nullptr && batch[n] != f) continue;
 #pragma unroll
     for (int i = 0; i < 9; ++i) m[i] += part[9 * n + i];
   }
 #pragma unroll
-  for (int i = 0; i < 9; ++i) red[i][tid] = m[i];
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) {
+  for (int i = 0; i < 9; ++i) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) red[i][tid] += red[i][tid + off];
-    }
-    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) m[i] += __shfl_down(m[i], off, 64);
   }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) red[i][tid >> 6] = m[i];
+  }
+  __syncthreads();
   if (tid < 9) {
     const int a = tid / 3, b = tid - 3 * a;
-    const double sym = 0.5 * (red[3 * a + b][0] + red[3 * b + a][0]);
+    double sab = 0.0, sba = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      sab += red[3 * a + b][w];
+      sba += red[3 * b + a][w];
+    }
+    const double sym = 0.5 * (sab + sba);
     virial[9 * f + tid] = -sym;
     if (stress != nullptr) {
       const double* __restrict__ c = cell + 9 * f;
@@ -228,7 +235,7 @@ int nqa_virial_finalize(const double* per_atom, const int64_t* batch, const doub
   }
   if (num_frames == 0) return NQA_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(virial_finalize_kernel, dim3((unsigned)num_frames), dim3(256), 0, s, per_atom,
+  hipLaunchKernelGGL(virial_finalize_kernel, dim3((unsigned)num_frames), dim3(1024), 0, s, per_atom,
                      num_frames > 1 ? batch : nullptr, cell, num_nodes, virial, stress);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {

@@ -1364,7 +1364,6 @@ def _emit(st: Structure) -> str:
         RN = RC + 1
         # chunk images: [w segments][x segments][g segments][y_in][y_out]; a segment = (kind, id, units)
         chunk_paths = [list(range(rbounds[c_], rbounds[c_ + 1])) for c_ in range(RC)]
-        img = []      # per chunk: dict kind -> list of (id, start_unit_in_stream, units)
         lds_off = []  # per chunk: dict (kind, id) -> byte offset inside the slot
         dma = []      # per chunk: list of (kind, lds_byte_off, nlanes, [(lane_lo, lane_hi, id, unit_in_segment_at_lane_lo)])
         for c_ in range(RC):

@@ -26,6 +26,14 @@ OPS = ["tp_scatter_fwd", "tp_scatter_bwd", "edge_vectors", "edge_vectors_adj", "
        "node_stage_fwd", "node_stage_bwd", "energy_head_fwd", "energy_head_bwd", "force_virial"]
 
 
+@pytest.fixture(autouse=True)
+def _fixed_order_pair_backward(monkeypatch):
+    """The tests of this module compare two evaluations BIT FOR BIT (C++ ops vs Python ops, cached vs fresh topology): the
+    pair-centric backward has to sum the other node's grad_x in a fixed order for that (rows + row sum instead of the
+    default accumulator of round 6, whose atomics add in arrival order).  Inherited by the child processes."""
+    monkeypatch.setenv("NQA_PAIR_GX_ATOMIC", "0")
+
+
 @pytest.fixture(scope="module")
 def cpp():
     if not os.path.exists(LIB) or not os.path.exists(RUNNER):

@@ -81,6 +81,12 @@ def test_cfg3_tensor_product_kernels():
     assert pair["vgpr_spill"] == 0 and kr.waves_per_simd(pair["vgpr"]) >= 2
     bx = _find(ks, "bwd_x_kernel<float, 4, false>")
     assert bx["vgpr_spill"] == 0 and kr.waves_per_simd(bx["vgpr"]) >= 4
+    # round 6: the LDS-ring pair kernel that now carries `roofline` (one wavefront per node, accumulator form): two wavefronts
+    # per SIMD, NOTHING spilled (a scratch reload is a vector load: hipcc's own vmcnt wait would drain the ring every pair)
+    for inst in ("bwd_pair_ring_kernel<1, true, true>", "bwd_pair_ring_kernel<1, true, false>", "bwd_pair_ring_kernel<4, true, true>",
+                 "bwd_pair_ring_kernel<1, false, false>"):
+        ring = _find(ks, inst)  # 247 VGPRs (GX), dynamic LDS: 4 x 19 456 B per workgroup
+        assert ring["vgpr_spill"] == 0 and ring["scratch"] == 0 and kr.waves_per_simd(ring["vgpr"]) >= 2, (inst, ring)
 
 
 def test_every_structure_kernel_without_spills_is_listed_or_known():
