@@ -282,6 +282,51 @@ def test_pair_backward_equals_per_edge_backward(device, system, form, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form,expect", [("ring_atomic", ("bwd_pair_ring_kernel", "gx_acc_finish_kernel")),
+                                         ("ring_rows", ("bwd_pair_ring_kernel", "gx_rows_sum_kernel")),
+                                         ("registers", ("bwd_pair_kernel", "gx_rows_sum_kernel"))])
+def test_the_selected_pair_kernels_are_the_ones_that_run(device, form, expect, monkeypatch):
+    """Which GPU kernels a call of `nqa_tp_scatter_bwd_pairs` launches under each of the three forms (kernel names from the
+    profiler's device activity records): the default must BE the LDS-ring kernel with the accumulator, not a fallback."""
+    from torch.profiler import ProfilerActivity, profile
+
+    from nequip_amd.nn._topology import EdgeTopology
+    from nequip_amd.utils import synthetic as syn
+
+    for k_, v_ in PAIR_FORMS[form].items():
+        monkeypatch.setenv(k_, v_)
+    pos, types, cell, names = syn.water_box(n_side=4, seed=1)
+    data = syn.make_data(pos, types, 4.5, cell)
+    name, f_in_1x, lmax, f_out_1x = next(s for s in STRUCTS if s[0] == "l2n_mid")
+    tps, f_in, e_at, mid_s, instructions = _module(f_in_1x, lmax, f_out_1x, 64, device)
+    k = tps._get_kernels()
+    ei = data["edge_index"].to(device)
+    N, E = data["pos"].shape[0], ei.shape[1]
+    topo = EdgeTopology(ei[0].contiguous(), ei[1].contiguous(), N)
+    pr = topo.pairing(data["edge_cell_shift"].to(device))
+    P = pr.num_pairs
+    g = torch.Generator().manual_seed(3)
+    d = lambda t: t.to(device)  # noqa: E731
+    x, y = d(torch.randn(N, k.dim_in1, generator=g)), d(torch.randn(E, k.dim_in2, generator=g))
+    w, go = d(torch.randn(P, k.weight_numel, generator=g) / 4), d(torch.randn(N, k.dim_out, generator=g))
+    k.bwd_pairs(x, y, w, go, topo, pr)  # (lists, workspace, first-launch attributes: outside the recorded region)
+    torch.cuda.synchronize()
+    try:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            k.bwd_pairs(x, y, w, go, topo, pr)
+            torch.cuda.synchronize()
+        names_seen = {e.key for e in prof.key_averages()}
+    except Exception as exc:  # pragma: no cover
+        pytest.skip(f"no device activity records here: {exc}")
+    if not any("nqa" in n for n in names_seen):
+        pytest.skip("the profiler returned no kernel names on this box")
+    for want in expect:
+        assert any(want + "<" in n or want + "(" in n for n in names_seen), (want, sorted(names_seen))
+    if form != "registers":
+        assert not any("bwd_pair_kernel<" in n for n in names_seen), sorted(names_seen)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["ring_atomic", "ring_rows"])
 def test_ring_kernel_more_than_64_pairs_per_wavefront(device, form, monkeypatch):
     """One wavefront of the ring kernel keeps the indices of 64 of its pairs in registers and fetches the next block when it
