@@ -576,14 +576,23 @@ def train_bench(args, world, rank, device, distributed):
     use_graph = (not distributed) and os.environ.get("NQA_TRAIN_GRAPH", "1") not in ("", "0")
     opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=use_graph)
 
-    def step():
+    collective_events = []  # (start, end) HIP events around post_backward of the instrumented steps (N > 1)
+
+    def step(record_collective=False):
         opt.zero_grad(set_to_none=True)
         out = model(dict(data))
         loss = (out["forces"] - f_target).square().mean() + (out["total_energy"] - e_target).square().mean()
         # the shipped training step: SimpleDDPStrategy.backward (parameter gradients off the data chain,
         # nequip_amd/utils/wgrad.py), then the flat all-reduce -- nequip/train/lightning.py:259-266
         strategy.backward(loss * strategy.world_size)
-        strategy.post_backward(loss)
+        if record_collective:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            strategy.post_backward(loss)
+            ev1.record()
+            collective_events.append((ev0, ev1))
+        else:
+            strategy.post_backward(loss)
         opt.step()
         return loss
 
@@ -641,13 +650,23 @@ def train_bench(args, world, rank, device, distributed):
             ktimer.reset()
             ktimer.enable(True)
         for _ in range(args.kernel_steps):
-            step()
+            step(record_collective=distributed)
         torch.cuda.synchronize()
         if rank == 0:
             ktimer.enable(False)
             kernels = ktimer.summary()
             roofline, step_roofline = roofline_objects(kernels, args.kernel_steps, elapsed / args.steps * 1e3,
                                                        args.workload, live_pmc=False)
+    # per-rank time of the gradient synchronisation (flatten + all-reduce + copy back; the device time between two events on
+    # the launching stream, so it includes waiting for the slowest rank): lets a scaling curve be split into compute and
+    # collective the day more than one GPU runs this
+    collective_ms = None
+    if distributed:
+        mine = (sum(a.elapsed_time(b) for a, b in collective_events) / len(collective_events)) if collective_events else 0.0
+        t = torch.tensor([mine], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        collective_ms = [float(g.item()) for g in gathered]
     if rank == 0:
         print(json.dumps({
             "metric": "atom-optimizer-steps/s (DDP force-matching training)",
@@ -658,7 +677,8 @@ def train_bench(args, world, rank, device, distributed):
                        f"({n_edges} edges), {w['n_species']} species, l_max={w['l_max']}, {w['num_features']} features, "
                        "energy+force MSE loss, Adam, flat gradient all-reduce (SimpleDDP)",
                        "parallelism": f"dp{world}", "final_loss": float(loss.detach()), "launch": launch,
-                       "collective": ("RCCL all-reduce of one flat fp32 gradient buffer per step" if distributed else "none (1 rank)")},
+                       "collective": ("RCCL all-reduce of one flat fp32 gradient buffer per step" if distributed else "none (1 rank)"),
+                       "collective_ms_per_rank": collective_ms},
             "roofline": roofline, "step_roofline": step_roofline,
             "kernels_ms_per_step": {k: v["total_ms"] / max(args.kernel_steps, 1) for k, v in kernels.items()},
         }))

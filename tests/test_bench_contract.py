@@ -134,6 +134,9 @@ def test_bench_two_ranks_training_line_on_a_shared_device(device):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and "all-reduce" in d["config"]["collective"]
+    # round 6: the gradient synchronisation timed on every rank (compute / collective split of a scaling curve)
+    per_rank = d["config"]["collective_ms_per_rank"]
+    assert isinstance(per_rank, list) and len(per_rank) == 2 and all(t > 0 for t in per_rank), per_rank
     assert d["value"] > 0 and "node_linear" in d["kernels_ms_per_step"]
 
 
