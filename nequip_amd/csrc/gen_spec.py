@@ -2311,8 +2311,8 @@ def _emit(st: Structure) -> str:
             A("      const size_t rsmem = (size_t)4 * kRingWaveBytes;")
             A("      const dim3 rgrid((unsigned)((items * rw + 3) / 4)), rblk(256);")
             A("#define NQA_RING_LAUNCH(W, GX_, AT_) do { \\")
-            A("        static const bool once_ = [] { return hipFuncSetAttribute((const void*)bwd_pair_ring_kernel<W, GX_, AT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kRingWaveBytes) == hipSuccess; }(); \\")
-            A("        if (!once_) return 1; \\")
+            A("        static bool lds_ok_[64] = {}; \\")
+            A("        if (!spec_allow_lds((const void*)bwd_pair_ring_kernel<W, GX_, AT_>, 4 * kRingWaveBytes, lds_ok_)) return 1; \\")
             A("        hipLaunchKernelGGL((bwd_pair_ring_kernel<W, GX_, AT_>), rgrid, rblk, rsmem, stream, a); } while (0)")
             A("#define NQA_RING_WPN(GX_, AT_) do { if (rw == 1) NQA_RING_LAUNCH(1, GX_, AT_); else if (rw == 2) NQA_RING_LAUNCH(2, GX_, AT_); else NQA_RING_LAUNCH(4, GX_, AT_); } while (0)")
             A("      if (a.out == nullptr) NQA_RING_WPN(false, false);")
@@ -2345,8 +2345,8 @@ def _emit(st: Structure) -> str:
             A("      if (sring_ && (a.mul & 63) == 0) {")
             A(f"        const size_t rsmem = (size_t)4 * {SR_WAVE};")
             A("#define NQA_SRING_LAUNCH(GX_, AT_) do { \\")
-            A("          static const bool once_ = [] { return hipFuncSetAttribute((const void*)bwd_pair_split_ring_kernel<GX_, AT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * " + str(20480) + ")) == hipSuccess; }(); \\")
-            A("          if (!once_) return 1; \\")
+            A("          static bool lds_ok_[64] = {}; \\")
+            A("          if (!spec_allow_lds((const void*)bwd_pair_split_ring_kernel<GX_, AT_>, 4 * " + str(20480) + ", lds_ok_)) return 1; \\")
             A("          hipLaunchKernelGGL((bwd_pair_split_ring_kernel<GX_, AT_>), grid, blk, rsmem, stream, a); } while (0)")
             A("        if (a.gx_atomic) NQA_SRING_LAUNCH(true, true); else NQA_SRING_LAUNCH(true, false);")
             A("#undef NQA_SRING_LAUNCH")

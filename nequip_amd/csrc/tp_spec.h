@@ -106,6 +106,18 @@ __device__ __forceinline__ int spec_wrow(const SpecArgs<T>& a, int slot) {
   return spec_wrow_of(a, spec_gwrow(a, slot));
 }
 
+// More than 64 KiB of dynamic LDS needs the function attribute, per device: set at a kernel's first launch on each device of
+// this process (host side).  `done`: the caller's per-kernel-instantiation table (a static at the launch site).
+static inline bool spec_allow_lds(const void* fn, int bytes, bool (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done[dev] = true;
+  }
+  return true;
+}
+
 // ---- LDS-DMA (global -> LDS without registers) ------------------------------------------------------------------
 // One instruction moves 64 lanes x 16 (or 4) bytes: lane l's bytes come from `base + lane_off` (wave-uniform 64-bit base in
 // scalar registers, per-lane 32-bit byte offset) and land at LDS byte address `lds + 16 l` (`lds + 4 l`), `lds` wave-uniform
