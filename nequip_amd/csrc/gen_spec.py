@@ -1633,8 +1633,9 @@ def _emit(st: Structure) -> str:
                 A("      if (hasC) {")
                 L.extend(ring_issue("        ", 0, "C", "s_"))
                 A("      }")
-                A(f"      {STG}spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)eiA * a.gy_stride + chunk * kS, lane);")
-                A(f"      {STG}spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eoA * a.gy_stride + chunk * kS, lane);")
+                A("      // (a.gy_atomic: more than one channel chunk per edge -- the chunks add into grad_y itself instead of partial rows)")
+                A(f"      {STG}spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)eiA * a.gy_stride + (a.gy_atomic ? 0 : chunk * kS), lane, a.gy_atomic != 0);")
+                A(f"      {STG}spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eoA * a.gy_stride + (a.gy_atomic ? 0 : chunk * kS), lane, a.gy_atomic != 0);")
             else:
                 A(f"      // refill this slot with chunk {c_ + 1} of the next pair")
                 A("      if (hasB) {")
@@ -2172,8 +2173,8 @@ def _emit(st: Structure) -> str:
                     A("          if (hasC) {")
                     L.extend(issue("            ", 0, "C", "s_"))
                     A("          }")
-                    A(f"          spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)eiA * a.gy_stride + (chunk * kPairParts + {part_i}) * kS, lane);")
-                    A(f"          spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eoA * a.gy_stride + (chunk * kPairParts + {part_i}) * kS, lane);")
+                    A(f"          spec_wave_reduce_store<T, kS>(qI, a.gy + (int64_t)eiA * a.gy_stride + (a.gy_atomic ? 0 : (chunk * kPairParts + {part_i}) * kS), lane, a.gy_atomic != 0);")
+                    A(f"          spec_wave_reduce_store<T, kS>(qX, a.gy + (int64_t)eoA * a.gy_stride + (a.gy_atomic ? 0 : (chunk * kPairParts + {part_i}) * kS), lane, a.gy_atomic != 0);")
                 else:
                     A("          if (hasB) {")
                     L.extend(issue("            ", c_ + 1, "B", "s_"))

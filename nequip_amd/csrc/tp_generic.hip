@@ -862,9 +862,25 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
       return NQA_ERR_LAUNCH;
     }
   }
+  // round 6: with more than one (channel chunk, part) per edge the ring kernels add their grad_y sums straight into the
+  // zeroed grad_y (same switch and same caveat as the grad_x accumulator: sums in arrival order) -- no [E, S x chunks] partial
+  // rows, no reduce pass.  Only where a ring kernel is what runs: the unsplit one for either request, the split one with grad_x.
+  const bool gy_atomic = nchunk > 1 && num_edges > 0 && pair_gx_atomic(plan, num_nodes, num_edges) &&
+                         (plan->spec->ring == 1 || (plan->spec->ring == 2 && grad_x != nullptr)) && [] {
+                           const char* er = std::getenv("NQA_PAIR_RING");
+                           return er == nullptr || er[0] != '0';
+                         }();
   if (nchunk == 1) {
     a.gy = static_cast<float*>(grad_y);
     a.gy_stride = plan->dim_in2;
+  } else if (gy_atomic) {
+    if (hipMemsetAsync(grad_y, 0, (size_t)num_edges * plan->dim_in2 * 4, s) != hipSuccess) {
+      set_error("nqa_tp_scatter_bwd_pairs: hipMemsetAsync of grad_y failed");
+      return NQA_ERR_LAUNCH;
+    }
+    a.gy = static_cast<float*>(grad_y);
+    a.gy_stride = plan->dim_in2;
+    a.gy_atomic = 1;
   } else {
     a.gy = static_cast<float*>(workspace);
     a.gy_stride = plan->dim_in2 * nchunk;
@@ -875,7 +891,7 @@ int nqa_tp_scatter_bwd_pairs(const nqa_plan* plan, const void* plan_image, int32
   }
   rc = check_launch("nqa_tp_scatter_bwd_pairs(pairs)");
   if (rc != NQA_OK) return rc;
-  if (nchunk > 1 && num_edges > 0) {
+  if (nchunk > 1 && num_edges > 0 && !gy_atomic) {
     const int64_t total = num_edges * (int64_t)plan->dim_in2;
     hipLaunchKernelGGL(spec_gy_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        static_cast<const float*>(workspace), static_cast<float*>(grad_y), plan->dim_in2, nchunk, total);

@@ -35,6 +35,8 @@ struct SpecArgs {
   int32_t din, dout, wn;
   int32_t gy_stride;
   int32_t gx_atomic;  // which = 4: the other node's grad_x goes into the zeroed accumulator gxe [N, din] by atomics (ring kernel)
+  int32_t gy_atomic;  // which = 4, ring kernels, more than one (chunk, part) per edge: gy is the zeroed grad_y [E, S] itself and
+                      // every wavefront adds its sums to it (no partial rows, no reduce pass)
 };
 
 // which: 0 = fwd, 1 = bwd_edge (+ gxe rows when a.gxe != null), 2 = bwd_x, 3 = per-source sum of the gxe rows,
@@ -241,8 +243,9 @@ __device__ __forceinline__ void spec_mask_dup(T* __restrict__ q, bool own) {
   for (int k = 0; k < K; ++k) q[k] = own ? q[k] : T(0);
 }
 
+// atomic (float, K <= 16 only): add the sums to dst instead of storing them (several wavefronts contribute to one row)
 template <typename T, int K>
-__device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, T* __restrict__ dst, int lane) {
+__device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, T* __restrict__ dst, int lane, bool atomic = false) {
   if constexpr (sizeof(T) != 4 || (K > 16)) {
     spec_wave_reduce_store_each<T, K>(q, dst, lane);
   } else {
@@ -261,7 +264,10 @@ __device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, 
     r2 = r;
     asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r), "+v"(r2));
     r += r2;
-    if (lane < K) dst[lane] = r;
+    if (lane < K) {
+      if (atomic) unsafeAtomicAdd(dst + lane, r);
+      else dst[lane] = r;
+    }
   }
 }
 
