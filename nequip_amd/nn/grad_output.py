@@ -13,6 +13,26 @@ from ._graph_mixin import GraphModuleMixin
 from .model_modifier_utils import model_modifier, replace_submodules
 
 
+# node-wise tensors a chain leaves in the data dictionary (registered node fields + the per-atom energies)
+from ..data import _keys as _data_keys  # noqa: E402
+
+_NODE_OUTPUT_KEYS = frozenset(_data_keys._NODE_FIELDS.values()) | {AtomicDataDict.PER_ATOM_ENERGY_KEY}
+
+
+class _SpatialOrder:
+    """A node permutation kept with the cached topology of the caller's edge list (ForceStressOutput._spatial_order)."""
+
+    def __init__(self, perm: torch.Tensor, rank: torch.Tensor, edge_index: torch.Tensor):
+        self.perm, self.rank, self.edge_index = perm, rank, edge_index  # new -> old, old -> new, relabelled [2, E]
+        self._types = None
+
+    def types_of(self, types: torch.Tensor) -> torch.Tensor:
+        key = (types.data_ptr(), types._version, tuple(types.shape))
+        if self._types is None or self._types[0] != key:
+            self._types = (key, types.index_select(0, self.perm), types)  # (keeps `types` alive: the address cannot be recycled)
+        return self._types[1]
+
+
 class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
     def __init__(self, func: GraphModuleMixin, do_derivatives: bool = True):
         super().__init__()
@@ -137,6 +157,51 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         self.__dict__["_seed_ok"] = (key, ok)
         return ok
 
+    def _spatial_order(self, pos, edge_index, batch, num_batch: int):
+        """Round 6.  The tensor-product kernels walk the nodes in index order, eight XCDs on contiguous index ranges, and gather
+        the rows of each node's neighbours: with atoms numbered along a space-filling curve the nodes in flight on an XCD are a
+        compact blob and their neighbours' rows are re-used out of its L2 while they are there (cu100k: 87.6 -> 83.0 ms with
+        the INPUT sorted that way).  Callers do not sort their atoms, so the model does it for the part of the evaluation
+        that is node-side: a Morton permutation of the atoms is computed once per cached neighbour list, the convolution
+        stack sees a relabelled edge list and permuted atom types -- node rows are then ALLOCATED in curve order -- and
+        node-wise results are permuted back.  Edge-wise tensors (in the caller's edge order), the edge vectors and the
+        force / virial adjoint keep the caller's numbering, so nothing is moved per evaluation except the per-atom results.
+        The model is permutation-equivariant: results differ by summation order only.  cu100k 86.1 -> 83.4 ms; at cfg-3's
+        10 125 atoms the forward gains what the pair kernel loses (its weight / y rows follow the edge order): large boxes only.
+        (Re-ordering the edges as well -- positions gathered, every edge-wise field permuted back -- was measured: 84.6 ms.)
+
+        Single frames of at least NQA_SPATIAL_ORDER_MIN (32 768) atoms whose neighbour list is in the cross-call topology
+        cache (a static list: benchmark loops, MD between list rebuilds); never computed inside a stream capture;
+        NQA_SPATIAL_ORDER=0 switches it off.  Returns None or a _SpatialOrder."""
+        if os.environ.get("NQA_SPATIAL_ORDER", "1") in ("", "0") or num_batch != 1 or not pos.is_cuda:
+            return None
+        n = pos.shape[0]
+        if n < int(os.environ.get("NQA_SPATIAL_ORDER_MIN", "32768") or 32768):
+            return None
+        from ._topology import topology_cache
+
+        if getattr(topology_cache, "_scope", None) is not None:
+            return None  # (per-evaluation topologies: the permutation would be recomputed every call)
+        topo = topology_cache.get(edge_index[0], edge_index[1], n)
+        if getattr(topo, "defer_pairing_verdict", False):
+            return None  # (graphed MD step: a new list inside every replay)
+        sp = getattr(topo, "_spatial", None)
+        if sp is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            with torch.no_grad():
+                q = torch.floor((pos.detach() - pos.detach().min(0).values) / 2.25).to(torch.int64).clamp_(0, 1023)
+                code = torch.zeros(n, dtype=torch.int64, device=pos.device)
+                for bit in range(10):
+                    for ax in range(3):
+                        code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+                perm = torch.sort(code, stable=True).indices
+                rank = torch.empty_like(perm)
+                rank[perm] = torch.arange(n, device=pos.device)
+                ei = rank[edge_index].contiguous()
+            sp = topo._spatial = _SpatialOrder(perm, rank, ei)
+        return sp
+
     def _forward_inference(self, data, pos, batch, num_batch: int, has_cell: bool):
         """First-order (eval mode) evaluation of the same quantities without the strain bookkeeping.
 
@@ -168,7 +233,23 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
                 edge_vec = _EdgeVectorsFn.apply(pos.detach(), cell, edge_index, shift, ebatch)
         edge_vec.requires_grad_(True)
         data[K.EDGE_VECTORS_KEY] = edge_vec
-        data = self.func(data)
+        sp = None if tracing else self._spatial_order(pos, edge_index, batch, num_batch)
+        if sp is None:
+            data = self.func(data)
+        else:
+            # the node-side pipeline runs in a spatially coherent node order (see _spatial_order): relabelled edge list and
+            # permuted atom types in, node fields permuted back out; everything edge-wise keeps the caller's edge order
+            types = data[K.ATOM_TYPE_KEY]
+            data[K.ATOM_TYPE_KEY] = sp.types_of(types)
+            data[K.EDGE_INDEX_KEY] = sp.edge_index
+            data = self.func(data)
+            data[K.ATOM_TYPE_KEY] = types
+            data[K.EDGE_INDEX_KEY] = edge_index
+            n_ = pos.shape[0]
+            for key in list(data.keys()):
+                v = data[key]
+                if key in _NODE_OUTPUT_KEYS and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n_:
+                    data[key] = v.index_select(0, sp.rank)
         with inputs_only_backward():
             pe = data.get(K.PER_ATOM_ENERGY_KEY) if self._energy_seed_allowed() else None
             if (pe is not None and pe.requires_grad and not tracing and pe.dim() == 2 and pe.shape[1] == 1

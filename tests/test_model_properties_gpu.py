@@ -219,3 +219,50 @@ def test_edge_vector_inputs_give_edge_forces(device):
     grad_pos.index_add_(0, ei[0].to(device), -ef)
     f_ref = ref[K.FORCE_KEY].detach().double()
     torch.testing.assert_close(-grad_pos, f_ref, rtol=0, atol=2e-5 * max(1.0, float(f_ref.abs().max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf", [8, 64])
+def test_spatial_node_order_is_invisible_in_the_results(device, monkeypatch, nf):
+    """Round 6: in eval mode the convolution stack of a large single frame runs in a Morton order of the atoms
+    (`ForceStressOutput._spatial_order`: relabelled edge list + permuted types in, node fields permuted back out).  Energy,
+    forces, virial / stress, per-atom energies, node features and the edge-wise fields -- in the CALLER's atom and edge
+    order -- must be what the model gives without it, on a box whose atoms arrive in a shuffled order (so that the
+    permutation is far from the identity); the caller's own tensors come back untouched."""
+    from nequip_amd.data import AtomicDataDict as K
+    from nequip_amd.nn._topology import topology_cache
+    from nequip_amd.utils import synthetic as syn
+
+    pos, types, cell, names = syn.water_box(n_side=5, seed=2)  # 375 atoms
+    rng = np.random.default_rng(0)
+    shuffle = rng.permutation(len(pos))
+    pos, types = np.asarray(pos)[shuffle], np.asarray(types)[shuffle]
+    model = _model(device, names, parity=False, nf=nf, num_layers=3)
+    data0 = syn.make_data(pos, types, 4.0, cell)
+
+    def run(flag):
+        monkeypatch.setenv("NQA_SPATIAL_ORDER", flag)
+        monkeypatch.setenv("NQA_SPATIAL_ORDER_MIN", "1")
+        topology_cache.clear()
+        data = {k: v.clone().to(device) for k, v in data0.items()}
+        out = model(data)
+        assert torch.equal(out[K.EDGE_INDEX_KEY], data0[K.EDGE_INDEX_KEY].to(device))       # the caller's list is handed back
+        assert torch.equal(out[K.ATOM_TYPE_KEY].cpu().view(-1), data0[K.ATOM_TYPE_KEY].view(-1))
+        got = {k: out[k].detach().double().cpu() for k in (K.TOTAL_ENERGY_KEY, K.FORCE_KEY, K.VIRIAL_KEY, K.STRESS_KEY,
+                                                           K.PER_ATOM_ENERGY_KEY, K.EDGE_VECTORS_KEY, K.EDGE_ATTRS_KEY)}
+        for k in (K.NODE_FEATURES_KEY, K.NODE_ATTRS_KEY):  # (whatever node-wise tensors the chain leaves behind)
+            if k in out and torch.is_tensor(out[k]):
+                got[k] = out[k].detach().double().cpu()
+        return got
+
+    plain, ordered = run("0"), run("1")
+    for k in plain:
+        scale = max(1.0, float(plain[k].abs().max()))
+        assert float((plain[k] - ordered[k]).abs().max()) <= 2e-5 * scale, k
+    # ... and the permutation really was applied (a second evaluation re-uses the cached one)
+    monkeypatch.setenv("NQA_SPATIAL_ORDER", "1")
+    data = {k: v.clone().to(device) for k, v in data0.items()}
+    model(data)
+    ei = data[K.EDGE_INDEX_KEY]
+    sp = getattr(topology_cache.get(ei[0], ei[1], len(pos)), "_spatial", None)
+    assert sp is not None and not torch.equal(sp.perm.cpu(), torch.arange(len(pos)))
