@@ -198,14 +198,18 @@ __device__ __forceinline__ double spec_wave_sum(double v) {
 // Reduce K per-lane values over the wavefront and store the K sums to dst[0..K).
 // Generic form: one full wave reduction per value (K * ~13 VALU instructions).
 template <typename T, int K>
-__device__ __forceinline__ void spec_wave_reduce_store_each(const T* __restrict__ q, T* __restrict__ dst, int lane) {
+__device__ __forceinline__ void spec_wave_reduce_store_each(const T* __restrict__ q, T* __restrict__ dst, int lane,
+                                                            bool atomic = false) {
   T mine = T(0);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const T r = spec_wave_sum(q[j]);
     if (lane == j) mine = r;
   }
-  if (lane < K) dst[lane] = mine;
+  if (lane < K) {
+    if (atomic) unsafeAtomicAdd(dst + lane, mine);
+    else dst[lane] = mine;
+  }
 }
 
 template <int CTRL>
@@ -243,11 +247,11 @@ __device__ __forceinline__ void spec_mask_dup(T* __restrict__ q, bool own) {
   for (int k = 0; k < K; ++k) q[k] = own ? q[k] : T(0);
 }
 
-// atomic (float, K <= 16 only): add the sums to dst instead of storing them (several wavefronts contribute to one row)
+// atomic: add the sums to dst instead of storing them (several wavefronts contribute to one row)
 template <typename T, int K>
 __device__ __forceinline__ void spec_wave_reduce_store(const T* __restrict__ q, T* __restrict__ dst, int lane, bool atomic = false) {
   if constexpr (sizeof(T) != 4 || (K > 16)) {
-    spec_wave_reduce_store_each<T, K>(q, dst, lane);
+    spec_wave_reduce_store_each<T, K>(q, dst, lane, atomic);
   } else {
     constexpr int KA = (K + 1) / 2, KB = (KA + 1) / 2, KC = (KB + 1) / 2;
     float a[KA], b[KB], c[KC], d[1];
