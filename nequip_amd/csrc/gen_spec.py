@@ -1434,7 +1434,10 @@ def _emit(st: Structure) -> str:
         A("  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));")
         A("  const int mul = a.mul;  // a multiple of 64 (the launcher sends other multiplicities to bwd_pair_kernel)")
         A("  const int nchunk = mul >> 6;")
-        A("  const int64_t witem = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
+        if os.environ.get("NQA_GEN_RING_NO_XCD_REMAP", "0") != "0":  # lab: workgroups in dispatch order (round-robin over the XCDs)
+            A("  const int64_t witem = (int64_t)blockIdx.x * 4 + wid;")
+        else:
+            A("  const int64_t witem = (int64_t)spec_xcd_remap(blockIdx.x, gridDim.x) * 4 + wid;")
         A("  const int64_t item = witem / WPN;")
         A("  const int wsub = (int)(witem - item * WPN);")
         A("  const bool valid = item < (int64_t)a.N * nchunk;  // (WPN < 4: the last workgroup may hold idle wavefronts)")
