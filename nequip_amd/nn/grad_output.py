@@ -239,11 +239,13 @@ class ForceStressOutput(GraphModuleMixin, torch.nn.Module):
         else:
             # the node-side pipeline runs in a spatially coherent node order (see _spatial_order): relabelled edge list and
             # permuted atom types in, node fields permuted back out; everything edge-wise keeps the caller's edge order
-            types = data[K.ATOM_TYPE_KEY]
-            data[K.ATOM_TYPE_KEY] = sp.types_of(types)
+            types = data.get(K.ATOM_TYPE_KEY)
+            if types is not None:
+                data[K.ATOM_TYPE_KEY] = sp.types_of(types)
             data[K.EDGE_INDEX_KEY] = sp.edge_index
             data = self.func(data)
-            data[K.ATOM_TYPE_KEY] = types
+            if types is not None:
+                data[K.ATOM_TYPE_KEY] = types
             data[K.EDGE_INDEX_KEY] = edge_index
             n_ = pos.shape[0]
             for key in list(data.keys()):

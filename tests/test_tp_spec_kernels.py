@@ -214,7 +214,9 @@ def test_spec_kernels_large_degree_and_wave_split(device, mul):
 # the three forms of the pair-centric backward for multiples of 64 channels (round 6; both switches are read at every call):
 # the LDS-ring kernel with the other node's grad_x in an atomically summed accumulator (default), the ring kernel with one
 # row per pair + the fixed-order row sum, and the register kernel of rounds 3-5
-PAIR_FORMS = {"ring_atomic": {}, "ring_rows": {"NQA_PAIR_GX_ATOMIC": "0"}, "registers": {"NQA_PAIR_RING": "0"}}
+PAIR_FORMS = {"ring_atomic": {"NQA_PAIR_RING": "1", "NQA_PAIR_GX_ATOMIC": "1"},  # (explicit: the suite may run under either switch)
+              "ring_rows": {"NQA_PAIR_RING": "1", "NQA_PAIR_GX_ATOMIC": "0"},
+              "registers": {"NQA_PAIR_RING": "0", "NQA_PAIR_GX_ATOMIC": "1"}}
 
 
 @pytest.mark.gpu
