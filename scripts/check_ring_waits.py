@@ -10,6 +10,10 @@ worth of each in the steady state.  hipcc does not see the copies (inline asm), 
     would drain the ring every iteration (correct, but the kernel would be the register kernel again);
   * M0 is written only by the copy statements.
 
+Checked: every `bwd_pair_ring_kernel` instantiation of every structure.  NOT checked: `bwd_pair_split_ring_kernel` (l_max 3: one
+loop per part inside a switch; its two heaviest parts spill 4-6 registers, whose scratch reloads are compiler waits inside
+the loop -- known, measured with them: cu100k 34.5 -> 30.7 ms).
+
     python scripts/check_ring_waits.py [csrc/build]      # the objects of the last build; exit code 1 on a violation
 """
 import os
