@@ -1095,6 +1095,9 @@ def _emit(st: Structure) -> str:
     # so every value becomes a pair (.x = in, .y = out): G[k] = (g_o[k], g_j[k]), X[i] = (x_j[i], x_o[i]), Y = (y_in, y_out),
     # the weight is shared.  One packed stream evaluates both edges; the owner-side intermediates T_ij(g_o) that the scalar
     # kernel hoisted out of the pair loop (~115 registers) are recomputed for free in the .x halves.
+    # OUTCOME (profiles/r6_pk_rate_and_packed_pair_call2.txt): 561 vs 575 us -- a v_pk_fma_f32 takes twice the passes of a
+    # v_fma_f32 (5.1 vs 2.6 cycles per wavefront instruction), the part reaches its fp32 rate without packing, and the first
+    # reading above was wrong about what bounds the kernel (see the LDS-ring section below).  Lab only: NQA_GEN_PAIR_PK=1.
     if pair_ok and os.environ.get("NQA_GEN_PAIR_PK", "0") != "0":
         pk_occ = os.environ.get("NQA_GEN_PAIR_PK_OCC", "2")
         pk_prefetch = os.environ.get("NQA_GEN_PAIR_PK_PREFETCH", "0") != "0"
@@ -1284,7 +1287,7 @@ def _emit(st: Structure) -> str:
         A("}")
 
     # ------------------------------------------------------------------ pair-centric backward, LDS ring (round 6)
-    # What held bwd_pair_kernel at half of the HBM roof (profiles/r6_pair_*.txt, r6_memonly_*.txt): one pair in flight per
+    # What held bwd_pair_kernel at half of the HBM roof (profiles/r6_pair_*.txt, r6_lab_call4.txt ... call7.txt; index: profiles/README_r6.md): one pair in flight per
     # wavefront at two wavefronts per SIMD.  The same loop WITHOUT its arithmetic takes 85 % of the kernel's time, with every
     # stream pointed at cache-hot rows still 42 % -- it is the serial chain indices -> row loads -> arithmetic -> stores of
     # each pair, 8 of them per CU, not bandwidth and not the vector ALU; a second operand set in registers spills (254 used).
